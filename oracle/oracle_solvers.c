@@ -1,0 +1,302 @@
+/*
+ * oracle_solvers.c -- CPU restatement of the three solver loops of the path.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  Citations are into /root/reference.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static double *dalloc(int n)
+{
+    return (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+}
+
+/* =========================================================================
+ * bicstab_omp/bicstab.cpp:93-196  BiCG  (the directory says "bicstab" but the
+ * algorithm is bi-conjugate gradient with A^T).
+ * ========================================================================= */
+
+/* bicstab.cpp:35-66 Transpose2: counting sort by column.  With int_transpose
+ * the value travels through an `int` exactly as `V = A.Value[j]` does (:37,57),
+ * i.e. truncation toward zero (defect D6).  0-based, like the program. */
+static void transpose2(int n, int nz, const int *rp, const int *ci, const double *v,
+                       int *trp, int *tci, double *tv, int int_transpose)
+{
+    memset(trp, 0, sizeof(int) * (size_t)(n + 1));
+    for (int i = 0; i < nz; i++)
+        trp[ci[i] + 1]++;
+    int S = 0;
+    for (int i = 1; i <= n; i++) {
+        int tmp = trp[i];
+        trp[i] = S;
+        S += tmp;
+    }
+    for (int i = 0; i < n; i++) {
+        for (int j = rp[i]; j < rp[i + 1]; j++) {
+            double V = int_transpose ? (double)(int)v[j] : v[j];
+            int r = ci[j];
+            int pos = trp[r + 1];
+            tv[pos] = V;
+            tci[pos] = i;
+            trp[r + 1]++;
+        }
+    }
+}
+
+int orc_bicg(int n, const int *rp_in, const int *ci_in, const double *v,
+             const double *b, double *x, int maxit, double eps,
+             int int_transpose, int parallel_vec, int *iters)
+{
+    /* the reference program is 0-based (bicstab.cpp:198-214); rebase if needed */
+    const int base = rp_in[0];
+    const int nz = rp_in[n] - base;
+    int *rp = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    int *ci = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));
+    for (int i = 0; i <= n; i++) rp[i] = rp_in[i] - base;
+    for (int i = 0; i < nz; i++) ci[i] = ci_in[i] - base;
+
+    int *trp = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    int *tci = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));
+    double *tv = (double *)malloc(sizeof(double) * (size_t)(nz > 0 ? nz : 1));
+    transpose2(n, nz, rp, ci, v, trp, tci, tv, int_transpose);          /* :99  */
+
+    double *R = dalloc(n), *biR = dalloc(n), *nR = dalloc(n), *nbiR = dalloc(n);
+    double *P = dalloc(n), *biP = dalloc(n), *nP = dalloc(n), *nbiP = dalloc(n);
+    double *multAP = dalloc(n), *multAtbiP = dalloc(n), *tmp;
+    double alfa, beta, numerator, denominator, check, norm;
+    int i, iter;
+
+    norm = sqrt(orc_dot(n, b, b));                                      /* :135 */
+    for (i = 0; i < n; i++) x[i] = 1.0;                                 /* :139 */
+    orc_spmv(n, rp, ci, v, x, multAP);                                  /* :142 */
+    for (i = 0; i < n; i++)
+        R[i] = biR[i] = P[i] = biP[i] = b[i] - multAP[i];               /* :144 */
+
+    for (iter = 0; iter < maxit; iter++) {                              /* :146 */
+        orc_spmv(n, rp, ci, v, P, multAP);                              /* :147 */
+        orc_spmv(n, trp, tci, tv, biP, multAtbiP);                      /* :148 */
+        numerator = orc_dot(n, biR, R);                                 /* :149 */
+        denominator = orc_dot(n, biP, multAP);                          /* :150 */
+        alfa = numerator / denominator;                                 /* :151 */
+#pragma omp parallel for schedule(static) if (parallel_vec)
+        for (i = 0; i < n; i++) nR[i] = R[i] - alfa * multAP[i];        /* :152 */
+#pragma omp parallel for schedule(static) if (parallel_vec)
+        for (i = 0; i < n; i++) nbiR[i] = biR[i] - alfa * multAtbiP[i]; /* :154 */
+        denominator = numerator;                                        /* :156 */
+        numerator = orc_dot(n, nbiR, nR);                               /* :157 */
+        beta = numerator / denominator;                                 /* :158 */
+#pragma omp parallel for schedule(static) if (parallel_vec)
+        for (i = 0; i < n; i++) nP[i] = nR[i] + beta * P[i];            /* :159 */
+#pragma omp parallel for schedule(static) if (parallel_vec)
+        for (i = 0; i < n; i++) nbiP[i] = nbiR[i] + beta * biP[i];      /* :161 */
+        /* the test uses the OLD R and leaves before x is updated (:164-166) */
+        check = sqrt(orc_dot(n, R, R)) / norm;                          /* :164 */
+        if (check < eps) break;                                         /* :165 */
+#pragma omp parallel for schedule(static) if (parallel_vec)
+        for (i = 0; i < n; i++) x[i] += alfa * P[i];                    /* :167 */
+        tmp = R; R = nR; nR = tmp;                                      /* :170 */
+        tmp = P; P = nP; nP = tmp;
+        tmp = biR; biR = nbiR; nbiR = tmp;
+        tmp = biP; biP = nbiP; nbiP = tmp;                              /* :181 */
+    }
+    if (iters) *iters = iter;
+
+    free(R); free(biR); free(nR); free(nbiR);
+    free(P); free(biP); free(nP); free(nbiP);
+    free(multAP); free(multAtbiP);
+    free(trp); free(tci); free(tv); free(rp); free(ci);
+    return 0;
+}
+
+/* =========================================================================
+ * pbicgstab.cu:45-154  gpu_pbicgstab : right-preconditioned BiCGSTAB, M = LU
+ * from ILU(0) (or M = I when vm == NULL).  Every cuBLAS/cuSPARSE call of the
+ * reference appears as one call below, in the reference's order.
+ * ========================================================================= */
+static void precond_apply(int n, const int *rp, const int *ci, const double *vm,
+                          const double *in, double *t, double *out)
+{
+    if (vm) {
+        orc_trsv_lower_unit(n, rp, ci, vm, in, t);   /* :92-94  / :121-123 */
+        orc_trsv_upper(n, rp, ci, vm, t, out);       /* :96-98  / :125-127 */
+    } else {
+        memcpy(t, in, sizeof(double) * (size_t)n);   /* L = I */
+        memcpy(out, t, sizeof(double) * (size_t)n);  /* U = I */
+    }
+}
+
+int orc_pbicgstab(int n, const int *rp, const int *ci, const double *a,
+                  const double *vm, const double *f, double *x,
+                  int maxit, double tol, double *hist, int hist_cap,
+                  orc_stats *st)
+{
+    double *r = dalloc(n), *rw = dalloc(n), *p = dalloc(n), *pw = dalloc(n);
+    double *s = dalloc(n), *t = dalloc(n), *v = dalloc(n);
+    double rho, rhop, beta, alpha = 0.0, negalpha, omega = 0.0, negomega, temp, temp2;
+    double nrmr = 0.0, nrmr0;
+    int i = 0, half_exit = 0, converged = 0;
+    rho = 0.0;
+
+    orc_csrmv(n, rp, ci, a, 1.0, x, 0.0, r);                 /* :67  r = A x      */
+    orc_scal(n, -1.0, r);                                     /* :69               */
+    orc_axpy(n, 1.0, f, r);                                   /* :70  r = f - A x  */
+    memcpy(rw, r, sizeof(double) * (size_t)n);                /* :72               */
+    memcpy(p, r, sizeof(double) * (size_t)n);                 /* :73               */
+    nrmr0 = orc_nrm2(n, r);                                   /* :74               */
+    nrmr = nrmr0;
+
+    for (i = 0; i < maxit;) {                                 /* :79               */
+        rhop = rho;                                           /* :80               */
+        rho = orc_dot(n, rw, r);                              /* :81               */
+        if (i > 0) {                                          /* :83               */
+            beta = (rho / rhop) * (alpha / omega);            /* :84               */
+            negomega = -omega;
+            orc_axpy(n, negomega, v, p);                      /* :86               */
+            orc_scal(n, beta, p);                             /* :87               */
+            orc_axpy(n, 1.0, r, p);                           /* :88               */
+        }
+        precond_apply(n, rp, ci, vm, p, t, pw);               /* :92-98            */
+        orc_csrmv(n, rp, ci, a, 1.0, pw, 0.0, v);             /* :104 v = A pw     */
+        temp = orc_dot(n, rw, v);                             /* :106              */
+        alpha = rho / temp;                                   /* :107              */
+        negalpha = -alpha;
+        orc_axpy(n, negalpha, v, r);                          /* :109              */
+        orc_axpy(n, alpha, pw, x);                            /* :110              */
+        nrmr = orc_nrm2(n, r);                                /* :111              */
+        if (hist && 2 * i < hist_cap) hist[2 * i] = nrmr;
+        if (nrmr < tol * nrmr0) {                             /* :116              */
+            half_exit = 1; converged = 1;
+            break;
+        }
+        precond_apply(n, rp, ci, vm, r, t, s);                /* :121-127          */
+        orc_csrmv(n, rp, ci, a, 1.0, s, 0.0, t);              /* :132 t = A s      */
+        temp = orc_dot(n, t, r);                              /* :135              */
+        temp2 = orc_dot(n, t, t);                             /* :136              */
+        omega = temp / temp2;                                 /* :137              */
+        negomega = -omega;
+        orc_axpy(n, omega, s, x);                             /* :139              */
+        orc_axpy(n, negomega, t, r);                          /* :140              */
+        nrmr = orc_nrm2(n, r);                                /* :142              */
+        if (hist && 2 * i + 1 < hist_cap) hist[2 * i + 1] = nrmr;
+        if (nrmr < tol * nrmr0) {                             /* :147              */
+            i++;
+            converged = 1;
+            break;
+        }
+        i++;                                                  /* :151              */
+    }
+    if (st) {
+        st->iters = i; st->half_exit = half_exit; st->converged = converged;
+        st->breakdown = 0; st->nrm0 = nrmr0; st->nrm = nrmr;
+    }
+    free(r); free(rw); free(p); free(pw); free(s); free(t); free(v);
+    return 1; /* the reference path always reports success (pbicgstab.cu:408) */
+}
+
+/* =========================================================================
+ * pbicgstab.cu:581-754  gpu_pbicgstab2 (d variant).  With d == NULL the
+ * mult_spec terms vanish, which is the intended maths of the plain variant
+ * (:425-578) whose `r += b; r0 = r` lines are commented out (:471-478, D1).
+ * The copy/scal/axpy triplets are kept exactly as the reference issues them.
+ * ========================================================================= */
+static void shifted_mv(int n, const int *rp, const int *ci, const double *a0,
+                       const double *d, double k, double alpha,
+                       const double *x, double *y)
+{
+    if (d) {
+        orc_mult_spec(n, x, d, k, y);                    /* :645 / :675 / :703 */
+        orc_csrmv(n, rp, ci, a0, alpha, x, 1.0, y);      /* :646 / :676 / :704 */
+    } else {
+        orc_csrmv(n, rp, ci, a0, alpha, x, 0.0, y);      /* :469 / :501 / :528 */
+    }
+}
+
+int orc_pbicgstab2(int n, const int *rp, const int *ci, const double *a0,
+                   const double *d, const double *x0_in, const double *b,
+                   int maxit, double tol, double *x, double *hist, int hist_cap,
+                   orc_stats *st)
+{
+    const size_t nb = sizeof(double) * (size_t)n;
+    double *x0 = dalloc(n), *r0 = dalloc(n), *r = dalloc(n), *r_ = dalloc(n);
+    double *v = dalloc(n), *v_ = dalloc(n), *p = dalloc(n), *p_ = dalloc(n);
+    double *s = dalloc(n), *t = dalloc(n), *h = dalloc(n);
+    double omega = 1, alpha = 1, beta = 0, rho = 1, rho_ = rho;   /* :614-618 */
+    double norm0, norm = 0.0;
+    int result = 0, breakdown = 0, converged = 0, it = 0;
+    (void)beta;
+
+    memcpy(x0, x0_in, nb);
+    memset(x, 0, nb);                                             /* :1001 */
+
+    shifted_mv(n, rp, ci, a0, d, -1.0, -1.0, x0, r);              /* :645-646 */
+    orc_axpy(n, 1.0, b, r);                                       /* :649 */
+    memcpy(r0, r, nb);                                            /* :652 */
+    norm0 = orc_nrm2(n, r);                                       /* :655 */
+    norm = norm0;
+
+    for (int i = 0; i < maxit; i++) {                             /* :662 */
+        it = i;
+        rho_ = orc_dot(n, r0, r);                                 /* :665 */
+        beta = (rho_ / rho) * (alpha / omega);                    /* :666 */
+        double momega = -omega;
+        memcpy(p_, v, nb);                                        /* :668 */
+        orc_scal(n, momega, p_);                                  /* :669 */
+        orc_axpy(n, 1.0, p, p_);                                  /* :670 */
+        orc_scal(n, beta, p_);                                    /* :671 */
+        orc_axpy(n, 1.0, r, p_);                                  /* :672 */
+
+        shifted_mv(n, rp, ci, a0, d, 1.0, 1.0, p_, v_);           /* :675-676 */
+
+        double dot_r_v = orc_dot(n, r0, v_);                      /* :688 */
+        alpha = rho_ / dot_r_v;                                   /* :689 */
+        double malpha = -alpha;
+
+        memcpy(h, p_, nb);                                        /* :694 */
+        orc_scal(n, alpha, h);                                    /* :695 */
+        orc_axpy(n, 1.0, x0, h);                                  /* :696 */
+
+        memcpy(s, v_, nb);                                        /* :698 */
+        orc_scal(n, malpha, s);                                   /* :699 */
+        orc_axpy(n, 1.0, r, s);                                   /* :700 */
+
+        shifted_mv(n, rp, ci, a0, d, 1.0, 1.0, s, t);             /* :703-704 */
+
+        double num = orc_dot(n, t, s);                            /* :708 */
+        double denum = orc_dot(n, t, t);                          /* :709 */
+        omega = num / denum;                                      /* :710 */
+        momega = -omega;
+
+        memcpy(x, s, nb);                                         /* :714 */
+        orc_scal(n, omega, x);                                    /* :715 */
+        orc_axpy(n, 1.0, h, x);                                   /* :716 */
+
+        memcpy(r_, t, nb);                                        /* :718 */
+        orc_scal(n, momega, r_);                                  /* :719 */
+        orc_axpy(n, 1.0, s, r_);                                  /* :720 */
+
+        norm = orc_nrm2(n, r_);                                   /* :723 */
+        if (hist && i < hist_cap) hist[i] = norm;
+        it = i + 1;
+        if (norm < tol * norm0) {                                 /* :730 */
+            result = 1; converged = 1;
+            break;
+        }
+        if (fabs(omega) < 1e-5 || isnan(omega)) {                 /* :735 */
+            breakdown = 1;
+            break;
+        }
+        memcpy(r, r_, nb);                                        /* :744 */
+        memcpy(p, p_, nb);                                        /* :745 */
+        memcpy(v, v_, nb);                                        /* :746 */
+        memcpy(x0, x, nb);                                        /* :747 */
+        rho = rho_;                                               /* :748 */
+    }
+    if (st) {
+        st->iters = it; st->half_exit = 0; st->converged = converged;
+        st->breakdown = breakdown; st->nrm0 = norm0; st->nrm = norm;
+    }
+    free(x0); free(r0); free(r); free(r_); free(v); free(v_);
+    free(p); free(p_); free(s); free(t); free(h);
+    return result;
+}
