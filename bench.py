@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- BiCGSTAB iterations/s + SpMV effective HBM GB/s on the 10M-row CSR workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[3], the config the metric is quoted on; fits one GPU):
+synthetic random CSR, 1e7 x 1e7, 50 nnz/row, fp64 values / int32 indices, generated in HBM
+(SURVEY 8d), b = A x*, x0 = 1, no preconditioner, row-sharded over N GPUs (strong scaling:
+the matrix is fixed, each rank owns n/N rows).  A "step" is one BiCGSTAB iteration = both
+half steps = 2 SpMV + 3 fused vector kernels (+ 2 all-gathers, 3 all-reduces when N > 1).
+The stopping tests are evaluated every step but not taken (CUDAMAT_FLAG_NO_EXIT), and the
+solve restarts from x0 = 1 every 25 steps so the residual stays far from underflow; each
+restart's extra SpMV is inside the timed region and not counted as a step.
+
+Output: ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+CHUNK = 25              # steps per restart
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="rand50", choices=["rand50", "poisson5"])
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--per-row", type=int, default=50)
+    ap.add_argument("--precond", default="none", choices=["none", "ilu0"])
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000)
+    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """the reference's CPU path (bicstab_omp BiCG, bicstab.cpp:93-196) as restated by the
+    oracle, faithful threading (SpMV + dot parallel, vector loops serial), timed on this
+    host on a bounded sample of the same workload: the first --cpu-rows rows' worth of the
+    same generator at the same nnz/row.  BiCG, like BiCGSTAB, costs 2 SpMV per iteration."""
+    import numpy as np
+    from oracle import oracle as O
+    n = args.cpu_rows
+    if args.workload == "poisson5":
+        nx = 1000
+        A = O.poisson5(nx, n // nx)
+        n = A.n
+    else:
+        A = O.rand_rows(n, args.per_row, args.seed)
+    b = O.spmv(A, O.xstar(n, args.seed + 1))
+    t0 = time.perf_counter()
+    x, it = O.bicg(A, b, maxit=args.cpu_iters, eps=0.0)
+    dt = time.perf_counter() - t0
+    it = max(it, 1)
+    scale = args.rows / float(n)
+    return {
+        "value": it / dt / scale, "unit": "iter/s", "cores": O.num_threads(), "kind": "port",
+        "sample": "oracle BiCG restatement of bicstab_omp (2 SpMV/iter; SpMV+dot OpenMP, vector loops "
+                  "serial as in the reference), %d iterations (incl. its A^T build) on a %d-row x %d nnz/row "
+                  "sample of the same generator; iter/s divided by %g to the %d-row size"
+                  % (it, n, args.per_row if args.workload == "rand50" else 5, scale, args.rows),
+        "sample_seconds": dt,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import cuda_mat_amd as cm
+    from cuda_mat_amd.dist import TorchComm, shard_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.rows
+    if args.workload == "poisson5":
+        nx = 4000
+        ny = n // nx
+        n = nx * ny
+    row0, row1, per = shard_rows(n, world, rank)
+    nloc = row1 - row0
+
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = cm.Context(local_rank, stream=stream.cuda_stream)
+        # ---- generate this rank's row block in HBM
+        if args.workload == "rand50":
+            rn = cm.lib().cudamat_rand_row_nnz(n, args.per_row)
+            nnz = nloc * rn
+            rp = torch.empty(nloc + 1, dtype=torch.int32, device=dev)
+            ci = torch.empty(nnz, dtype=torch.int32, device=dev)
+            va = torch.empty(nnz, dtype=torch.float64, device=dev)
+            ctx.gen_rand_rows(n, args.per_row, args.seed, row0, row1, 0, rp, ci, va)
+        else:
+            rp = torch.empty(nloc + 1, dtype=torch.int32, device=dev)
+            tmp_nnz = 5 * nloc
+            ci = torch.empty(tmp_nnz, dtype=torch.int32, device=dev)
+            va = torch.empty(tmp_nnz, dtype=torch.float64, device=dev)
+            ctx.gen_poisson5(nx, ny, row0, row1, 0, rp, ci, va)
+            nnz = int(rp[-1].item())
+        solver = cm.Solver(ctx, nloc, n, nnz, rp, ci, va, 0)
+        del rp, ci, va
+        torch.cuda.empty_cache()
+        comm = None
+        if world > 1:
+            comm = TorchComm(device=dev)
+            solver.set_comm(comm.struct)
+        xs = torch.empty(nloc, dtype=torch.float64, device=dev)
+        b = torch.empty(nloc, dtype=torch.float64, device=dev)
+        x = torch.empty(nloc, dtype=torch.float64, device=dev)
+        ctx.gen_xstar(row0, row1, args.seed + 1, xs)
+        solver.spmv(xs, b)                    # b = A x*
+        precond = cm.PRECOND_ILU0 if args.precond == "ilu0" else cm.PRECOND_NONE
+        if precond:
+            solver.ilu0()
+        flags = cm.FLAG_NO_EXIT | cm.FLAG_X0_ONES
+
+        def run(steps, fl):
+            ms_spmv, n_spmv, ms_trsv, n_trsv = 0.0, 0, 0.0, 0
+            left = steps
+            while left > 0:
+                k = min(left, CHUNK)
+                st = solver.solve(b, x, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=k, tol=1e-8, flags=fl)
+                assert st.iters == k, (st.iters, k)
+                ms_spmv += st.ms_spmv
+                n_spmv += st.n_spmv
+                ms_trsv += st.ms_trsv
+                n_trsv += st.n_trsv
+                left -= k
+            return ms_spmv, n_spmv, ms_trsv, n_trsv, st
+
+        def barrier():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        # ---- correctness gate: with the real stopping rule the solve must converge to x*
+        st = solver.solve(b, x, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8,
+                          flags=cm.FLAG_X0_ONES)
+        err = float((x - xs).abs().max().item())
+        assert st.converged and err < 1e-6, "parity gate failed: converged=%d max|x-x*|=%g" % (st.converged, err)
+        conv_iters = st.iters
+
+        run(args.warmup, flags)
+        barrier()
+        t0 = time.perf_counter()
+        ms_spmv, n_spmv, ms_trsv, n_trsv, st = run(args.steps, flags | cm.FLAG_PROFILE)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+
+    its = args.steps / dt
+    spmv_ms = ms_spmv / max(n_spmv, 1)
+    # algorithmic bytes of one local SpMV launch: values+colidx, rowptr, x once, y once
+    b_spmv = 12.0 * nnz + 4.0 * (nloc + 1) + 8.0 * n + 8.0 * nloc
+    achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    vec_bytes = 144.0 * nloc
+    if rank == 0:
+        out = {
+            "metric": "BiCGSTAB iterations/s (1e7-row CSR, 50 nnz/row, fp64)" if args.workload == "rand50"
+                      else "BiCGSTAB iterations/s (5-pt Poisson CSR)",
+            "value": its, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s n=%d nnz=%d%s, x0=1, b=A*xstar, %s, row-sharded x%d"
+                                   % (args.workload, n, nnz * world if args.workload == "rand50" else nnz,
+                                      "/rank" if (world > 1 and args.workload != "rand50") else "",
+                                      "ILU(0)" if precond else "no preconditioner", world),
+                       "rows": n, "nnz_per_rank": nnz, "parallelism": "rows/%d" % world,
+                       "converges_in_iters": conv_iters},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_spmv, "avg_launch_ms": spmv_ms,
+                         "launches_timed": n_spmv,
+                         "iteration_bytes": 2 * b_spmv + vec_bytes,
+                         "iteration_frac": (2 * b_spmv + vec_bytes) * its / 1e9 / HBM_PEAK_GBS},
+            "spmv_gbs": achieved,
+        }
+        if precond:
+            out["trsv_ms_per_apply"] = ms_trsv / max(n_trsv / 2, 1)
+            out["levels"] = [st.n_levels_l, st.n_levels_u]
+        if world == 1 and args.cpu_baseline != "off":
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    solver.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+// common.h -- internal declarations shared by the HIP translation units of
+// libcudamat_hip.so.  gfx950 only; wave = 64.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "cudamat.h"
+
+namespace cm {
+
+void set_error(const char *fmt, ...);
+int fail_hip(hipError_t e, const char *what, const char *file, int line);
+
+#define CM_HIP(expr)                                                        \
+    do {                                                                    \
+        hipError_t e__ = (expr);                                            \
+        if (e__ != hipSuccess) return cm::fail_hip(e__, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define CM_TRY(expr)                          \
+    do {                                      \
+        int rc__ = (expr);                    \
+        if (rc__ != CUDAMAT_OK) return rc__;  \
+    } while (0)
+
+#define CM_ARG(cond, msg)                     \
+    do {                                      \
+        if (!(cond)) {                        \
+            cm::set_error("bad argument: %s", msg); \
+            return CUDAMAT_ERR_ARG;           \
+        }                                     \
+    } while (0)
+
+constexpr int kBlock = 256;          // threads per workgroup (4 waves)
+constexpr int kMaxParts = 2048;      // upper bound on partial sums per reduction stage
+constexpr int kVecGridMax = 1024;    // workgroups of a streaming vector kernel
+constexpr int kSpmvGridMax = 2048;   // workgroups of an SpMV launch (256 CUs x 8)
+
+// A scalar that lives on the device: either `count` per-workgroup partial sums
+// (interleaved with stride `stride`, summed in a fixed order by every consumer
+// workgroup) or, when count == 0, one already reduced value (sharded runs: the
+// partials were summed by reduce_parts and all-reduced across ranks).
+struct ScalarSrc {
+    const double *ptr;
+    int count;
+    int stride;
+};
+
+// Device-side state of one solve.  Lives in HBM; every kernel of the loop reads
+// `state` first and returns at once when it is non-zero ("freeze on exit"), so
+// kernels enqueued past the stopping point change nothing.
+struct LoopState {
+    int state;       // 0 running, 1 half-step exit, 2 full-step exit, 3 omega breakdown
+    int it;          // the reference's loop counter i
+    int pad[2];
+    double rho[2];   // rho of iteration it (slot it&1) and it-1
+    double alpha;
+    double omega;
+    double nrm0;
+    double tolabs;   // tol * nrm0
+    double nrm;      // last residual norm evaluated
+};
+
+enum Check { CHECK_NONE = 0, CHECK_HALF = 1, CHECK_FULL = 2 };
+
+}  // namespace cm
+
+struct cudamat_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    double *parts;   // kMaxParts * 2 doubles scratch for the standalone dot/nrm2
+};

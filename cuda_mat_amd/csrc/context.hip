@@ -1,0 +1,251 @@
+// context.hip -- error reporting, context, device memory helpers, timers and the
+// elementary-kernel entry points of the C ABI (include/cudamat.h).
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "kernels.h"
+
+namespace cm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail_hip(hipError_t e, const char *what, const char *file, int line)
+{
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    return CUDAMAT_ERR_HIP;
+}
+
+}  // namespace cm
+
+using namespace cm;
+
+extern "C" int cudamat_version(void) { return CUDAMAT_VERSION; }
+extern "C" const char *cudamat_last_error(void) { return g_err; }
+
+extern "C" int cudamat_device_count(int *count)
+{
+    CM_ARG(count, "count is NULL");
+    *count = 0;
+    CM_HIP(hipGetDeviceCount(count));
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_ctx_create(int device, void *stream, cudamat_ctx **out)
+{
+    CM_ARG(out, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    CM_HIP(hipGetDeviceCount(&count));
+    if (count <= 0) {
+        set_error("no HIP device visible: libcudamat_hip has no CPU fallback");
+        return CUDAMAT_ERR_HIP;
+    }
+    CM_ARG(device >= 0 && device < count, "device index out of range");
+    CM_HIP(hipSetDevice(device));
+    cudamat_ctx *c = (cudamat_ctx *)calloc(1, sizeof(cudamat_ctx));
+    if (!c) return CUDAMAT_ERR_NOMEM;
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { free(c); return fail_hip(e, "hipStreamCreate", __FILE__, __LINE__); }
+        c->own_stream = true;
+    }
+    hipError_t e = hipMalloc((void **)&c->parts, sizeof(double) * 2 * kMaxParts);
+    if (e != hipSuccess) {
+        if (c->own_stream) hipStreamDestroy(c->stream);
+        free(c);
+        return fail_hip(e, "hipMalloc(parts)", __FILE__, __LINE__);
+    }
+    *out = c;
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_ctx_destroy(cudamat_ctx *ctx)
+{
+    if (!ctx) return CUDAMAT_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->parts);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    free(ctx);
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_ctx_sync(cudamat_ctx *ctx)
+{
+    CM_ARG(ctx, "ctx is NULL");
+    CM_HIP(hipStreamSynchronize(ctx->stream));
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_ctx_stream(cudamat_ctx *ctx, void **stream)
+{
+    CM_ARG(ctx && stream, "null pointer");
+    *stream = (void *)ctx->stream;
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_malloc(cudamat_ctx *ctx, size_t bytes, void **dev)
+{
+    CM_ARG(ctx && dev, "null pointer");
+    CM_HIP(hipSetDevice(ctx->device));
+    *dev = nullptr;
+    hipError_t e = hipMalloc(dev, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? CUDAMAT_ERR_NOMEM : CUDAMAT_ERR_HIP;
+    }
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_free(cudamat_ctx *ctx, void *dev)
+{
+    CM_ARG(ctx, "ctx is NULL");
+    if (!dev) return CUDAMAT_OK;
+    CM_HIP(hipStreamSynchronize(ctx->stream));
+    CM_HIP(hipFree(dev));
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_h2d(cudamat_ctx *ctx, void *dev, const void *host, size_t bytes)
+{
+    CM_ARG(ctx && (bytes == 0 || (dev && host)), "null pointer");
+    if (!bytes) return CUDAMAT_OK;
+    CM_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CM_HIP(hipStreamSynchronize(ctx->stream));
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_d2h(cudamat_ctx *ctx, void *host, const void *dev, size_t bytes)
+{
+    CM_ARG(ctx && (bytes == 0 || (dev && host)), "null pointer");
+    if (!bytes) return CUDAMAT_OK;
+    CM_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CM_HIP(hipStreamSynchronize(ctx->stream));
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_memset(cudamat_ctx *ctx, void *dev, int value, size_t bytes)
+{
+    CM_ARG(ctx && (bytes == 0 || dev), "null pointer");
+    if (!bytes) return CUDAMAT_OK;
+    CM_HIP(hipMemsetAsync(dev, value, bytes, ctx->stream));
+    return CUDAMAT_OK;
+}
+
+// ---- timers: a pair of HIP events recorded on the context's stream ---------------
+struct cm_timer { hipEvent_t a, b; };
+
+extern "C" int cudamat_timer_create(cudamat_ctx *ctx, void **timer)
+{
+    CM_ARG(ctx && timer, "null pointer");
+    cm_timer *t = (cm_timer *)calloc(1, sizeof(cm_timer));
+    if (!t) return CUDAMAT_ERR_NOMEM;
+    CM_HIP(hipEventCreate(&t->a));
+    CM_HIP(hipEventCreate(&t->b));
+    *timer = t;
+    return CUDAMAT_OK;
+}
+extern "C" int cudamat_timer_start(cudamat_ctx *ctx, void *timer)
+{
+    CM_ARG(ctx && timer, "null pointer");
+    CM_HIP(hipEventRecord(((cm_timer *)timer)->a, ctx->stream));
+    return CUDAMAT_OK;
+}
+extern "C" int cudamat_timer_stop(cudamat_ctx *ctx, void *timer)
+{
+    CM_ARG(ctx && timer, "null pointer");
+    CM_HIP(hipEventRecord(((cm_timer *)timer)->b, ctx->stream));
+    return CUDAMAT_OK;
+}
+extern "C" int cudamat_timer_elapsed_ms(cudamat_ctx *ctx, void *timer, double *ms)
+{
+    CM_ARG(ctx && timer && ms, "null pointer");
+    cm_timer *t = (cm_timer *)timer;
+    CM_HIP(hipEventSynchronize(t->b));
+    float f = 0.f;
+    CM_HIP(hipEventElapsedTime(&f, t->a, t->b));
+    *ms = (double)f;
+    return CUDAMAT_OK;
+}
+extern "C" int cudamat_timer_destroy(cudamat_ctx *ctx, void *timer)
+{
+    (void)ctx;
+    if (!timer) return CUDAMAT_OK;
+    cm_timer *t = (cm_timer *)timer;
+    hipEventDestroy(t->a);
+    hipEventDestroy(t->b);
+    free(t);
+    return CUDAMAT_OK;
+}
+
+// ---- elementary kernels ---------------------------------------------------------------
+extern "C" int cudamat_spmv(cudamat_ctx *ctx, int n, const int *rowptr, const int *colidx,
+                            const double *val, int base, double alpha, const double *x,
+                            const double *d, double beta, double *y)
+{
+    CM_ARG(ctx && rowptr && colidx && val && x && y, "null pointer");
+    CM_ARG(n >= 0 && (base == 0 || base == 1), "n >= 0, base in {0,1}");
+    if (n == 0) return CUDAMAT_OK;
+    // nnz is needed only to choose lanes-per-row: read the last row pointer
+    int last = 0;
+    CM_HIP(hipMemcpyAsync(&last, rowptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CM_HIP(hipStreamSynchronize(ctx->stream));
+    SpmvPlan plan = plan_spmv(n, (int64_t)last - base);
+    SpmvArgs a{};
+    a.n = n;
+    a.rp = rowptr;
+    a.ci = colidx - base;   // rp values (with base) index these shifted arrays directly
+    a.val = val - base;
+    a.x = x - base;
+    a.d = d;
+    a.xd = x;
+    a.alpha = alpha;
+    a.beta = beta;
+    a.y = y;
+    a.dot = 0;
+    a.loop = LoopArgs{nullptr, nullptr, 0, 0, 0};
+    a.check = CHECK_NONE;
+    return launch_spmv(ctx->stream, plan, a);
+}
+
+extern "C" int cudamat_dot(cudamat_ctx *ctx, int64_t n, const double *x, const double *y,
+                           double *out_dev)
+{
+    CM_ARG(ctx && out_dev && n >= 0 && (n == 0 || (x && y)), "bad argument");
+    int np = 0;
+    CM_TRY(launch_dot_parts(ctx->stream, n, x, y, ctx->parts, &np));
+    return launch_reduce_parts(ctx->stream, ScalarSrc{ctx->parts, np, 1}, 1, out_dev, 0);
+}
+
+extern "C" int cudamat_nrm2(cudamat_ctx *ctx, int64_t n, const double *x, double *out_dev)
+{
+    CM_ARG(ctx && out_dev && n >= 0 && (n == 0 || x), "bad argument");
+    int np = 0;
+    CM_TRY(launch_dot_parts(ctx->stream, n, x, x, ctx->parts, &np));
+    return launch_reduce_parts(ctx->stream, ScalarSrc{ctx->parts, np, 1}, 1, out_dev, 1);
+}
+
+extern "C" int cudamat_axpy(cudamat_ctx *ctx, int64_t n, double alpha, const double *x, double *y)
+{
+    CM_ARG(ctx && n >= 0 && (n == 0 || (x && y)), "bad argument");
+    return launch_axpy(ctx->stream, n, alpha, x, y);
+}
+
+extern "C" int cudamat_scal(cudamat_ctx *ctx, int64_t n, double alpha, double *x)
+{
+    CM_ARG(ctx && n >= 0 && (n == 0 || x), "bad argument");
+    return launch_scal(ctx->stream, n, alpha, x);
+}

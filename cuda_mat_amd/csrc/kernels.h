@@ -1,0 +1,73 @@
+// kernels.h -- launch wrappers of the hand-written gfx950 kernels (internal API).
+#pragma once
+#include "common.h"
+
+namespace cm {
+
+struct LoopArgs {
+    LoopState *st;     // NULL: kernel used outside a solve (no freeze / checks)
+    double *hist;
+    int hist_cap;
+    int loop;          // CUDAMAT_LOOP_*
+    int no_exit;
+};
+
+struct SpmvPlan {
+    int lanes;            // lanes cooperating on one row (2..64)
+    int grid;             // workgroups
+    int rows_per_block;   // contiguous rows owned by a workgroup
+};
+SpmvPlan plan_spmv(int n_rows, int64_t nnz);
+
+// y = alpha*(A x + d .* xd) + beta*y  on 0- or 1-based CSR (base folded into the
+// pointers by the caller).  dot: 0 none, 1: parts[2b] = sum y*w, 2: also
+// parts[2b+1] = sum y*y.  check: CHECK_HALF evaluates the half-step stopping test
+// from `half` in the prologue.
+struct SpmvArgs {
+    int n;
+    const int *rp;
+    const int *ci;
+    const double *val;
+    const double *x;      // indexed by column id
+    const double *d;      // optional diagonal shift (local rows)
+    const double *xd;     // x restricted to the local rows (for d .* x)
+    double alpha, beta;
+    double *y;
+    int dot;
+    const double *w;
+    double *parts;
+    LoopArgs loop;
+    int check;
+    ScalarSrc half;
+};
+int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a);
+
+int vec_grid(int64_t n);
+
+// r = b - r (r holds A x0 on entry), rw = r, p = r; parts[2b] = parts[2b+1] = sum r^2
+int launch_init(hipStream_t s, int64_t n, const double *b, double *r, double *rw, double *p,
+                double *parts, int *nparts);
+// one workgroup: set up LoopState from the initial reduction
+int launch_init_finish(hipStream_t s, LoopState *st, ScalarSrc init, double tol);
+// p = r + beta (p - omega v), preceded by the full-step test of the previous iteration
+int launch_update_p(hipStream_t s, LoopArgs la, ScalarSrc full, int64_t n, const double *r,
+                    double *p, const double *v);
+// alpha = rho / (rw.v); r -= alpha v; x += alpha pw; parts[2b] = sum r^2
+int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, const double *v,
+                double *x, const double *pw, double *parts, int *nparts);
+// omega = (t.r)/(t.t); x += omega s; r -= omega t; parts = (rw.r, r.r); it++
+int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, const double *sv,
+                double *r, const double *t, const double *rw, double *parts, int *nparts);
+// standalone stopping tests (one workgroup)
+int launch_check(hipStream_t s, LoopArgs la, ScalarSrc src, int which);
+// out[k] = sum of partials, k < K (one workgroup)
+int launch_reduce_parts(hipStream_t s, ScalarSrc in, int K, double *out, int sqrt_it);
+// generic streaming kernels
+int launch_dot_parts(hipStream_t s, int64_t n, const double *x, const double *y, double *parts,
+                     int *nparts);
+int launch_axpy(hipStream_t s, int64_t n, double alpha, const double *x, double *y);
+int launch_scal(hipStream_t s, int64_t n, double alpha, double *x);
+int launch_fill(hipStream_t s, int64_t n, double value, double *x);
+int launch_rebase(hipStream_t s, int64_t n, const int *in, int shift, int *out);
+
+}  // namespace cm

@@ -1,0 +1,600 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels of the BiCGSTAB inner loop.
+//
+// Everything here is HBM-bandwidth-bound fp64 streaming / gather work (<= 0.17
+// flop/byte): no MFMA.  What matters is (a) coalesced 16-byte-per-lane loads on
+// the streamed vectors and contiguous row chunks per workgroup on the CSR
+// arrays, (b) one pass per fused update instead of the reference's
+// copy/scal/axpy triplets (pbicgstab.cu:86-88,109-110,139-140,668-672,...),
+// (c) dot products produced by the kernel that already streams the operands,
+// reduced wave64-shuffle -> LDS -> per-workgroup partial -> fixed-order sum in
+// the consumer's prologue (bitwise reproducible, no atomics, no host sync).
+//
+// Scalars (rho, alpha, omega, norms) never leave the device: see LoopState.
+#include "kernels.h"
+
+namespace cm {
+
+// ------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int L>
+__device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// every thread of the 256-thread workgroup receives the K sums (fixed order)
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *lds)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+    __syncthreads();  // lds may still be read from a previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) lds[wave * K + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        v[k] = ((lds[0 * K + k] + lds[1 * K + k]) + lds[2 * K + k]) + lds[3 * K + k];
+}
+
+template <int K>
+__device__ __forceinline__ void load_scalars(const ScalarSrc &s, double (&out)[K], double *lds)
+{
+    if (s.count == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) out[k] = s.ptr[k];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) out[k] = 0.0;
+    for (int j = threadIdx.x; j < s.count; j += kBlock) {
+#pragma unroll
+        for (int k = 0; k < K; k++) out[k] += s.ptr[(size_t)j * s.stride + k];
+    }
+    block_sum<K>(out, lds);
+}
+
+__device__ __forceinline__ bool leader() { return blockIdx.x == 0 && threadIdx.x == 0; }
+
+// ------------------------------------------------------------- stopping tests
+// half-step test, pbicgstab.cu:111-118.  Returns true when the caller must return.
+__device__ __forceinline__ bool check_half(const LoopArgs &la, const ScalarSrc &half, double *lds)
+{
+    LoopState *st = la.st;
+    if (st->state != 0) return true;
+    double sc[1];
+    load_scalars<1>(half, sc, lds);
+    const double nrm = sqrt(sc[0]);
+    const int it = st->it;
+    if (la.loop == CUDAMAT_LOOP_PBICGSTAB) {
+        if (leader()) {
+            st->nrm = nrm;
+            if (la.hist && 2 * it < la.hist_cap) la.hist[2 * it] = nrm;
+        }
+        if (!la.no_exit && nrm < st->tolabs) {
+            if (leader()) st->state = 1;
+            return true;
+        }
+    }
+    return false;
+}
+
+// full-step test of iteration it-1, pbicgstab.cu:142-151 / :723-742.  sc = (rw.r, r.r)
+__device__ __forceinline__ bool check_full(const LoopArgs &la, const double (&sc)[2])
+{
+    LoopState *st = la.st;
+    const int it = st->it;
+    if (it == 0) return false;
+    const double nrm = sqrt(sc[1]);
+    const double omega = st->omega;
+    if (leader()) {
+        st->nrm = nrm;
+        if (la.hist) {
+            const int slot = (la.loop == CUDAMAT_LOOP_PBICGSTAB) ? 2 * (it - 1) + 1 : it - 1;
+            if (slot < la.hist_cap) la.hist[slot] = nrm;
+        }
+    }
+    if (la.no_exit) return false;
+    if (nrm < st->tolabs) {
+        if (leader()) st->state = 2;
+        return true;
+    }
+    if (la.loop == CUDAMAT_LOOP_PBICGSTAB2 && (fabs(omega) < 1e-5 || isnan(omega))) {
+        if (leader()) st->state = 3;
+        return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(kBlock) void k_check(LoopArgs la, ScalarSrc src, int which)
+{
+    __shared__ double lds[8];
+    if (la.st->state != 0) return;
+    if (which == CHECK_HALF) {
+        check_half(la, src, lds);
+    } else {
+        double sc[2];
+        load_scalars<2>(src, sc, lds);
+        check_full(la, sc);
+    }
+}
+
+int launch_check(hipStream_t s, LoopArgs la, ScalarSrc src, int which)
+{
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, s, la, src, which);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce_parts(ScalarSrc in, int K, double *out, int sqrt_it)
+{
+    __shared__ double lds[8];
+    for (int k = 0; k < K; k++) {
+        ScalarSrc one{in.ptr + k, in.count, in.stride};
+        double sc[1];
+        load_scalars<1>(one, sc, lds);
+        if (threadIdx.x == 0) out[k] = sqrt_it ? sqrt(sc[0]) : sc[0];
+    }
+}
+
+int launch_reduce_parts(hipStream_t s, ScalarSrc in, int K, double *out, int sqrt_it)
+{
+    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, s, in, K, out, sqrt_it);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// ------------------------------------------------------------------------ SpMV
+// One group of L lanes per row (L = 64: one wavefront per row), a workgroup owns a
+// contiguous chunk of rows so that its 4 waves stream one contiguous piece of
+// val/colidx; chunks are dealt to XCDs in contiguous eighths so neighbouring rows
+// (which share x entries for banded matrices) meet in the same 4 MiB L2.
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a, int rows_per_block)
+{
+    __shared__ double lds[8];
+    if (a.loop.st) {
+        if (a.check == CHECK_HALF) {
+            if (check_half(a.loop, a.half, lds)) return;
+        } else if (a.loop.st->state != 0) {
+            return;
+        }
+    }
+    constexpr int RPB = kBlock / L;
+    const int lane = threadIdx.x & (L - 1);
+    const int group = threadIdx.x / L;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int cid = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+    const long long r0 = (long long)cid * rows_per_block;
+    const int row_begin = (int)(r0 < a.n ? r0 : a.n);
+    const int row_end = (int)(r0 + rows_per_block < a.n ? r0 + rows_per_block : a.n);
+
+    double acc[2] = {0.0, 0.0};
+    for (int row = row_begin + group; row < row_end; row += RPB) {
+        const int s = a.rp[row], e = a.rp[row + 1];
+        double sum = 0.0;
+        for (int k = s + lane; k < e; k += L)
+            sum += __builtin_nontemporal_load(a.val + k) * a.x[__builtin_nontemporal_load(a.ci + k)];
+        sum = group_sum<L>(sum);
+        if (lane == 0) {
+            if (a.d) sum += a.d[row] * a.xd[row];
+            double out = a.alpha * sum;
+            if (a.beta != 0.0) out += a.beta * a.y[row];
+            a.y[row] = out;
+            if (a.dot) {
+                acc[0] += out * a.w[row];
+                acc[1] += out * out;
+            }
+        }
+    }
+    if (a.dot) {
+        block_sum<2>(acc, lds);
+        if (threadIdx.x == 0) {
+            a.parts[2 * b] = acc[0];
+            a.parts[2 * b + 1] = acc[1];
+        }
+    }
+}
+
+SpmvPlan plan_spmv(int n_rows, int64_t nnz)
+{
+    SpmvPlan p;
+    const double mean = n_rows > 0 ? (double)nnz / n_rows : 1.0;
+    int L = 64;
+    if (mean <= 3.0) L = 2;
+    else if (mean <= 6.0) L = 4;
+    else if (mean <= 12.0) L = 8;
+    else if (mean <= 40.0) L = 16;
+    else if (mean <= 96.0) L = 32;
+    if (const char *e = getenv("CUDAMAT_SPMV_LANES")) {
+        int v = atoi(e);
+        if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L = v;
+    }
+    p.lanes = L;
+    const int rpb = kBlock / L;
+    long long groups = ((long long)n_rows + rpb - 1) / rpb;
+    int grid = (int)(groups < kSpmvGridMax ? groups : kSpmvGridMax);
+    if (grid < 1) grid = 1;
+    long long per = ((long long)n_rows + grid - 1) / grid;
+    per = (per + rpb - 1) / rpb * rpb;
+    if (per < rpb) per = rpb;
+    p.rows_per_block = (int)per;
+    p.grid = (int)(((long long)n_rows + per - 1) / per);
+    if (p.grid < 1) p.grid = 1;
+    return p;
+}
+
+int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a)
+{
+    dim3 g(plan.grid), b(kBlock);
+    switch (plan.lanes) {
+    case 2:  hipLaunchKernelGGL(k_spmv<2>, g, b, 0, s, a, plan.rows_per_block); break;
+    case 4:  hipLaunchKernelGGL(k_spmv<4>, g, b, 0, s, a, plan.rows_per_block); break;
+    case 8:  hipLaunchKernelGGL(k_spmv<8>, g, b, 0, s, a, plan.rows_per_block); break;
+    case 16: hipLaunchKernelGGL(k_spmv<16>, g, b, 0, s, a, plan.rows_per_block); break;
+    case 32: hipLaunchKernelGGL(k_spmv<32>, g, b, 0, s, a, plan.rows_per_block); break;
+    default: hipLaunchKernelGGL(k_spmv<64>, g, b, 0, s, a, plan.rows_per_block); break;
+    }
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// ------------------------------------------------------- streaming vector kernels
+// 16 bytes per lane (double2) whenever every operand is 16-byte aligned; a fixed
+// grid (<= kVecGridMax workgroups) walks the vector grid-stride so that the number
+// of partial sums is bounded and the reduction order depends on n only.
+int vec_grid(int64_t n)
+{
+    int64_t g = (n / 2 + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kVecGridMax) g = kVecGridMax;
+    return (int)g;
+}
+
+static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+#define CM_VEC_LOOP(N, BODY2, BODY1)                                                   \
+    {                                                                                  \
+        const int64_t n2__ = VEC ? (N) / 2 : 0;                                        \
+        const int64_t stride__ = (int64_t)gridDim.x * kBlock;                          \
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2__; i += stride__) { BODY2 } \
+        for (int64_t i = 2 * n2__ + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < (N); i += stride__) { BODY1 } \
+    }
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_init(int64_t n, const double *b, double *r, double *rw,
+                                                 double *p, double *parts)
+{
+    __shared__ double lds[8];
+    double acc[1] = {0.0};
+    CM_VEC_LOOP(n,
+        {
+            const double2 bb = ((const double2 *)b)[i];
+            double2 rr = ((double2 *)r)[i];
+            rr.x = bb.x - rr.x; rr.y = bb.y - rr.y;        // r = f - A x (pbicgstab.cu:67-70)
+            ((double2 *)r)[i] = rr; ((double2 *)rw)[i] = rr; ((double2 *)p)[i] = rr;  // :72-73
+            acc[0] += rr.x * rr.x; acc[0] += rr.y * rr.y;
+        },
+        {
+            const double rr = b[i] - r[i];
+            r[i] = rr; rw[i] = rr; p[i] = rr;
+            acc[0] += rr * rr;
+        })
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) {
+        parts[2 * blockIdx.x] = acc[0];       // rho0 = rw.r = r.r
+        parts[2 * blockIdx.x + 1] = acc[0];   // ||r0||^2
+    }
+}
+
+int launch_init(hipStream_t s, int64_t n, const double *b, double *r, double *rw, double *p,
+                double *parts, int *nparts)
+{
+    const int g = vec_grid(n);
+    *nparts = g;
+    if (aligned16(b) && aligned16(r) && aligned16(rw) && aligned16(p))
+        hipLaunchKernelGGL(k_init<1>, dim3(g), dim3(kBlock), 0, s, n, b, r, rw, p, parts);
+    else
+        hipLaunchKernelGGL(k_init<0>, dim3(g), dim3(kBlock), 0, s, n, b, r, rw, p, parts);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void k_init_finish(LoopState *st, ScalarSrc init, double tol)
+{
+    __shared__ double lds[8];
+    double sc[2];
+    load_scalars<2>(init, sc, lds);
+    if (threadIdx.x == 0) {
+        const double nrm0 = sqrt(sc[1]);           // pbicgstab.cu:74 / :655
+        st->state = 0;
+        st->it = 0;
+        st->rho[0] = 1.0;                          // pbicgstab.cu:617 (rho = 1)
+        st->rho[1] = 1.0;
+        st->alpha = 1.0;                           // :615
+        st->omega = 1.0;                           // :614
+        st->nrm0 = nrm0;
+        st->tolabs = tol * nrm0;
+        st->nrm = nrm0;
+    }
+}
+
+int launch_init_finish(hipStream_t s, LoopState *st, ScalarSrc init, double tol)
+{
+    hipLaunchKernelGGL(k_init_finish, dim3(1), dim3(kBlock), 0, s, st, init, tol);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// p = r + beta (p - omega v)          pbicgstab.cu:83-89 (axpy, scal, axpy) fused
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_update_p(LoopArgs la, ScalarSrc full, int64_t n,
+                                                     const double *r, double *p, const double *v)
+{
+    __shared__ double lds[8];
+    LoopState *st = la.st;
+    if (st->state != 0) return;
+    const int it = st->it;
+    double sc[2];
+    load_scalars<2>(full, sc, lds);
+    if (check_full(la, sc)) return;
+    const double rho = sc[0];                              // :81  rho = rw.r
+    const double rhop = st->rho[(it + 1) & 1];             // :80
+    const double alpha = st->alpha, omega = st->omega;
+    if (leader()) st->rho[it & 1] = rho;
+    if (it == 0) return;                                   // :83  p = r already (:73)
+    const double beta = (rho / rhop) * (alpha / omega);    // :84
+    const double nomega = -omega;
+    CM_VEC_LOOP(n,
+        {
+            const double2 rr = ((const double2 *)r)[i];
+            const double2 vv = ((const double2 *)v)[i];
+            double2 pp = ((double2 *)p)[i];
+            pp.x = fma(nomega, vv.x, pp.x); pp.y = fma(nomega, vv.y, pp.y);   // :86
+            pp.x = beta * pp.x;             pp.y = beta * pp.y;               // :87
+            pp.x = rr.x + pp.x;             pp.y = rr.y + pp.y;               // :88
+            ((double2 *)p)[i] = pp;
+        },
+        {
+            double pp = fma(nomega, v[i], p[i]);
+            pp = beta * pp;
+            p[i] = r[i] + pp;
+        })
+}
+
+int launch_update_p(hipStream_t s, LoopArgs la, ScalarSrc full, int64_t n, const double *r,
+                    double *p, const double *v)
+{
+    const int g = vec_grid(n);
+    if (aligned16(r) && aligned16(p) && aligned16(v))
+        hipLaunchKernelGGL(k_update_p<1>, dim3(g), dim3(kBlock), 0, s, la, full, n, r, p, v);
+    else
+        hipLaunchKernelGGL(k_update_p<0>, dim3(g), dim3(kBlock), 0, s, la, full, n, r, p, v);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// alpha = rho/(rw.v); r -= alpha v; x += alpha pw; ||r||^2     pbicgstab.cu:106-111
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_half(LoopArgs la, ScalarSrc rv, int64_t n, double *r,
+                                                 const double *v, double *x, const double *pw,
+                                                 double *parts)
+{
+    __shared__ double lds[8];
+    LoopState *st = la.st;
+    if (st->state != 0) return;
+    const int it = st->it;
+    double sc[1];
+    load_scalars<1>(rv, sc, lds);
+    const double alpha = st->rho[it & 1] / sc[0];          // :107
+    const double nalpha = -alpha;
+    if (leader()) st->alpha = alpha;
+    double acc[1] = {0.0};
+    CM_VEC_LOOP(n,
+        {
+            const double2 vv = ((const double2 *)v)[i];
+            const double2 pp = ((const double2 *)pw)[i];
+            double2 rr = ((double2 *)r)[i];
+            double2 xx = ((double2 *)x)[i];
+            rr.x = fma(nalpha, vv.x, rr.x); rr.y = fma(nalpha, vv.y, rr.y);   // :109
+            xx.x = fma(alpha, pp.x, xx.x);  xx.y = fma(alpha, pp.y, xx.y);    // :110
+            ((double2 *)r)[i] = rr; ((double2 *)x)[i] = xx;
+            acc[0] += rr.x * rr.x; acc[0] += rr.y * rr.y;                     // :111
+        },
+        {
+            const double rr = fma(nalpha, v[i], r[i]);
+            r[i] = rr;
+            x[i] = fma(alpha, pw[i], x[i]);
+            acc[0] += rr * rr;
+        })
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) parts[blockIdx.x] = acc[0];
+}
+
+int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, const double *v,
+                double *x, const double *pw, double *parts, int *nparts)
+{
+    const int g = vec_grid(n);
+    *nparts = g;
+    if (aligned16(r) && aligned16(v) && aligned16(x) && aligned16(pw))
+        hipLaunchKernelGGL(k_half<1>, dim3(g), dim3(kBlock), 0, s, la, rv, n, r, v, x, pw, parts);
+    else
+        hipLaunchKernelGGL(k_half<0>, dim3(g), dim3(kBlock), 0, s, la, rv, n, r, v, x, pw, parts);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// omega = (t.r)/(t.t); x += omega s; r -= omega t; (rw.r, r.r); it++   pbicgstab.cu:135-151
+// s may alias r (no preconditioner): s is read before r is written, per element.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_full(LoopArgs la, ScalarSrc tt, int64_t n, double *x,
+                                                 const double *sv, double *r, const double *t,
+                                                 const double *rw, double *parts)
+{
+    __shared__ double lds[8];
+    LoopState *st = la.st;
+    if (st->state != 0) return;
+    double sc[2];
+    load_scalars<2>(tt, sc, lds);
+    const double omega = sc[0] / sc[1];                    // :137
+    const double nomega = -omega;
+    double acc[2] = {0.0, 0.0};
+    CM_VEC_LOOP(n,
+        {
+            const double2 ss = ((const double2 *)sv)[i];
+            const double2 ttv = ((const double2 *)t)[i];
+            const double2 ww = ((const double2 *)rw)[i];
+            double2 rr = ((double2 *)r)[i];
+            double2 xx = ((double2 *)x)[i];
+            xx.x = fma(omega, ss.x, xx.x);   xx.y = fma(omega, ss.y, xx.y);   // :139
+            rr.x = fma(nomega, ttv.x, rr.x); rr.y = fma(nomega, ttv.y, rr.y); // :140
+            ((double2 *)x)[i] = xx; ((double2 *)r)[i] = rr;
+            acc[0] += ww.x * rr.x; acc[0] += ww.y * rr.y;                     // :81 of i+1
+            acc[1] += rr.x * rr.x; acc[1] += rr.y * rr.y;                     // :142
+        },
+        {
+            const double ss = sv[i];
+            x[i] = fma(omega, ss, x[i]);
+            const double rr = fma(nomega, t[i], r[i]);
+            r[i] = rr;
+            acc[0] += rw[i] * rr;
+            acc[1] += rr * rr;
+        })
+    block_sum<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        parts[2 * blockIdx.x] = acc[0];
+        parts[2 * blockIdx.x + 1] = acc[1];
+    }
+    if (leader()) {
+        st->omega = omega;
+        st->it = st->it + 1;                               // :148 / :151
+    }
+}
+
+int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, const double *sv,
+                double *r, const double *t, const double *rw, double *parts, int *nparts)
+{
+    const int g = vec_grid(n);
+    *nparts = g;
+    if (aligned16(x) && aligned16(sv) && aligned16(r) && aligned16(t) && aligned16(rw))
+        hipLaunchKernelGGL(k_full<1>, dim3(g), dim3(kBlock), 0, s, la, tt, n, x, sv, r, t, rw, parts);
+    else
+        hipLaunchKernelGGL(k_full<0>, dim3(g), dim3(kBlock), 0, s, la, tt, n, x, sv, r, t, rw, parts);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// ---------------------------------------------------------------- BLAS-1 pieces
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_dot(int64_t n, const double *x, const double *y,
+                                                double *parts)
+{
+    __shared__ double lds[8];
+    double acc[1] = {0.0};
+    CM_VEC_LOOP(n,
+        {
+            const double2 a = ((const double2 *)x)[i];
+            const double2 b = ((const double2 *)y)[i];
+            acc[0] += a.x * b.x; acc[0] += a.y * b.y;
+        },
+        { acc[0] += x[i] * y[i]; })
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) parts[blockIdx.x] = acc[0];
+}
+
+int launch_dot_parts(hipStream_t s, int64_t n, const double *x, const double *y, double *parts,
+                     int *nparts)
+{
+    const int g = vec_grid(n);
+    *nparts = g;
+    if (aligned16(x) && aligned16(y))
+        hipLaunchKernelGGL(k_dot<1>, dim3(g), dim3(kBlock), 0, s, n, x, y, parts);
+    else
+        hipLaunchKernelGGL(k_dot<0>, dim3(g), dim3(kBlock), 0, s, n, x, y, parts);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_axpy(int64_t n, double alpha, const double *x, double *y)
+{
+    CM_VEC_LOOP(n,
+        {
+            const double2 a = ((const double2 *)x)[i];
+            double2 b = ((double2 *)y)[i];
+            b.x = fma(alpha, a.x, b.x); b.y = fma(alpha, a.y, b.y);
+            ((double2 *)y)[i] = b;
+        },
+        { y[i] = fma(alpha, x[i], y[i]); })
+}
+
+int launch_axpy(hipStream_t s, int64_t n, double alpha, const double *x, double *y)
+{
+    const int g = vec_grid(n);
+    if (aligned16(x) && aligned16(y))
+        hipLaunchKernelGGL(k_axpy<1>, dim3(g), dim3(kBlock), 0, s, n, alpha, x, y);
+    else
+        hipLaunchKernelGGL(k_axpy<0>, dim3(g), dim3(kBlock), 0, s, n, alpha, x, y);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_scal(int64_t n, double alpha, double *x, int fill)
+{
+    CM_VEC_LOOP(n,
+        {
+            double2 a = ((double2 *)x)[i];
+            a.x = fill ? alpha : alpha * a.x; a.y = fill ? alpha : alpha * a.y;
+            ((double2 *)x)[i] = a;
+        },
+        { x[i] = fill ? alpha : alpha * x[i]; })
+}
+
+int launch_scal(hipStream_t s, int64_t n, double alpha, double *x)
+{
+    const int g = vec_grid(n);
+    if (aligned16(x)) hipLaunchKernelGGL(k_scal<1>, dim3(g), dim3(kBlock), 0, s, n, alpha, x, 0);
+    else hipLaunchKernelGGL(k_scal<0>, dim3(g), dim3(kBlock), 0, s, n, alpha, x, 0);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+int launch_fill(hipStream_t s, int64_t n, double value, double *x)
+{
+    const int g = vec_grid(n);
+    if (aligned16(x)) hipLaunchKernelGGL(k_scal<1>, dim3(g), dim3(kBlock), 0, s, n, value, x, 1);
+    else hipLaunchKernelGGL(k_scal<0>, dim3(g), dim3(kBlock), 0, s, n, value, x, 1);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void k_rebase(int64_t n, const int *in, int shift, int *out)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = in[i] + shift;
+}
+
+int launch_rebase(hipStream_t s, int64_t n, const int *in, int shift, int *out)
+{
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_rebase, dim3((int)g), dim3(kBlock), 0, s, n, in, shift, out);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+}  // namespace cm

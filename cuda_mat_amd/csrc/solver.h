@@ -1,0 +1,71 @@
+// solver.h -- the HBM-resident system behind cudamat_solver_* (internal).
+#pragma once
+#include <vector>
+
+#include "kernels.h"
+
+namespace cm {
+
+constexpr int kLag = 2;            // host looks at the state written kLag iterations ago
+constexpr int kRing = kLag + 2;
+
+struct TriFactor {                 // one triangular factor in level-major storage
+    int nlevels = 0;
+    std::vector<int> level_ptr;    // host: rows of level l are [level_ptr[l], level_ptr[l+1])
+    int *rp = nullptr;             // device, n+1, rows in level order, 0-based
+    int *ci = nullptr;             // device, column ids (original numbering)
+    double *val = nullptr;         // device
+    int *row_of = nullptr;         // device: original row id of permuted row
+    double *dinv = nullptr;        // device: 1/diag in permuted order (upper only)
+    int64_t nnz = 0;
+};
+
+}  // namespace cm
+
+struct cudamat_solver {
+    cudamat_ctx *ctx = nullptr;
+    int n = 0;                 // local rows
+    int n_pad = 0;             // rows per rank in a sharded run (== n when single)
+    int64_t n_cols = 0;
+    int64_t nnz = 0;
+    int *rp = nullptr, *ci = nullptr;
+    double *val = nullptr;
+    const double *d = nullptr;
+    cm::SpmvPlan plan{};
+
+    // work vectors (n_pad doubles each, pad kept zero)
+    double *r = nullptr, *rw = nullptr, *p = nullptr, *pw = nullptr, *s = nullptr, *t = nullptr,
+           *v = nullptr;
+    double *gather = nullptr;  // world * n_pad doubles (sharded runs)
+
+    // reduction workspace: four stages of per-workgroup partials + reduced scalars
+    double *parts_full = nullptr, *parts_rv = nullptr, *parts_half = nullptr, *parts_tt = nullptr;
+    double *red = nullptr;     // 8 doubles
+    cm::LoopState *st = nullptr;       // device
+    cm::LoopState *st_ring = nullptr;  // pinned host, kRing slots
+    hipEvent_t ev[cm::kRing] = {};
+    double *hist = nullptr;    // device
+    int hist_cap = 0;
+    int hist_count = 0;
+    int last_loop = 0;
+
+    // profiling events
+    std::vector<hipEvent_t> prof_ev;
+
+    // row sharding
+    bool sharded = false;
+    cudamat_comm comm{};
+
+    // ILU(0)
+    bool has_ilu = false;
+    double *lu = nullptr;      // nnz doubles on A's pattern
+    int *diag_pos = nullptr;   // position of the diagonal in each row
+    cm::TriFactor L, U;
+    double t_analysis = 0.0, t_factor = 0.0;
+};
+
+namespace cm {
+int ilu0_setup(cudamat_solver *s);
+int ilu0_release(cudamat_solver *s);
+int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *rhs, double *out);
+}  // namespace cm

@@ -1,0 +1,86 @@
+"""Row-block sharding of the BiCGSTAB path across the GPUs of one node.
+
+The reference is single-GPU; this is the multi-GPU design of SURVEY.md section 8e:
+rank g owns the contiguous rows [g*per, min(n, (g+1)*per)), per = ceil(n / world), and the
+matching slice of every vector.  The only data-path exchanges are
+  * an all-gather of the SpMV input vector (2 per iteration), and
+  * an all-reduce of 1-3 scalars (3 per iteration),
+issued by the C++ loop (csrc/solver.hip) through the two callbacks of `cudamat_comm`.
+TorchComm implements them with torch.distributed: backend "nccl" (= RCCL over xGMI) for
+device buffers, "gloo" for host buffers (CPU tests of the plumbing).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import ALLGATHER_FN, ALLREDUCE_FN, Comm
+
+
+def shard_rows(n, world, rank):
+    """(row0, row1, per): the uniform row blocks cudamat_solver_set_comm requires"""
+    per = (n + world - 1) // world
+    row0 = min(n, per * rank)
+    row1 = min(n, row0 + per)
+    return row0, row1, per
+
+
+class _CudaPtr:
+    """zero-copy view of a raw device pointer for torch.as_tensor"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+class TorchComm:
+    """cudamat_comm backed by torch.distributed (one process per GPU)"""
+
+    def __init__(self, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = device      # torch.device("cuda", i) or None for host pointers (gloo)
+        self._views = {}
+        self.n_allgather = 0
+        self.n_allreduce = 0
+        self.error = None
+        self._ag = ALLGATHER_FN(self._allgather)
+        self._ar = ALLREDUCE_FN(self._allreduce)
+        self.struct = Comm(self.rank, self.world, None, self._ag, self._ar)
+
+    def _view(self, ptr, count):
+        key = (ptr, count)
+        t = self._views.get(key)
+        if t is None:
+            if self.device is not None:
+                t = self.torch.as_tensor(_CudaPtr(ptr, count), device=self.device)
+            else:
+                buf = (C.c_double * count).from_address(ptr)
+                t = self.torch.from_numpy(np.frombuffer(buf, dtype=np.float64, count=count))
+            self._views[key] = t
+        return t
+
+    # The loop enqueues kernels on the context's stream, which must be torch's CURRENT stream
+    # on this device (Context(stream=torch.cuda.current_stream().cuda_stream)): the NCCL
+    # backend orders its collective after the work already queued on the current stream and
+    # makes the current stream wait for it; no host synchronisation happens here.
+    def _allgather(self, user, send, recv, count):
+        try:
+            self.dist.all_gather_into_tensor(self._view(recv, count * self.world), self._view(send, count),
+                                             group=self.group)
+            self.n_allgather += 1
+            return 0
+        except Exception as e:  # noqa: BLE001 - must not unwind through the C frame
+            self.error = e
+            return 1
+
+    def _allreduce(self, user, buf, count):
+        try:
+            self.dist.all_reduce(self._view(buf, count), op=self.dist.ReduceOp.SUM, group=self.group)
+            self.n_allreduce += 1
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self.error = e
+            return 1

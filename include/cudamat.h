@@ -1,0 +1,216 @@
+/*
+ * cudamat.h -- C ABI of libcudamat_hip.so: the MI355X (gfx950) BiCGSTAB hot path.
+ *
+ * This is the drop-in boundary for the reference's solver path.  Every entry
+ * point takes plain pointers and sizes (no C++/torch types) and returns an
+ * int status (CUDAMAT_OK == 0); nothing here ever calls exit() (the reference
+ * does, helper_cuda.h:999-1014).  cudamat_last_error() describes the last
+ * failure on the calling thread.  There is NO CPU fallback: without a HIP
+ * device every compute entry point fails with CUDAMAT_ERR_HIP.
+ *
+ * What each group replaces in /root/reference:
+ *   cudamat_solve                 bicgstab / bicgstab / bicgstab_lu_precond
+ *                                 (pbicgstab.h:113,116,119; pbicgstab.cu:157-409,
+ *                                 756-922, 926-1088): host CSR in, host x out.
+ *   cudamat_solver_*              the same solve with everything resident in HBM
+ *                                 (what pbicgstab.cu:365-374 times as dtAlg), plus
+ *                                 row-sharded multi-GPU operation through two
+ *                                 caller-supplied collectives (new: the reference
+ *                                 is single-GPU).
+ *   cudamat_spmv                  cusparseDcsrmv      pbicgstab.cu:67,104,132,469,
+ *                                                     501,528,646,676,704 (+ the
+ *                                                     mult_spec diagonal term :36-42)
+ *   cudamat_dot / cudamat_nrm2    cublasDdot/Dnrm2    pbicgstab.cu:74,81,106,111,...
+ *   cudamat_axpy / cudamat_scal   cublasDaxpy/Dscal   pbicgstab.cu:69-70,86-88,...
+ *   cudamat_ilu0 / cudamat_trsv   cusparseDcsrilu0 / cusparseDcsrsv_analysis+solve
+ *                                 (via cudamat_solver_ilu0 / _precond_apply)
+ *   cudamat_load_mtx              loadMMSparseMatrix  mmio_wrapper.h:133-348
+ *   cudamat_to_dense_vector       toDenseVector       pbicgstab.cu:1101-1115
+ *   cudamat_gen_*                 synthetic inputs of SURVEY section 8d (the
+ *                                 reference's O(n^2) rand() generators,
+ *                                 pbicgstab.h:32-76, cannot reach 1e7 rows)
+ *
+ * CSR conventions are the reference's: fp64 values, int32 indices, index base
+ * taken from rowptr[0] (0 or 1, pbicgstab.cu:201), columns strictly increasing
+ * inside a row (mmio_wrapper.h:123).
+ */
+#ifndef CUDAMAT_H
+#define CUDAMAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUDAMAT_VERSION 1
+
+/* status codes */
+#define CUDAMAT_OK              0
+#define CUDAMAT_ERR_HIP         1   /* HIP runtime / no device                      */
+#define CUDAMAT_ERR_ARG         2   /* bad argument                                  */
+#define CUDAMAT_ERR_ZERO_PIVOT  3   /* ILU(0): zero or structurally missing diagonal */
+#define CUDAMAT_ERR_NOMEM       4
+#define CUDAMAT_ERR_IO          5
+#define CUDAMAT_ERR_COMM        6   /* a caller-supplied collective failed           */
+
+/* preconditioner (cudamat_solve / cudamat_solver_solve) */
+#define CUDAMAT_PRECOND_NONE    0
+#define CUDAMAT_PRECOND_ILU0    1
+
+/* which reference loop's stopping rules to follow */
+#define CUDAMAT_LOOP_PBICGSTAB  0   /* pbicgstab.cu:45-154: half-step + full-step exits
+                                       against tol*||r0||, no breakdown guard           */
+#define CUDAMAT_LOOP_PBICGSTAB2 1   /* pbicgstab.cu:581-754: end-of-iteration exit,
+                                       |omega| < 1e-5 / NaN guard => not converged      */
+
+/* flags for cudamat_solver_solve */
+#define CUDAMAT_FLAG_DEBUG      1   /* print the reference's debug lines                */
+#define CUDAMAT_FLAG_PROFILE    2   /* bracket every SpMV / trsv launch with HIP events */
+#define CUDAMAT_FLAG_NO_EXIT    4   /* evaluate the stopping tests but never leave:
+                                       fixed-length timing windows (bench.py)           */
+#define CUDAMAT_FLAG_X0_ONES    8   /* start from x0 = 1 (pbicgstab.cu:306-308,827-831)
+                                       instead of the contents of x                     */
+
+typedef struct cudamat_ctx cudamat_ctx;         /* device + stream + reduction workspace  */
+typedef struct cudamat_solver cudamat_solver;   /* one HBM-resident linear system          */
+
+typedef struct cudamat_stats {
+    int iters;          /* the reference loop counter on exit                            */
+    int half_exit;      /* left through the half-step test (pbicgstab.cu:116)            */
+    int converged;      /* a stopping test fired                                         */
+    int breakdown;      /* omega guard fired (pbicgstab.cu:735)                          */
+    double nrm0;        /* ||r0||                                                        */
+    double nrm;         /* last residual norm the loop computed                          */
+    double t_analysis;  /* s, level analysis           (pbicgstab.cu:335-347)            */
+    double t_factor;    /* s, ILU(0) factorisation     (pbicgstab.cu:356-363)            */
+    double t_solve;     /* s, iteration loop = dtAlg   (pbicgstab.cu:365-374)            */
+    double t_total;     /* s, whole call incl. H2D/D2H                                   */
+    /* CUDAMAT_FLAG_PROFILE: device time by kernel class inside the loop                */
+    double ms_spmv;     int n_spmv;
+    double ms_trsv;     int n_trsv;
+    int n_levels_l;     int n_levels_u;
+} cudamat_stats;
+
+/* Collectives for a row-sharded solve, supplied by the host program (e.g. RCCL
+ * through torch.distributed).  Both are enqueued on / ordered
+ * with the context's stream by the callee and must not block the host longer
+ * than the enqueue.  Pointers are device pointers.  Return 0 on success.
+ *   allgather: every rank contributes `count` doubles; recv holds world*count.
+ *   allreduce: in-place sum of `count` doubles.                                      */
+typedef int (*cudamat_allgather_fn)(void *user, const double *send, double *recv, int64_t count);
+typedef int (*cudamat_allreduce_fn)(void *user, double *buf, int count);
+typedef struct cudamat_comm {
+    int rank;
+    int world;
+    void *user;
+    cudamat_allgather_fn allgather;
+    cudamat_allreduce_fn allreduce;
+} cudamat_comm;
+
+int         cudamat_version(void);
+const char *cudamat_last_error(void);
+int         cudamat_device_count(int *count);
+
+/* ---- context ------------------------------------------------------------------ */
+/* stream: a hipStream_t created by the caller (e.g. torch's current stream) or
+ * NULL to let the context create and own one.                                       */
+int cudamat_ctx_create(int device, void *stream, cudamat_ctx **out);
+int cudamat_ctx_destroy(cudamat_ctx *ctx);
+int cudamat_ctx_sync(cudamat_ctx *ctx);
+int cudamat_ctx_stream(cudamat_ctx *ctx, void **stream);
+
+/* device memory for hosts without an allocator of their own                         */
+int cudamat_malloc(cudamat_ctx *ctx, size_t bytes, void **dev);
+int cudamat_free(cudamat_ctx *ctx, void *dev);
+int cudamat_h2d(cudamat_ctx *ctx, void *dev, const void *host, size_t bytes);
+int cudamat_d2h(cudamat_ctx *ctx, void *host, const void *dev, size_t bytes);
+int cudamat_memset(cudamat_ctx *ctx, void *dev, int value, size_t bytes);
+
+/* stream-ordered timers (HIP events on the context's stream)                        */
+int cudamat_timer_create(cudamat_ctx *ctx, void **timer);
+int cudamat_timer_start(cudamat_ctx *ctx, void *timer);
+int cudamat_timer_stop(cudamat_ctx *ctx, void *timer);
+int cudamat_timer_elapsed_ms(cudamat_ctx *ctx, void *timer, double *ms);  /* syncs */
+int cudamat_timer_destroy(cudamat_ctx *ctx, void *timer);
+
+/* ---- elementary kernels on device pointers ------------------------------------- */
+/* y = alpha*(A x + d .* x) + beta*y ; d may be NULL ; base = index base of rowptr /
+ * colidx (they are read as given).  n rows; x has as many entries as A has columns. */
+int cudamat_spmv(cudamat_ctx *ctx, int n, const int *rowptr, const int *colidx,
+                 const double *val, int base, double alpha, const double *x,
+                 const double *d, double beta, double *y);
+/* *out_dev = sum x_i y_i (device scalar, fixed reduction order => reproducible)     */
+int cudamat_dot(cudamat_ctx *ctx, int64_t n, const double *x, const double *y, double *out_dev);
+/* *out_dev = sqrt(sum x_i^2)                                                        */
+int cudamat_nrm2(cudamat_ctx *ctx, int64_t n, const double *x, double *out_dev);
+int cudamat_axpy(cudamat_ctx *ctx, int64_t n, double alpha, const double *x, double *y);
+int cudamat_scal(cudamat_ctx *ctx, int64_t n, double alpha, double *x);
+
+/* ---- HBM-resident system --------------------------------------------------------- */
+/* Local row block of a (possibly row-sharded) square system.
+ *   n_local : rows owned by this rank (== n for a single GPU)
+ *   n_cols  : number of columns = global dimension
+ *   rowptr/colidx/val : DEVICE pointers, base taken from `base`; they are copied
+ *   (and rebased to 0) into the solver's own HBM arrays, so the caller may free them.
+ * Work vectors and the reduction workspace are allocated here, once.                 */
+int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz,
+                          const int *rowptr, const int *colidx, const double *val,
+                          int base, cudamat_solver **out);
+int cudamat_solver_destroy(cudamat_solver *s);
+/* (A0 + diag(d)) variant, pbicgstab.h:116; d is a device vector of n_local doubles
+ * that must stay alive; NULL removes it.                                             */
+int cudamat_solver_set_shift(cudamat_solver *s, const double *d);
+/* ILU(0) of the local block sharing A's pattern + level analysis of L and U
+ * (pbicgstab.cu:336-359).  Single rank only.                                          */
+int cudamat_solver_ilu0(cudamat_solver *s);
+/* copies the LU values (nnz doubles, same ordering as val) to a device buffer         */
+int cudamat_solver_ilu0_values(cudamat_solver *s, double *out_dev);
+/* out = U^-1 L^-1 in  (what one preconditioning step applies, pbicgstab.cu:92-98)     */
+int cudamat_solver_precond_apply(cudamat_solver *s, const double *in, double *out);
+/* row-sharded operation; comm is copied.  world == 1 or NULL => single GPU.           */
+int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *comm);
+/* y_local = (A + diag(d)) x ; x is the LOCAL slice, gathered through comm if sharded  */
+int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, double *y_local);
+/* Solve.  b, x: device vectors of n_local doubles; x holds the initial guess on entry
+ * (unless CUDAMAT_FLAG_X0_ONES) and the solution on return.                           */
+int cudamat_solver_solve(cudamat_solver *s, const double *b, double *x, int precond,
+                         int loop, int maxit, double tol, int flags, cudamat_stats *st);
+/* residual-norm history of the last solve: LOOP_PBICGSTAB: hist[2i], hist[2i+1] =
+ * norm after the half / full step of iteration i; LOOP_PBICGSTAB2: hist[i].
+ * Copies min(cap, available) doubles to the HOST buffer, returns the count in *count. */
+int cudamat_solver_history(cudamat_solver *s, double *hist_host, int cap, int *count);
+
+/* ---- drop-in host-pointer solve ---------------------------------------------------- */
+/* One call = what the three reference entry points do: upload, (analyse, factor,)
+ * iterate, download.  d / x0 may be NULL (x0 NULL => ones).  x receives the iterate
+ * even when not converged.  Returns CUDAMAT_OK whenever the solve ran; convergence
+ * is reported in st (may be NULL).                                                    */
+int cudamat_solve(int n, int nnz, const double *A, const int *iA, const int *jA,
+                  const double *d, const double *x0, const double *b, int precond,
+                  int loop, int maxit, double tol, int debug, double *x,
+                  cudamat_stats *st);
+
+/* ---- synthetic inputs, generated in HBM ------------------------ */
+int64_t cudamat_poisson5_nnz(int nx, int ny);
+int cudamat_gen_poisson5(cudamat_ctx *ctx, int nx, int ny, int64_t row0, int64_t row1,
+                         int base, int *rowptr, int *colidx, double *val);
+int cudamat_rand_row_nnz(int64_t n, int per_row);
+int cudamat_gen_rand_rows(cudamat_ctx *ctx, int64_t n, int per_row, uint64_t seed,
+                          int64_t row0, int64_t row1, int base, int *rowptr,
+                          int *colidx, double *val);
+int cudamat_gen_xstar(cudamat_ctx *ctx, int64_t i0, int64_t i1, uint64_t seed, double *x);
+
+/* ---- Matrix Market I/O (host only) -------------------------------------------------- */
+/* semantics of loadMMSparseMatrix(filename,'d',csr,...) mmio_wrapper.h:133-348:
+ * returns 0 ok / CUDAMAT_ERR_IO; outputs are malloc'd, release with cudamat_host_free
+ * (or free()).                                                                        */
+int cudamat_load_mtx(const char *filename, int csr_format, int *m, int *n, int *nnz,
+                     double **val, int **row, int **col);
+void cudamat_host_free(void *p);
+void cudamat_to_dense_vector(int n, int nnz, const double *A, const int *IA, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUDAMAT_H */

@@ -1,0 +1,136 @@
+"""CPU-side checks of the product boundary: the C-ABI library builds, loads and exports
+every symbol include/cudamat.h declares; the Matrix Market loader (host code) reproduces
+the reference loader's outputs; compute entry points fail loudly without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURES = ["mat3", "mat3_A0", "vec3", "vec3_d", "mat900", "mat10000"]
+
+
+@pytest.fixture(scope="module")
+def cm():
+    import cuda_mat_amd as cm
+    cm.lib()
+    return cm
+
+
+def test_every_declared_symbol_is_exported(cm):
+    hdr = open(os.path.join(ROOT, "include", "cudamat.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cudamat_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"cudamat_allgather_fn", "cudamat_allreduce_fn"}
+    assert len(declared) >= 40
+    from cuda_mat_amd import _lib
+    assert declared == set(_lib._SIGS), declared ^ set(_lib._SIGS)
+    for name in declared:
+        assert hasattr(cm.lib(), name), name
+    assert cm.lib().cudamat_version() == 1
+
+
+def test_struct_layouts_match_header(cm):
+    import ctypes as C
+    # cudamat_stats: 4 ints | 6 doubles | double,int(+pad) | double | 3 ints (+pad to 8)
+    assert C.sizeof(cm.Stats) == 16 + 48 + 16 + 8 + 16
+    assert cm.Stats.ms_spmv.offset == 64 and cm.Stats.n_levels_u.offset == 96
+    assert C.sizeof(cm.Comm) == 8 + 8 + 8 + 8
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_loader_matches_reference_loader(cm, golden_dir, name):
+    """cudamat_load_mtx == what the reference's loadMMSparseMatrix returned (golden npz)"""
+    g = np.load(os.path.join(golden_dir, "loader_%s.npz" % name))
+    err, m, n, nnz, val, row, col = cm.loadMMSparseMatrix(os.path.join(golden_dir, name + ".mtx"), "d", True)
+    assert err == 0 and (m, n, nnz) == (int(g["m"]), int(g["n"]), int(g["nnz"]))
+    np.testing.assert_array_equal(row, g["rowptr"])
+    np.testing.assert_array_equal(col, g["colidx"])
+    np.testing.assert_array_equal(val, g["val"])
+
+
+def test_loader_csc_and_dense_vector(cm, golden_dir):
+    g = np.load(os.path.join(golden_dir, "loader_mat900_csc.npz"))
+    err, m, n, nnz, val, row, col = cm.loadMMSparseMatrix(os.path.join(golden_dir, "mat900.mtx"), "d", False)
+    assert err == 0
+    np.testing.assert_array_equal(row, g["rowptr"])
+    np.testing.assert_array_equal(col, g["colidx"])
+    np.testing.assert_array_equal(val, g["val"])
+    err, m, n, nnz, val, row, col = cm.loadMMSparseMatrix(os.path.join(golden_dir, "vec3_d.mtx"))
+    np.testing.assert_array_equal(cm.toDenseVector(m, nnz, val, row), [1.0, 0.0, 1.0])
+
+
+def _write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+def test_loader_edge_cases_agree_with_oracle_restatement(cm, oracle, tmp_path):
+    cases = {
+        # skew-symmetric: mirrored entry negated (mmio_wrapper.h:205-207)
+        "skew.mtx": "%%MatrixMarket matrix coordinate real skew-symmetric\n3 3 2\n2 1 5.0\n3 2 -1.5\n",
+        # integer field accepted (mmio_wrapper.h:166 comment)
+        "int.mtx": "%%MatrixMarket matrix coordinate integer general\n% c\n2 3 3\n1 3 7\n2 1 -2\n1 1 4\n",
+        # 0-based file
+        "base0.mtx": "%%MatrixMarket matrix coordinate real general\n3 3 3\n0 0 1\n1 2 2\n2 1 3\n",
+        # 1-based file with empty last row and column: detected as base 0 (reference quirk :266-289)
+        "quirk.mtx": "%%MatrixMarket matrix coordinate real general\n4 4 3\n1 1 1\n2 3 2\n3 2 3\n",
+        # blank line before the size line, upper-case banner tokens
+        "blank.mtx": "%%MatrixMarket MATRIX Coordinate Real General\n% x\n\n2 2 2\n1 1 1.5\n2 2 2.5\n",
+        # empty rows in the middle
+        "gaps.mtx": "%%MatrixMarket matrix coordinate real general\n5 5 3\n1 5 1\n5 1 2\n3 3 9\n",
+    }
+    for name, text in cases.items():
+        path = _write(tmp_path, name, text)
+        err, m, n, nnz, val, row, col = cm.loadMMSparseMatrix(path)
+        assert err == 0, name
+        A = oracle.mtx_load(path)
+        assert (m, n, nnz) == (A.n, A.m, A.nnz), name
+        np.testing.assert_array_equal(row, A.rowptr)
+        np.testing.assert_array_equal(col, A.colidx)
+        np.testing.assert_array_equal(val, A.val)
+    assert cm.loadMMSparseMatrix(_write(tmp_path, "quirk2.mtx", cases["quirk.mtx"]))[5][0] == 0
+
+
+def test_loader_rejects_what_the_reference_rejects(cm, oracle, tmp_path, capfd):
+    bad = {
+        "missing.mtx": None,
+        "both.mtx": "%%MatrixMarket matrix coordinate real general\n3 3 2\n0 1 1\n3 3 2\n",     # base 0 and 1
+        "dup.mtx": "%%MatrixMarket matrix coordinate real general\n3 3 3\n1 1 1\n1 1 2\n3 3 1\n",  # duplicate
+        "pattern.mtx": "%%MatrixMarket matrix coordinate pattern general\n2 2 1\n1 1\n",
+        "complex.mtx": "%%MatrixMarket matrix coordinate complex general\n2 2 1\n1 1 1 0\n",
+        "array.mtx": "%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n",
+        "short.mtx": "%%MatrixMarket matrix coordinate real general\n3 3 3\n1 1 1\n2 2 2\n",      # truncated
+        "nobanner.mtx": "3 3 1\n1 1 1\n",
+    }
+    for name, text in bad.items():
+        path = str(tmp_path / name) if text is None else _write(tmp_path, name, text)
+        assert cm.loadMMSparseMatrix(path)[0] == 1, name
+        with pytest.raises(IOError):
+            oracle.mtx_load(path)
+    capfd.readouterr()
+
+
+def test_compute_fails_loudly_without_gpu(cm):
+    """no silent CPU fallback: without a HIP device every compute entry point raises"""
+    if cm.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(cm.CudamatError) as e:
+        cm.Context(0)
+    assert e.value.code == 1
+    A = np.array([2.0]), np.array([0, 1], np.int32), np.array([0], np.int32)
+    with pytest.raises(cm.CudamatError):
+        cm.bicgstab(1, 1, A[0], A[1], A[2], np.array([1.0]), 10, 1e-8)
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under cuda_mat_amd/ or include/ may use it"""
+    for base in ("cuda_mat_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".c", "Makefile")):
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert "liboracle" not in text and "import oracle" not in text \
+                        and "from oracle" not in text and "orc_" not in text, os.path.join(dirpath, f)

@@ -1,0 +1,313 @@
+"""GPU parity tests: the HIP path (through the C ABI, libcudamat_hip.so) against the CPU
+oracle on the same inputs.  Integer/index work and integer-valued SpMV are bit-exact;
+floating-point tolerances are the ones SURVEY.md section 8c states, written at each test.
+Run on the GPU box with:  python -m pytest tests -m gpu"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope="module")
+def cm():
+    import cuda_mat_amd as cm
+    assert cm.device_count() > 0, "no HIP device: the product has no CPU fallback"
+    return cm
+
+
+@pytest.fixture(scope="module")
+def ctx(cm):
+    c = cm.Context(0)
+    yield c
+    c.close()
+
+
+def _load(oracle, golden_dir, name):
+    return oracle.mtx_load(os.path.join(golden_dir, name + ".mtx"))
+
+
+def _dev_csr(ctx, A):
+    return ctx.array(A.rowptr), ctx.array(A.colidx), ctx.array(A.val)
+
+
+# ------------------------------------------------------------------ generators
+def test_rand_generator_matches_oracle(ctx, oracle):
+    n, per_row, seed = 20000, 50, 0x5EED
+    for row0, row1, base in [(0, n, 0), (5000, 9000, 1), (n - 17, n, 0)]:
+        want = oracle.rand_rows(n, per_row, seed, row0, row1, base)
+        nr = row1 - row0
+        rp, ci, v = ctx.empty(nr + 1, np.int32), ctx.empty(nr * 50, np.int32), ctx.empty(nr * 50)
+        ctx.gen_rand_rows(n, per_row, seed, row0, row1, base, rp, ci, v)
+        np.testing.assert_array_equal(rp.download(), want.rowptr)
+        np.testing.assert_array_equal(ci.download(), want.colidx)
+        np.testing.assert_array_equal(v.download(), want.val)
+        for a in (rp, ci, v):
+            a.free()
+    # tiny n: fewer than per_row distinct columns exist
+    want = oracle.rand_rows(7, 50, 1)
+    rp, ci, v = ctx.empty(8, np.int32), ctx.empty(49, np.int32), ctx.empty(49)
+    ctx.gen_rand_rows(7, 50, 1, 0, 7, 0, rp, ci, v)
+    np.testing.assert_array_equal(ci.download(), want.colidx)
+    np.testing.assert_array_equal(v.download(), want.val)
+
+
+@pytest.mark.parametrize("nx,ny", [(40, 25), (1, 9), (9, 1), (100, 100)])
+def test_poisson_generator_matches_oracle(ctx, oracle, nx, ny):
+    want = oracle.poisson5(nx, ny, base=1)
+    n = nx * ny
+    rp, ci, v = ctx.empty(n + 1, np.int32), ctx.empty(want.nnz, np.int32), ctx.empty(want.nnz)
+    ctx.gen_poisson5(nx, ny, 0, n, 1, rp, ci, v)
+    np.testing.assert_array_equal(rp.download(), want.rowptr)
+    np.testing.assert_array_equal(ci.download(), want.colidx)
+    np.testing.assert_array_equal(v.download(), want.val)
+    # a row block carries a local rowptr and global column ids
+    r0, r1 = n // 3, (2 * n) // 3 + 1
+    k0, k1 = want.rowptr[r0] - 1, want.rowptr[r1] - 1
+    rp2, ci2, v2 = ctx.empty(r1 - r0 + 1, np.int32), ctx.empty(k1 - k0, np.int32), ctx.empty(k1 - k0)
+    ctx.gen_poisson5(nx, ny, r0, r1, 0, rp2, ci2, v2)
+    np.testing.assert_array_equal(rp2.download(), want.rowptr[r0:r1 + 1] - want.rowptr[r0])
+    np.testing.assert_array_equal(ci2.download(), want.colidx[k0:k1] - 1)
+    np.testing.assert_array_equal(v2.download(), want.val[k0:k1])
+
+
+def test_xstar_matches_oracle(ctx, oracle):
+    x = ctx.empty(1000)
+    ctx.gen_xstar(123, 1123, 77, x)
+    np.testing.assert_array_equal(x.download(), oracle.xstar(5000, 77, 123, 1123))
+
+
+# ------------------------------------------------------------------------ SpMV
+@pytest.mark.parametrize("name", ["mat3", "mat900", "mat10000", "rand20000x50", "poisson300x200"])
+@pytest.mark.parametrize("lanes", [None, 2, 16, 64])
+def test_spmv_bit_exact_on_integer_data(ctx, oracle, golden_dir, name, lanes, monkeypatch):
+    """integer-valued A and x: every product and partial sum is exact in fp64, so the
+    result is independent of summation order => bit-exact against MatrixVectorMult
+    (bicstab.cpp:69-80) for every lanes-per-row variant of the kernel."""
+    if lanes:
+        monkeypatch.setenv("CUDAMAT_SPMV_LANES", str(lanes))
+    if name == "rand20000x50":
+        A = oracle.rand_rows(20000, 50, 0x5EED)
+    elif name == "poisson300x200":
+        A = oracle.poisson5(300, 200, base=1)
+    else:
+        A = _load(oracle, golden_dir, name)
+    rng = np.random.default_rng(1)
+    x = rng.integers(-8, 9, A.n).astype(np.float64)
+    want = oracle.spmv(A, x)
+    rp, ci, v = _dev_csr(ctx, A)
+    dx, dy = ctx.array(x), ctx.empty(A.n)
+    ctx.spmv(A.n, rp, ci, v, A.base, dx, dy)
+    np.testing.assert_array_equal(dy.download(), want)
+    # the other base
+    B = A.rebased(1 - A.base)
+    rp2, ci2 = ctx.array(B.rowptr), ctx.array(B.colidx)
+    dy.zero()
+    ctx.spmv(A.n, rp2, ci2, v, B.base, dx, dy)
+    np.testing.assert_array_equal(dy.download(), want)
+    # csrmv call-site forms: (alpha,beta) = (-1,0) pbicgstab.cu:469, (-1,1) :646, (1,1) :676
+    y0 = rng.integers(-8, 9, A.n).astype(np.float64)
+    d = rng.integers(-3, 4, A.n).astype(np.float64)
+    for alpha, beta in [(-1.0, 0.0), (-1.0, 1.0), (1.0, 1.0)]:
+        dy.upload(y0)
+        ctx.spmv(A.n, rp, ci, v, A.base, dx, dy, alpha=alpha, beta=beta)
+        np.testing.assert_array_equal(dy.download(), oracle.csrmv(A, alpha, x, beta, y0))
+    # fused diagonal term = mult_spec + csrmv(beta=1), pbicgstab.cu:675-676
+    dd = ctx.array(d)
+    ctx.spmv(A.n, rp, ci, v, A.base, dx, dy, d=dd)
+    np.testing.assert_array_equal(dy.download(), oracle.csrmv(A, 1.0, x, 1.0, x * d))
+
+
+def test_spmv_real_data_tolerance(ctx, oracle, golden_dir):
+    """real-valued data: |y - y_ref| <= 4 nnz_row eps sum|a_ij x_j|"""
+    A = oracle.rand_rows(20000, 50, 3)
+    rng = np.random.default_rng(2)
+    A.val[:] = rng.standard_normal(A.nnz)
+    x = rng.standard_normal(A.n)
+    want = oracle.spmv(A, x)
+    absA = oracle.Csr(A.n, A.rowptr, A.colidx, np.abs(A.val), A.m)
+    bound = 4 * 50 * EPS * oracle.spmv(absA, np.abs(x))
+    rp, ci, v = _dev_csr(ctx, A)
+    dx, dy = ctx.array(x), ctx.empty(A.n)
+    ctx.spmv(A.n, rp, ci, v, 0, dx, dy)
+    assert np.all(np.abs(dy.download() - want) <= bound)
+
+
+def test_spmv_ragged_and_empty_rows(ctx, oracle):
+    """empty rows, one very long row, n not a multiple of anything"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    n = 1237
+    S = sp.random(n, n, density=0.01, random_state=7, format="lil")
+    S[5, :] = 0
+    S[17, :] = 1.0            # dense row
+    S[n - 1, :] = 0           # empty last row
+    S = S.tocsr()
+    S.data[:] = rng.integers(1, 5, S.nnz)
+    S.sort_indices()
+    A = oracle.Csr(n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), n)
+    x = rng.integers(-4, 5, n).astype(np.float64)
+    rp, ci, v = _dev_csr(ctx, A)
+    dx, dy = ctx.array(x), ctx.empty(n)
+    ctx.spmv(n, rp, ci, v, 0, dx, dy)
+    np.testing.assert_array_equal(dy.download(), oracle.spmv(A, x))
+
+
+# ------------------------------------------------------------------- BLAS-1 pieces
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 1000, 100003, 1 << 20])
+def test_dot_nrm2_axpy_scal(cm, ctx, n):
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dy = ctx.array(x), ctx.array(y)
+    ref = math.fsum(x * y)
+    scale = math.fsum(np.abs(x * y))
+    got = ctx.dot(n, dx, dy)
+    assert abs(got - ref) <= 1e-13 * scale          # rel 1e-13 vs an exact sum
+    assert got == ctx.dot(n, dx, dy)                # fixed reduction order => reproducible
+    nr = ctx.nrm2(n, dx)
+    assert abs(nr - math.sqrt(math.fsum(x * x))) <= 1e-13 * nr
+    ctx.axpy(n, 0.375, dx, dy)
+    np.testing.assert_allclose(dy.download(), 0.375 * x + y, rtol=4 * EPS, atol=4 * EPS)
+    ctx.scal(n, -2.0, dx)
+    np.testing.assert_array_equal(dx.download(), -2.0 * x)
+    # misaligned operands take the scalar path: same result
+    if n > 3:
+        big = ctx.array(np.concatenate([[0.0], x]))
+        out = ctx.empty(1)
+        cm.api.check(cm.lib().cudamat_dot(ctx.h, n - 1, big.ptr + 8, big.ptr + 8, out.ptr))
+        assert abs(out.download()[0] - math.fsum(x[:n - 1] ** 2)) <= 1e-13 * math.fsum(x ** 2)
+
+
+# ------------------------------------------------------------------------- solver
+def _solve_dev(cm, ctx, A, b, x0=None, d=None, **kw):
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+    db = ctx.array(b)
+    dx = ctx.array(np.ones(A.n) if x0 is None else x0)
+    if d is not None:
+        s.set_shift(ctx.array(d))
+    st = s.solve(db, dx, **kw)
+    x = dx.download()
+    h = s.history()
+    s.close()
+    return x, st, h
+
+
+@pytest.mark.parametrize("name,tol", [("mat900", 1e-6), ("mat900", 1e-8), ("mat10000", 1e-8)])
+def test_pbicgstab_no_precond_vs_oracle(cm, ctx, oracle, golden_dir, name, tol):
+    """gpu_pbicgstab (pbicgstab.cu:45-154) with M = I, x0 = 1, b = A x*.
+    Tolerances: true residual <= 1e-7 * ||r0|| at tol 1e-8 (10 tol in general),
+    ||x_gpu - x_cpu|| / ||x_cpu|| <= 1e-5, iteration count within +-10 % (>= +-2)."""
+    A = _load(oracle, golden_dir, name)
+    xs = 1.0 + np.sin(np.arange(A.n))
+    b = oracle.spmv(A, xs)
+    xo, so, ho = oracle.pbicgstab(A, b, maxit=2000, tol=tol, want_hist=True)
+    x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=2000, tol=tol)
+    assert st.converged and so.converged
+    assert abs(st.iters - so.iters) <= max(2, 0.1 * so.iters)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5
+    assert np.linalg.norm(b - oracle.spmv(A, x)) <= 10 * tol * so.nrm0
+    assert abs(st.nrm0 - so.nrm0) <= 1e-12 * so.nrm0
+    # the convergence history starts out identical to rounding and ends below tol
+    k = min(len(h), 8)
+    np.testing.assert_allclose(h[:k], ho[:k], rtol=1e-9)
+    assert len(h) == 2 * st.iters + (1 if st.half_exit else 0)
+    assert h[-1] < tol * st.nrm0 and np.all(h[:-1] >= tol * st.nrm0)
+
+
+def test_freeze_on_exit_is_exact(cm, ctx, oracle, golden_dir):
+    """kernels enqueued past the stopping point must not change x: the result with a huge
+    maxit is bit-identical to the result when the loop is cut at the converged iteration."""
+    A = _load(oracle, golden_dir, "mat900")
+    b = oracle.spmv(A, 1.0 + np.sin(np.arange(A.n)))
+    x1, st1, _ = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=2000, tol=1e-8)
+    cut = st1.iters + (1 if st1.half_exit else 0)
+    x2, st2, _ = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=cut, tol=1e-8)
+    assert st2.iters == st1.iters and st2.half_exit == st1.half_exit and st2.converged
+    np.testing.assert_array_equal(x1, x2)
+    # and a repeat gives the same bits (deterministic reductions)
+    x3, st3, _ = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=2000, tol=1e-8)
+    np.testing.assert_array_equal(x1, x3)
+
+
+def test_pbicgstab2_variants_vs_oracle(cm, ctx, oracle, golden_dir):
+    """gpu_pbicgstab2 (pbicgstab.cu:581-754): mat3 known answer through the (A0 + I d) form,
+    then mat900 with its diagonal split off, against the oracle restatement."""
+    A0 = _load(oracle, golden_dir, "mat3_A0")
+    d = oracle.to_dense_vector(_load(oracle, golden_dir, "vec3_d"))
+    b = oracle.to_dense_vector(_load(oracle, golden_dir, "vec3"))
+    x, st, h = _solve_dev(cm, ctx, A0, b, x0=np.ones(3), d=d, loop=cm.LOOP_PBICGSTAB2, maxit=2000, tol=1e-5)
+    ok, xo, so, ho = oracle.pbicgstab2(A0, b, d=d, tol=1e-5, want_hist=True)
+    assert st.converged and st.iters == so.iters == 3
+    np.testing.assert_allclose(x, [7 / 6, 17 / 3, -23 / 6], rtol=1e-7)
+    np.testing.assert_allclose(h, ho[:3], rtol=1e-6)
+
+    A = _load(oracle, golden_dir, "mat900")
+    S = A.to_scipy().tolil()
+    dg = S.diagonal().copy()
+    S.setdiag(0)
+    S = S.tocsr()
+    S.eliminate_zeros()
+    S.sort_indices()
+    A0 = oracle.Csr(A.n, (S.indptr + 1).astype(np.int32), (S.indices + 1).astype(np.int32), S.data, A.n)
+    b = oracle.spmv(A, 1.0 + np.sin(np.arange(A.n)))
+    x0 = np.cos(np.arange(A.n))
+    ok, xo, so = oracle.pbicgstab2(A0, b, d=dg, x0=x0, tol=1e-8)
+    x, st, h = _solve_dev(cm, ctx, A0, b, x0=x0, d=dg, loop=cm.LOOP_PBICGSTAB2, maxit=2000, tol=1e-8)
+    assert ok and st.converged and abs(st.iters - so.iters) <= max(2, 0.1 * so.iters)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5
+    assert np.linalg.norm(b - oracle.spmv(A, x)) <= 1e-7 * so.nrm0
+
+
+def test_pbicgstab2_breakdown_and_maxit(cm, ctx, oracle):
+    A = oracle.poisson5(30, 30, base=0)
+    b = oracle.spmv(A, 1.0 + np.sin(np.arange(A.n)))
+    x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB2, maxit=3, tol=1e-12)
+    ok, xo, so = oracle.pbicgstab2(A, b, maxit=3, tol=1e-12)
+    assert not st.converged and not st.breakdown and st.iters == 3 == so.iters
+    np.testing.assert_allclose(x, xo, rtol=1e-9)
+    # omega = 0 on a skew-symmetric matrix => the |omega| < 1e-5 guard (pbicgstab.cu:735)
+    Ask = oracle.Csr(2, np.array([0, 1, 2], np.int32), np.array([1, 0], np.int32), np.array([1.0, -1.0]), 2)
+    x, st, h = _solve_dev(cm, ctx, Ask, np.array([1.0, 2.0]), loop=cm.LOOP_PBICGSTAB2, maxit=10, tol=1e-12)
+    assert st.breakdown and not st.converged and st.iters == 1
+    # maxit = 0 leaves x = x0
+    x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=0, tol=1e-8)
+    assert st.iters == 0 and not st.converged and np.all(x == 1.0)
+
+
+def test_drop_in_entry_points(cm, oracle, golden_dir):
+    """the host-pointer functions that mirror pbicgstab.h:113,116 (bool result, x, dtAlg)"""
+    A = _load(oracle, golden_dir, "mat10000")
+    xs = 1.0 + np.sin(np.arange(A.n))
+    b = oracle.spmv(A, xs)
+    ok, x, dt, st = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 2000, 1e-8)
+    oko, xo, so = oracle.pbicgstab2(A, b, tol=1e-8)
+    assert ok and oko and dt > 0
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5
+    assert np.linalg.norm(x - xs) / np.linalg.norm(xs) <= 5e-6
+    ok, x, dt, st = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 5, 1e-8)
+    assert not ok and st.iters == 5
+    # solution agrees with the reference CPU program's own output on the same system
+    g = np.load(os.path.join(golden_dir, "bicg_mat10000_sin.npz"))
+    ok, x, dt, st = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, g["b"], 2000, 1e-8)
+    assert ok and np.linalg.norm(x - g["x"]) / np.linalg.norm(g["x"]) <= 2e-5   # its 6-digit print + eps 1e-6
+    A0 = _load(oracle, golden_dir, "mat3_A0")
+    d = oracle.to_dense_vector(_load(oracle, golden_dir, "vec3_d"))
+    b3 = oracle.to_dense_vector(_load(oracle, golden_dir, "vec3"))
+    ok, x, dt, st = cm.bicgstab_d(3, A0.nnz, A0.val, A0.rowptr, A0.colidx, d, np.ones(3), b3, 2000, 1e-5)
+    assert ok
+    np.testing.assert_allclose(x, [7 / 6, 17 / 3, -23 / 6], rtol=1e-7)
+
+
+def test_rand_matrix_solution_matches_reference_program(cm, ctx, oracle, golden_dir):
+    """the synthetic random matrix (integer entries) at 20000 x 50: GPU BiCGSTAB solution vs the
+    UNMODIFIED reference CPU program's printed solution (tests/golden/bicg_rand20000x50.npz)."""
+    g = np.load(os.path.join(golden_dir, "bicg_rand20000x50.npz"))
+    A = oracle.rand_rows(20000, 50, 0x5EED)
+    x, st, h = _solve_dev(cm, ctx, A, g["b"], loop=cm.LOOP_PBICGSTAB, maxit=2000, tol=1e-8)
+    assert st.converged
+    assert np.linalg.norm(x - g["x"]) / np.linalg.norm(g["x"]) <= 1e-5
+    np.testing.assert_allclose(x, oracle.xstar(20000, 0x5EED + 1), rtol=1e-7)
