@@ -74,7 +74,12 @@ def lib():
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_to_dense_vector.argtypes = [C.c_int, C.c_int, f64p, i32p, f64p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
         _lib = L
+        # A GPU box exposes every host core but grants a CPU share of about 16: an OpenMP team
+        # of 128 spinning threads makes the small solves of the test-suite crawl.
+        if "OMP_NUM_THREADS" not in os.environ:
+            L.orc_set_num_threads(default_threads())
     return _lib
 
 
@@ -256,8 +261,20 @@ def to_dense_vector(A):
     return out
 
 
+def default_threads():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(16, avail))
+
+
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
 
 
 # ---- the unmodified reference (oracle/_ref), only where it was built --------

@@ -243,7 +243,8 @@ def test_pbicgstab2_variants_vs_oracle(cm, ctx, oracle, golden_dir):
     ok, xo, so, ho = oracle.pbicgstab2(A0, b, d=d, tol=1e-5, want_hist=True)
     assert st.converged and st.iters == so.iters == 3
     np.testing.assert_allclose(x, [7 / 6, 17 / 3, -23 / 6], rtol=1e-7)
-    np.testing.assert_allclose(h, ho[:3], rtol=1e-6)
+    np.testing.assert_allclose(h[:2], ho[:2], rtol=1e-6)   # the third is pure rounding noise
+    assert len(h) == 3 and h[2] < 1e-5 * st.nrm0
 
     A = _load(oracle, golden_dir, "mat900")
     S = A.to_scipy().tolil()
