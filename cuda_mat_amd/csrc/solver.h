@@ -61,6 +61,7 @@ struct cudamat_solver {
     double *lu = nullptr;      // nnz doubles on A's pattern
     int *diag_pos = nullptr;   // position of the diagonal in each row
     cm::TriFactor L, U;
+    void *ilu_plans = nullptr;  // launch plans owned by ilu.hip
     double t_analysis = 0.0, t_factor = 0.0;
 };
 

@@ -312,3 +312,85 @@ def test_rand_matrix_solution_matches_reference_program(cm, ctx, oracle, golden_
     assert st.converged
     assert np.linalg.norm(x - g["x"]) / np.linalg.norm(g["x"]) <= 1e-5
     np.testing.assert_allclose(x, oracle.xstar(20000, 0x5EED + 1), rtol=1e-7)
+
+
+# ------------------------------------------------------------- ILU(0) + triangular solves
+def _real_sparse(oracle, n, density, seed, base=0):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, n, density=density, random_state=seed, format="csr")
+    S.data[:] = rng.uniform(-1, 1, S.nnz)
+    S = (S + sp.diags(4.0 + rng.random(n))).tocsr()
+    S.sort_indices()
+    return oracle.Csr(n, (S.indptr + base).astype(np.int32), (S.indices + base).astype(np.int32),
+                      S.data.copy(), n)
+
+
+@pytest.mark.parametrize("name", ["mat900", "mat10000", "rand20000x50", "real3000", "longrows"])
+def test_ilu0_factors_and_trsv_vs_oracle(cm, ctx, oracle, golden_dir, name):
+    """cusparseDcsrilu0 + csrsv_solve replacements (pbicgstab.cu:359, :92-98) against the oracle's
+    sequential IKJ ILU(0) and substitutions.  Tolerance: rtol 1e-12 on the factors (same operations,
+    different association only inside a row update), 1e-10 on the preconditioner application."""
+    if name == "rand20000x50":
+        A = oracle.rand_rows(20000, 50, 0x5EED)
+    elif name == "real3000":
+        A = _real_sparse(oracle, 3000, 0.004, 11, base=1)
+    elif name == "longrows":
+        A = _real_sparse(oracle, 400, 0.6, 5)          # ~240 entries per row, deep dependency chains
+    else:
+        A = _load(oracle, golden_dir, name)
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+    s.ilu0()
+    want = oracle.ilu0(A)
+    np.testing.assert_allclose(s.ilu0_values(), want, rtol=1e-12, atol=1e-14)
+    rng = np.random.default_rng(0)
+    rhs = rng.standard_normal(A.n)
+    dr, do = ctx.array(rhs), ctx.empty(A.n)
+    s.precond_apply(dr, do)
+    ref = oracle.trsv_upper(A, want, oracle.trsv_lower_unit(A, want, rhs))
+    np.testing.assert_allclose(do.download(), ref, rtol=1e-10, atol=1e-12)
+    # level counts equal the dependency depth the oracle computes
+    st = s.solve(dr, do, precond=cm.PRECOND_ILU0, maxit=1, tol=1e-30, flags=cm.FLAG_X0_ONES)
+    assert st.n_levels_l == oracle.levels(A, upper=False)[0]
+    assert st.n_levels_u == oracle.levels(A, upper=True)[0]
+    s.close()
+
+
+@pytest.mark.parametrize("name,tol", [("mat900", 1e-6), ("mat900", 1e-8), ("mat10000", 1e-8)])
+def test_pbicgstab_ilu0_vs_oracle(cm, ctx, oracle, golden_dir, name, tol):
+    """bicgstab_lu_precond's loop (pbicgstab.cu:45-154 with M = LU) vs the oracle restatement"""
+    A = _load(oracle, golden_dir, name)
+    xs = 1.0 + np.sin(np.arange(A.n))
+    b = oracle.spmv(A, xs)
+    xo, so, ho = oracle.pbicgstab(A, b, vm=oracle.ilu0(A), maxit=2000, tol=tol, want_hist=True)
+    x, st, h = _solve_dev(cm, ctx, A, b, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PBICGSTAB, maxit=2000, tol=tol)
+    assert st.converged and abs(st.iters - so.iters) <= max(2, 0.1 * so.iters)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5
+    assert np.linalg.norm(b - oracle.spmv(A, x)) <= 10 * tol * so.nrm0
+    k = min(len(h), 6)
+    np.testing.assert_allclose(h[:k], ho[:k], rtol=1e-8)
+
+
+def test_ilu0_rejects_missing_diagonal_and_lu_drop_in(cm, ctx, oracle, golden_dir):
+    A3 = _load(oracle, golden_dir, "mat3")      # no (2,2) entry: violates pbicgstab.h:118
+    s = cm.Solver.from_host_csr(ctx, A3.rowptr, A3.colidx, A3.val)
+    with pytest.raises(cm.CudamatError) as e:
+        s.ilu0()
+    assert e.value.code == 3
+    s.close()
+    # numerically zero pivot
+    Z = oracle.Csr(2, np.array([0, 2, 4], np.int32), np.array([0, 1, 0, 1], np.int32),
+                   np.array([1.0, 1.0, 1.0, 1.0]), 2)
+    s = cm.Solver.from_host_csr(ctx, Z.rowptr, Z.colidx, Z.val)
+    with pytest.raises(cm.CudamatError) as e:
+        s.ilu0()
+    assert e.value.code == 3
+    s.close()
+    A = _load(oracle, golden_dir, "mat10000")
+    xs = 1.0 + np.sin(np.arange(A.n))
+    b = oracle.spmv(A, xs)
+    ok, x, dt, st = cm.bicgstab_lu_precond(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 2000, 1e-8)
+    assert ok and st.converged and st.n_levels_l == 199
+    assert np.linalg.norm(x - xs) / np.linalg.norm(xs) <= 5e-6
+    ok, x, dt, st = cm.bicgstab_lu_precond(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 2, 1e-8)
+    assert ok and not st.converged       # the reference returns true regardless (pbicgstab.cu:408)
