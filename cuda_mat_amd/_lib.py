@@ -68,6 +68,7 @@ _SIGS = {
     "cudamat_free": (C.c_int, [_P, _P]),
     "cudamat_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "cudamat_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "cudamat_d2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "cudamat_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
     "cudamat_timer_create": (C.c_int, [_P, C.POINTER(_P)]),
     "cudamat_timer_start": (C.c_int, [_P, _P]),

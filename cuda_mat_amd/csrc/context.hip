@@ -137,6 +137,14 @@ extern "C" int cudamat_d2h(cudamat_ctx *ctx, void *host, const void *dev, size_t
     return CUDAMAT_OK;
 }
 
+extern "C" int cudamat_d2d(cudamat_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    CM_ARG(ctx && (bytes == 0 || (dst && src)), "null pointer");
+    if (!bytes) return CUDAMAT_OK;
+    CM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return CUDAMAT_OK;
+}
+
 extern "C" int cudamat_memset(cudamat_ctx *ctx, void *dev, int value, size_t bytes)
 {
     CM_ARG(ctx && (bytes == 0 || dev), "null pointer");

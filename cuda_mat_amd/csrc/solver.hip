@@ -152,7 +152,9 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     CM_ARG(s, "solver is NULL");
     hipStreamSynchronize(s->ctx->stream);
     free_work(s);
-    if (!comm || comm->world <= 1) {
+    const char *force = getenv("CUDAMAT_FORCE_SHARDED");
+    const bool forced = comm && comm->world == 1 && force && force[0] == '1';
+    if (!comm || (comm->world <= 1 && !forced)) {
         s->sharded = false;
         s->n_pad = s->n;
         return CUDAMAT_OK;

@@ -125,6 +125,7 @@ int cudamat_malloc(cudamat_ctx *ctx, size_t bytes, void **dev);
 int cudamat_free(cudamat_ctx *ctx, void *dev);
 int cudamat_h2d(cudamat_ctx *ctx, void *dev, const void *host, size_t bytes);
 int cudamat_d2h(cudamat_ctx *ctx, void *host, const void *dev, size_t bytes);
+int cudamat_d2d(cudamat_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async, stream-ordered */
 int cudamat_memset(cudamat_ctx *ctx, void *dev, int value, size_t bytes);
 
 /* stream-ordered timers (HIP events on the context's stream)                        */
@@ -168,7 +169,8 @@ int cudamat_solver_ilu0(cudamat_solver *s);
 int cudamat_solver_ilu0_values(cudamat_solver *s, double *out_dev);
 /* out = U^-1 L^-1 in  (what one preconditioning step applies, pbicgstab.cu:92-98)     */
 int cudamat_solver_precond_apply(cudamat_solver *s, const double *in, double *out);
-/* row-sharded operation; comm is copied.  world == 1 or NULL => single GPU.           */
+/* row-sharded operation; comm is copied.  world == 1 or NULL => single GPU (unless the
+ * environment sets CUDAMAT_FORCE_SHARDED=1, which keeps the collective path for testing). */
 int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *comm);
 /* y_local = (A + diag(d)) x ; x is the LOCAL slice, gathered through comm if sharded  */
 int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, double *y_local);

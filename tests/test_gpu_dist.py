@@ -1,0 +1,141 @@
+"""Row-sharded path on the GPU box (one GPU): the real C++ sharded loop driven by W emulated ranks
+(threads with their own contexts/streams; collectives = host-synchronised copies, tests/dist_sim.py)
+and by torch.distributed's NCCL(=RCCL) backend at world size 1 with the sharded path forced."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cm():
+    import cuda_mat_amd as cm
+    assert cm.device_count() > 0
+    return cm
+
+
+def _run_rank(cm, group, rank, n, A, b, out, **kw):
+    import dist_sim
+    from cuda_mat_amd.dist import shard_rows
+    try:
+        ctx = cm.Context(0)
+        row0, row1, per = shard_rows(n, group.world, rank)
+        rp = (A.rowptr[row0:row1 + 1] - A.rowptr[row0]).astype(np.int32)
+        k0, k1 = A.rowptr[row0], A.rowptr[row1]
+        s = cm.Solver.from_host_csr(ctx, rp, A.colidx[k0:k1], A.val[k0:k1], n_cols=n)
+        comm = dist_sim.ThreadComm(cm, group, rank, ctx)
+        s.set_comm(comm.struct)
+        db, dx = ctx.array(b[row0:row1]), ctx.array(np.ones(row1 - row0))
+        # y = A x through the sharded SpMV entry point
+        dy = ctx.empty(row1 - row0)
+        s.spmv(db, dy)
+        y = dy.download()
+        st = s.solve(db, dx, **kw)
+        out[rank] = (row0, row1, dx.download(), st.as_dict(), s.history(), y, comm.n_allgather, comm.n_allreduce)
+        s.close()
+        ctx.close()
+    except Exception as e:  # noqa: BLE001
+        group.barrier.abort()
+        out[rank] = e
+
+
+@pytest.mark.parametrize("world,n,per_row", [(2, 20000, 50), (3, 10007, 20), (4, 4096, 8)])
+def test_cpp_sharded_loop_with_emulated_ranks(cm, oracle, world, n, per_row):
+    import dist_sim
+    A = oracle.rand_rows(n, per_row, 0x5EED)
+    xs = oracle.xstar(n, 0x5EEE)
+    b = oracle.spmv(A, xs)
+    group = dist_sim.ThreadGroup(world)
+    out = [None] * world
+    th = [threading.Thread(target=_run_rank, args=(cm, group, r, n, A, b, out),
+                           kwargs=dict(loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    for o in out:
+        assert not isinstance(o, Exception) and o is not None, o
+    x = np.concatenate([o[2] for o in out])
+    y = np.concatenate([o[5] for o in out])
+    np.testing.assert_array_equal(y, oracle.spmv(A, b))          # integer-valued A, b in 1/8ths: exact
+    st0 = out[0][3]
+    for o in out:                                                # every rank took the same decisions
+        assert (o[3]["iters"], o[3]["half_exit"], o[3]["converged"]) == (st0["iters"], st0["half_exit"], st0["converged"])
+        np.testing.assert_array_equal(o[4], out[0][4])
+    xo, so, ho = oracle.pbicgstab(A, b, maxit=200, tol=1e-8, want_hist=True)
+    assert st0["converged"] and abs(st0["iters"] - so.iters) <= 1
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
+    np.testing.assert_allclose(x, xs, rtol=1e-7)
+    k = min(len(out[0][4]), 6)
+    np.testing.assert_allclose(out[0][4][:k], ho[:k], rtol=1e-9)
+    # single-GPU solve of the same system gives the same answer to rounding
+    ctx = cm.Context(0)
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+    db, dx = ctx.array(b), ctx.array(np.ones(n))
+    st1 = s.solve(db, dx, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8)
+    assert abs(st1.iters - st0["iters"]) <= 1
+    assert np.linalg.norm(dx.download() - x) / np.linalg.norm(x) <= 1e-8
+    s.close()
+    ctx.close()
+    # collective counts: init (1 gather for x0, 1 for the spmv call, 1 reduce), then 2 + 3 per iteration,
+    # plus whatever the host enqueued past the stopping point (at most kLag + 1 iterations)
+    it, half = st0["iters"], st0["half_exit"]
+    ran = it + (1 if half else 0)
+    assert 2 + 2 * ran <= out[0][6] <= 2 + 2 * (ran + 3)
+    assert 1 + 3 * ran <= out[0][7] <= 1 + 3 * (ran + 3)
+
+
+def test_sharded_rejects_mismatched_blocks_and_ilu(cm, oracle):
+    import dist_sim
+    A = oracle.rand_rows(1000, 10, 1)
+    ctx = cm.Context(0)
+    s = cm.Solver.from_host_csr(ctx, A.rowptr[:401] - A.rowptr[0], A.colidx[:A.rowptr[400]], A.val[:A.rowptr[400]],
+                                n_cols=1000)
+    comm = dist_sim.ThreadComm(cm, dist_sim.ThreadGroup(2), 0, ctx)
+    with pytest.raises(cm.CudamatError) as e:      # rank 0 of 2 must own 500 rows, has 400
+        s.set_comm(comm.struct)
+    assert e.value.code == 2
+    s.close()
+    ctx.close()
+
+
+def test_torch_nccl_world1_forced_sharded(cm, oracle, monkeypatch):
+    """TorchComm over the NCCL (= RCCL) backend on the real GPU: pointer->tensor views, stream
+    ordering against the context's stream (= torch's current stream) and the collective calls."""
+    import torch
+    import torch.distributed as dist
+    from cuda_mat_amd.dist import TorchComm
+    monkeypatch.setenv("CUDAMAT_FORCE_SHARDED", "1")
+    n = 20000
+    A = oracle.rand_rows(n, 50, 0x5EED)
+    xs = oracle.xstar(n, 0x5EEE)
+    b = oracle.spmv(A, xs)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", rank=0, world_size=1, device_id=dev)
+    try:
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            ctx = cm.Context(0, stream=stream.cuda_stream)
+            comm = TorchComm(device=dev)
+            s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+            s.set_comm(comm.struct)
+            tb = torch.from_numpy(b).to(dev)
+            tx = torch.ones(n, dtype=torch.float64, device=dev)
+            st = s.solve(tb, tx, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8)
+            stream.synchronize()
+            assert comm.error is None, comm.error
+            assert comm.n_allgather >= 1 + 2 * st.iters and comm.n_allreduce >= 1 + 3 * st.iters
+            x = tx.cpu().numpy()
+            s.close()
+            ctx.close()
+    finally:
+        dist.destroy_process_group()
+    xo, so = oracle.pbicgstab(A, b, maxit=200, tol=1e-8)
+    assert st.converged and abs(st.iters - so.iters) <= 1
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8

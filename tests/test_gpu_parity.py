@@ -320,7 +320,10 @@ def _real_sparse(oracle, n, density, seed, base=0):
     rng = np.random.default_rng(seed)
     S = sp.random(n, n, density=density, random_state=seed, format="csr")
     S.data[:] = rng.uniform(-1, 1, S.nnz)
-    S = (S + sp.diags(4.0 + rng.random(n))).tocsr()
+    S.setdiag(0)
+    S.eliminate_zeros()
+    # strictly diagonally dominant rows keep ILU(0) (no pivoting) well conditioned
+    S = (S + sp.diags(1.0 + rng.random(n) + np.asarray(abs(S).sum(axis=1)).ravel())).tocsr()
     S.sort_indices()
     return oracle.Csr(n, (S.indptr + base).astype(np.int32), (S.indices + base).astype(np.int32),
                       S.data.copy(), n)
