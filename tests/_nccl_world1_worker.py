@@ -1,0 +1,54 @@
+"""subprocess body of tests/test_gpu_dist.py::test_torch_nccl_world1_forced_sharded.
+torch is imported FIRST: torch wheels bundle their own HIP runtime, and a process must not
+initialise two of them (load order: torch, then libcudamat_hip.so, which then binds to it)."""
+import os
+import sys
+
+import torch  # noqa: F401  (first!)
+import torch.distributed as dist
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["CUDAMAT_FORCE_SHARDED"] = "1"
+
+import cuda_mat_amd as cm  # noqa: E402
+from cuda_mat_amd.dist import TorchComm  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    n = 20000
+    A = O.rand_rows(n, 50, 0x5EED)
+    xs = O.xstar(n, 0x5EEE)
+    b = O.spmv(A, xs)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[1], rank=0, world_size=1,
+                            device_id=dev)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = cm.Context(0, stream=stream.cuda_stream)
+        comm = TorchComm(device=dev)
+        s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+        s.set_comm(comm.struct)
+        tb = torch.from_numpy(b).to(dev)
+        tx = torch.ones(n, dtype=torch.float64, device=dev)
+        st = s.solve(tb, tx, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8)
+        stream.synchronize()
+        assert comm.error is None, comm.error
+        assert comm.n_allgather >= 1 + 2 * st.iters and comm.n_allreduce >= 1 + 3 * st.iters
+        x = tx.cpu().numpy()
+        s.close()
+        ctx.close()
+    dist.destroy_process_group()
+    xo, so = O.pbicgstab(A, b, maxit=200, tol=1e-8)
+    assert st.converged and abs(st.iters - so.iters) <= 1, (st.iters, so.iters)
+    err = np.linalg.norm(x - xo) / np.linalg.norm(xo)
+    assert err <= 1e-8, err
+    print("NCCL_WORLD1_OK iters=%d allgather=%d allreduce=%d err=%.2e" % (st.iters, comm.n_allgather,
+                                                                          comm.n_allreduce, err))
+
+
+if __name__ == "__main__":
+    main()

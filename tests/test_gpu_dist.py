@@ -104,38 +104,16 @@ def test_sharded_rejects_mismatched_blocks_and_ilu(cm, oracle):
     ctx.close()
 
 
-def test_torch_nccl_world1_forced_sharded(cm, oracle, monkeypatch):
+def test_torch_nccl_world1_forced_sharded():
     """TorchComm over the NCCL (= RCCL) backend on the real GPU: pointer->tensor views, stream
-    ordering against the context's stream (= torch's current stream) and the collective calls."""
-    import torch
-    import torch.distributed as dist
-    from cuda_mat_amd.dist import TorchComm
-    monkeypatch.setenv("CUDAMAT_FORCE_SHARDED", "1")
-    n = 20000
-    A = oracle.rand_rows(n, 50, 0x5EED)
-    xs = oracle.xstar(n, 0x5EEE)
-    b = oracle.spmv(A, xs)
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", rank=0, world_size=1, device_id=dev)
-    try:
-        stream = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(stream):
-            ctx = cm.Context(0, stream=stream.cuda_stream)
-            comm = TorchComm(device=dev)
-            s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
-            s.set_comm(comm.struct)
-            tb = torch.from_numpy(b).to(dev)
-            tx = torch.ones(n, dtype=torch.float64, device=dev)
-            st = s.solve(tb, tx, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8)
-            stream.synchronize()
-            assert comm.error is None, comm.error
-            assert comm.n_allgather >= 1 + 2 * st.iters and comm.n_allreduce >= 1 + 3 * st.iters
-            x = tx.cpu().numpy()
-            s.close()
-            ctx.close()
-    finally:
-        dist.destroy_process_group()
-    xo, so = oracle.pbicgstab(A, b, maxit=200, tol=1e-8)
-    assert st.converged and abs(st.iters - so.iters) <= 1
-    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
+    ordering against the context's stream (= torch's current stream) and the collective calls.
+    Runs in a subprocess that imports torch first (one HIP runtime per process)."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nccl_world1_worker.py")
+    r = subprocess.run([sys.executable, worker, str(port)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
