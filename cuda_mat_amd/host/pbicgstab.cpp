@@ -1,0 +1,74 @@
+// pbicgstab.cpp -- libcuda_mat.so: the C++ entry points of include/pbicgstab.h and
+// include/mmio_wrapper.h as shims over the C ABI (libcudamat_hip.so).  Host code only.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+#include "mmio_wrapper.h"
+#include "pbicgstab.h"
+
+static thread_local cudamat_stats g_last;
+
+const cudamat_stats *cudamat_last_stats() { return &g_last; }
+
+double second(void)
+{
+    return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+double rand_float_0_1() { return static_cast<double>(rand()) / static_cast<double>(RAND_MAX); }
+
+double rand_float(double min, double max) { return rand_float_0_1() * (max - min) + min; }
+
+void gen_rand_vector(int n, double *vector, double probability_of_zero, double min, double max)
+{
+    for (int i = 0; i < n; ++i)
+        vector[i] = rand_float_0_1() <= probability_of_zero ? 0.0 : rand_float(min, max);
+}
+
+void toDenseVector(int n, int nnz, double *A, int *IA, double *out) { cudamat_to_dense_vector(n, nnz, A, IA, out); }
+
+int loadMMSparseMatrix(char *filename, char elem_type, bool csrFormat, int *m, int *n, int *nnz, double **aVal,
+                       int **aRowInd, int **aColInd)
+{
+    if (elem_type != 'd' && elem_type != 'D') {
+        std::fprintf(stderr, "!!!! only element type 'd' is supported\n");
+        return 1;
+    }
+    return cudamat_load_mtx(filename, csrFormat ? 1 : 0, m, n, nnz, aVal, aRowInd, aColInd) == CUDAMAT_OK ? 0 : 1;
+}
+
+static bool run(int n, int nnz, double *A, int *iA, int *jA, double *d, double *x0, double *b, int precond, int loop,
+                int maxit, double tol, bool debug, double *x, double *dtAlg, bool always_true)
+{
+    std::memset(&g_last, 0, sizeof(g_last));
+    const int rc = cudamat_solve(n, nnz, A, iA, jA, d, x0, b, precond, loop, maxit, tol, debug ? 1 : 0, x, &g_last);
+    if (dtAlg) *dtAlg = g_last.t_solve;
+    if (rc != CUDAMAT_OK) {
+        std::fprintf(stderr, "!!!! cudamat: %s\n", cudamat_last_error());
+        return false;
+    }
+    return always_true ? true : g_last.converged != 0;
+}
+
+bool bicgstab(int n, int nnz, double *A, int *iA, int *jA, double *b, int maxit, double tol, bool debug, double *x,
+              double *dtAlg)
+{
+    return run(n, nnz, A, iA, jA, nullptr, nullptr, b, CUDAMAT_PRECOND_NONE, CUDAMAT_LOOP_PBICGSTAB2, maxit, tol, debug,
+               x, dtAlg, false);
+}
+
+bool bicgstab(int n, int nnz, double *A0, int *iA0, int *jA0, double *d, double *x0, double *b, int maxit, double tol,
+              bool debug, double *x, double *dtAlg)
+{
+    return run(n, nnz, A0, iA0, jA0, d, x0, b, CUDAMAT_PRECOND_NONE, CUDAMAT_LOOP_PBICGSTAB2, maxit, tol, debug, x,
+               dtAlg, false);
+}
+
+bool bicgstab_lu_precond(int n, int nnz, double *A, int *iA, int *jA, double *b, int maxit, double tol, bool debug,
+                         double *x, double *dtAlg)
+{
+    // the reference reports success whenever the solve ran (pbicgstab.cu:408)
+    return run(n, nnz, A, iA, jA, nullptr, nullptr, b, CUDAMAT_PRECOND_ILU0, CUDAMAT_LOOP_PBICGSTAB, maxit, tol, debug, x,
+               dtAlg, true);
+}
