@@ -3,6 +3,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "spmv_pb.h"
 
 namespace cm {
 
@@ -32,6 +33,9 @@ struct cudamat_solver {
     double *val = nullptr;
     const double *d = nullptr;
     cm::SpmvPlan plan{};
+    int spmv_mode = -1;        // -1 undecided, 0 CSR wave-per-row kernel, 1 propagation-blocking kernels
+    cm::PbPlan pb{};
+    double ms_csr = 0.0, ms_pb = 0.0;   // auto-tune timings
 
     // work vectors (n_pad doubles each, pad kept zero)
     double *r = nullptr, *rw = nullptr, *p = nullptr, *pw = nullptr, *s = nullptr, *t = nullptr,

@@ -67,6 +67,8 @@ static int ensure_work(cudamat_solver *s)
     return CUDAMAT_OK;
 }
 
+static int ensure_spmv_mode(cudamat_solver *s);
+
 extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz,
                                      const int *rowptr, const int *colidx, const double *val,
                                      int base, cudamat_solver **out)
@@ -127,6 +129,7 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
     ilu0_release(s);
+    pb_free(&s->pb);
     free_work(s);
     void *ptrs[] = {s->rp, s->ci, s->val, s->parts_full, s->parts_rv, s->parts_half, s->parts_tt,
                     s->red, s->st, s->hist};
@@ -152,6 +155,8 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     CM_ARG(s, "solver is NULL");
     hipStreamSynchronize(s->ctx->stream);
     free_work(s);
+    pb_free(&s->pb);
+    s->spmv_mode = -1;
     const char *force = getenv("CUDAMAT_FORCE_SHARDED");
     const bool forced = comm && comm->world == 1 && force && force[0] == '1';
     if (!comm || (comm->world <= 1 && !forced)) {
@@ -206,7 +211,64 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
     a.loop = la;
     a.check = check;
     a.half = half;
+    if (s->spmv_mode == 1) return launch_spmv_pb(s->ctx->stream, s->pb, a);
     return launch_spmv(s->ctx->stream, s->plan, a);
+}
+
+// number of per-workgroup partial sums an SpMV launch leaves in `parts`
+static int spmv_parts(const cudamat_solver *s) { return s->spmv_mode == 1 ? s->pb.NRB : s->plan.grid; }
+
+// Choose the SpMV implementation for this matrix (once): the blocked two-phase kernels when the
+// columns are scattered over a vector far larger than L2 AND they measure faster than the
+// wave-per-row CSR kernel on this device.  CUDAMAT_SPMV_MODE=csr|pb overrides.
+static int ensure_spmv_mode(cudamat_solver *s)
+{
+    if (s->spmv_mode >= 0) return CUDAMAT_OK;
+    hipStream_t st = s->ctx->stream;
+    const char *env = getenv("CUDAMAT_SPMV_MODE");
+    const bool force_csr = env && !strcmp(env, "csr");
+    const bool force_pb = env && !strcmp(env, "pb");
+    s->spmv_mode = 0;
+    if (force_csr || s->n == 0 || s->nnz == 0) return CUDAMAT_OK;
+    if (!force_pb && !pb_candidate(st, s->n, s->n_cols, s->nnz, s->rp, s->ci)) return CUDAMAT_OK;
+    int rc = pb_build(st, s->n, s->n_cols, s->nnz, s->rp, s->ci, s->val, &s->pb);
+    if (rc != CUDAMAT_OK) {
+        if (force_pb) return rc;
+        return CUDAMAT_OK;            // e.g. out of memory for the blocked copy: keep CSR
+    }
+    if (force_pb) { s->spmv_mode = 1; return CUDAMAT_OK; }
+    const LoopArgs la_none{nullptr, nullptr, 0, 0, 0};
+    const ScalarSrc nosrc{nullptr, 0, 1};
+    const double *xin = s->sharded ? s->gather : s->p;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float ms[2] = {0.f, 0.f};
+    for (int mode = 0; mode < 2; mode++) {
+        s->spmv_mode = mode;
+        SpmvArgs a{};
+        a.n = s->n; a.rp = s->rp; a.ci = s->ci; a.val = s->val; a.x = xin; a.d = nullptr; a.xd = s->p;
+        a.alpha = 1.0; a.beta = 0.0; a.y = s->v; a.dot = 0; a.loop = la_none; a.check = CHECK_NONE; a.half = nosrc;
+        for (int rep = 0; rep < 3; rep++) {
+            if (rep == 1) hipEventRecord(e0, st);
+            rc = mode ? launch_spmv_pb(st, s->pb, a) : launch_spmv(st, s->plan, a);
+            if (rc) break;
+        }
+        hipEventRecord(e1, st);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms[mode], e0, e1);
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    CM_HIP(hipMemsetAsync(s->v, 0, sizeof(double) * (size_t)(s->n_pad > 0 ? s->n_pad : 1), st));
+    s->ms_csr = ms[0] / 2;
+    s->ms_pb = ms[1] / 2;
+    s->spmv_mode = (rc == CUDAMAT_OK && ms[1] < ms[0]) ? 1 : 0;
+    if (s->spmv_mode == 0) pb_free(&s->pb);
+    if (getenv("CUDAMAT_VERBOSE"))
+        fprintf(stderr, "cudamat: SpMV auto-tune csr %.3f ms, blocked %.3f ms (build %.3f s) -> %s\n", s->ms_csr, s->ms_pb,
+                s->pb.build_seconds, s->spmv_mode ? "blocked" : "csr");
+    return CUDAMAT_OK;
 }
 
 static int allreduce(cudamat_solver *s, double *buf, int count)
@@ -223,6 +285,7 @@ extern "C" int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, dou
     CM_ARG(s && x_local && y_local, "null pointer");
     CM_HIP(hipSetDevice(s->ctx->device));
     CM_TRY(ensure_work(s));
+    CM_TRY(ensure_spmv_mode(s));
     const double *xin = x_local;
     if (s->sharded) {   // the gather needs n_pad entries with a zero pad
         CM_HIP(hipMemcpyAsync(s->pw, x_local, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice,
@@ -272,6 +335,7 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
     const double t_begin = now_s();
     hipStream_t st = s->ctx->stream;
     CM_TRY(ensure_work(s));
+    CM_TRY(ensure_spmv_mode(s));
     if (precond && !s->has_ilu) CM_TRY(ilu0_setup(s));
 
     const int need_hist = (loop == CUDAMAT_LOOP_PBICGSTAB ? 2 : 1) * (maxit > 0 ? maxit : 1);
@@ -325,7 +389,7 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
         if (profile) hipEventRecord(prof_event(s, pe++), st);
         CM_TRY(spmv_local(s, pw, s->v, 1, s->rw, s->parts_rv, la, CHECK_NONE, nosrc));
         if (profile) hipEventRecord(prof_event(s, pe++), st);
-        ScalarSrc rv_src{s->parts_rv, s->plan.grid, 2};
+        ScalarSrc rv_src{s->parts_rv, spmv_parts(s), 2};
         if (sharded) {
             CM_TRY(launch_reduce_parts(st, rv_src, 1, s->red + 0, 0));
             CM_TRY(allreduce(s, s->red + 0, 1));
@@ -335,7 +399,7 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
         CM_TRY(launch_half(st, la, rv_src, n, s->r, s->v, x, pw, s->parts_half, &np_half));
         const ScalarSrc half_src{s->parts_half, np_half, 1};
         const double *sv = s->r;
-        ScalarSrc tt_src{s->parts_tt, s->plan.grid, 2};
+        ScalarSrc tt_src{s->parts_tt, spmv_parts(s), 2};
         if (!sharded) {
             if (precond) {                                        // :116, :121-127
                 CM_TRY(launch_check(st, la, half_src, CHECK_HALF));

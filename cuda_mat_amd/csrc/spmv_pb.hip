@@ -1,0 +1,421 @@
+// spmv_pb.hip -- two-phase ("propagation blocking") CSR SpMV for scattered columns.
+//
+// Why: with 50 random columns per row over an 80 MB x (C4), the wave-per-row CSR kernel is bound
+// by the fabric, not by HBM: every 8-byte gather of x misses the 4 MiB XCD L2 and drags a 128-byte
+// line (measured 69 GB moved per launch for 6.2 GB of algorithmic bytes).
+// Here both the gather side and the scatter side live in LDS and HBM sees only streams:
+//
+//   phase 1  one workgroup per COLUMN block: the x tile (<= 13 K doubles) is staged in LDS; the
+//            block's entries (value fp64 + local column u16, stored contiguously) are streamed and
+//            the products P[k] = val[k] * x[col[k]] are streamed back out (8 B each);
+//   phase 2  one workgroup per ROW block, one wavefront per sub-block of rows whose y tile sits
+//            in LDS: the wave walks the column blocks in order and adds the products of its
+//            (sub-block, column block) segment into the tile with ds_add_f64, then writes y
+//            (+ diagonal term, alpha/beta, fused dot partials).
+//
+// Entries are stored once, at analysis time, in (column block, row block, row, column) order.
+// A row's products therefore reach its accumulator in increasing column order, each product rounded
+// once and added once -- the same sequence of roundings as the reference CPU loop
+// `b[i] += A.Value[j] * x[A.Col[j]]` (bicstab_omp/bicstab.cpp:72-77) -- and a row is owned by exactly
+// one wave, so the result is deterministic (no inter-wave races, no global atomics).
+// HBM traffic per SpMV: 10 B/nnz read + 8 B/nnz written (phase 1), 10 B/nnz read (phase 2).
+#include <algorithm>
+#include <chrono>
+#include <vector>
+
+#include "spmv_pb.h"
+
+namespace cm {
+
+typedef unsigned short u16;
+constexpr int kPbBuildWaves = 4;
+constexpr int kP1Threads = 1024;
+constexpr int kTileMax = 13312;        // doubles per LDS tile (104 KB)
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T>
+static int dalloc(T **p, size_t count)
+{
+    *p = nullptr;
+    hipError_t e = hipMalloc((void **)p, sizeof(T) * (count ? count : 1));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", sizeof(T) * count, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? CUDAMAT_ERR_NOMEM : CUDAMAT_ERR_HIP;
+    }
+    return CUDAMAT_OK;
+}
+
+void pb_free(PbPlan *p)
+{
+    void *ptrs[] = {p->pv, p->pc, p->pr, p->P, p->cstart, p->sstart, p->slen};
+    for (void *q : ptrs)
+        if (q) hipFree(q);
+    *p = PbPlan();
+}
+
+// ------------------------------------------------------------------ candidate estimate
+__global__ __launch_bounds__(kBlock) void k_pb_span(int n, int samples, const int *rp, const int *ci,
+                                                    unsigned long long *acc)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= samples) return;
+    const int row = (int)(((long long)t * n) / samples);
+    const int s = rp[row], e = rp[row + 1];
+    if (e - s >= 2) {
+        atomicAdd(&acc[0], (unsigned long long)(ci[e - 1] - ci[s]));
+        atomicAdd(&acc[1], 1ULL);
+    }
+}
+
+bool pb_candidate(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci)
+{
+    if (n < 65536 || nnz < (1 << 22) || n_cols * 8 < (8 << 20)) return false;   // x within ~2 L2s: CSR is fine
+    if ((double)nnz / n < 8.0) return false;
+    if ((int64_t)n > (int64_t)kMaxParts * kTileMax) return false;
+    unsigned long long *acc = nullptr, h[2] = {0, 0};
+    if (hipMalloc((void **)&acc, 16) != hipSuccess) return false;
+    hipMemsetAsync(acc, 0, 16, st);
+    const int samples = n < 8192 ? n : 8192;
+    hipLaunchKernelGGL(k_pb_span, dim3((samples + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, samples, rp, ci, acc);
+    hipMemcpyAsync(h, acc, 16, hipMemcpyDeviceToHost, st);
+    hipStreamSynchronize(st);
+    hipFree(acc);
+    if (!h[1]) return false;
+    const double span_bytes = 8.0 * (double)h[0] / (double)h[1];
+    return span_bytes > (double)(16 << 20);      // a row's gathers spread over more than 4 L2s
+}
+
+// ------------------------------------------------------------------ analysis (one-off)
+// One wavefront per sub-block walks its rows in order.  COUNT: entries per column block.
+// FILL: place every entry at cursor[cb]++ (cursor in LDS, seeded with the global start of the
+// (cb, sub) segment) -- deterministic, no global atomics.  Equal-cb lanes of one load are adjacent
+// (columns are sorted), so a lane's rank inside its run is lane - (first lane of the run).
+template <bool FILL>
+__global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_rows(int n, const int *rp, const int *ci,
+                                                               const double *val, int CB, int NCB, int SR,
+                                                               int NSUB, int *bins, double *pv, u16 *pc, u16 *pr)
+{
+    extern __shared__ int lds_i[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub = blockIdx.x * kPbBuildWaves + wave;
+    if (sub >= NSUB) return;
+    int *cur = lds_i + (size_t)wave * NCB;
+    for (int c = lane; c < NCB; c += 64) cur[c] = FILL ? bins[(size_t)c * NSUB + sub] : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const long long row0 = (long long)sub * SR;
+    const int row1 = (int)(row0 + SR < n ? row0 + SR : n);
+    for (int row = (int)row0; row < row1; row++) {
+        const int rs = rp[row], re = rp[row + 1];
+        for (int k0 = rs; k0 < re; k0 += 64) {
+            const int k = k0 + lane;
+            const bool active = k < re;
+            const int col = active ? ci[k] : -1;
+            const int cb = active ? col / CB : -1;
+            const int prev = __shfl_up(cb, 1, 64);
+            const bool head = lane == 0 || cb != prev;
+            int hs = head ? lane : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(hs, o, 64);
+                if (lane >= o) hs = t > hs ? t : hs;
+            }
+            const int next = __shfl_down(cb, 1, 64);
+            const bool tail = lane == 63 || next != cb;
+            if (active) {
+                const int base = cur[cb];
+                const int rank = lane - hs;
+                if (FILL) {
+                    const int dest = base + rank;
+                    pv[dest] = val[k];
+                    pc[dest] = (u16)(col - cb * CB);
+                    pr[dest] = (u16)(row - (int)row0);
+                }
+                if (tail) cur[cb] = base + rank + 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (!FILL)
+        for (int c = lane; c < NCB; c += 64) bins[(size_t)c * NSUB + sub] = cur[c];
+}
+
+static int round_blocks(int64_t n, int tile_max)
+{
+    // number of blocks: a multiple of the CU count (whole rounds of workgroups) with tiles <= tile_max
+    int64_t m = (n + (int64_t)256 * tile_max - 1) / ((int64_t)256 * tile_max);
+    if (m < 1) m = 1;
+    return (int)(256 * m);
+}
+
+int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
+             const double *val, PbPlan *out)
+{
+    const double t0 = now_s();
+    PbPlan p;
+    p.n = n;
+    p.n_cols = n_cols;
+    p.nnz = nnz;
+    p.NCB = round_blocks(n_cols, kTileMax);
+    p.CB = (int)((n_cols + p.NCB - 1) / p.NCB);
+    p.NCB = (int)((n_cols + p.CB - 1) / p.CB);
+    p.NRB = round_blocks(n, kTileMax);
+    p.RB = (int)(((int64_t)n + p.NRB - 1) / p.NRB);
+    p.NRB = (int)(((int64_t)n + p.RB - 1) / p.RB);
+    // waves per row block: aim at ~56 entries per (sub-block, column block) segment
+    const double per_rb_cb = (double)nnz / ((double)p.NRB * p.NCB);
+    p.NW = per_rb_cb >= 640 ? 16 : per_rb_cb >= 320 ? 8 : 4;
+    p.SR = (p.RB + p.NW - 1) / p.NW;
+    p.RB = p.SR * p.NW;
+    p.NRB = (int)(((int64_t)n + p.RB - 1) / p.RB);
+    p.NSUB = p.NRB * p.NW;
+    if (p.NRB > kMaxParts || p.CB > 65536 || p.SR > 65536) {
+        set_error("pb_build: matrix shape outside the blocked kernel's limits");
+        return CUDAMAT_ERR_ARG;
+    }
+    const size_t nbins = (size_t)p.NCB * p.NSUB;
+    int *bins = nullptr;
+    int rc = CUDAMAT_OK;
+    do {
+        if ((rc = dalloc(&bins, nbins))) break;
+        if ((rc = dalloc(&p.pv, (size_t)nnz))) break;
+        if ((rc = dalloc(&p.pc, (size_t)nnz + 8))) break;
+        if ((rc = dalloc(&p.pr, (size_t)nnz + 8))) break;
+        if ((rc = dalloc(&p.P, (size_t)nnz + 8))) break;
+        if ((rc = dalloc(&p.cstart, (size_t)p.NCB + 1))) break;
+        if ((rc = dalloc(&p.sstart, nbins))) break;
+        if ((rc = dalloc(&p.slen, nbins))) break;
+        const unsigned grid = (unsigned)((p.NSUB + kPbBuildWaves - 1) / kPbBuildWaves);
+        const size_t lds = sizeof(int) * (size_t)kPbBuildWaves * p.NCB;
+        hipFuncSetAttribute((const void *)k_pb_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)k_pb_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(k_pb_rows<false>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, p.CB,
+                           p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr);
+        if (hipGetLastError() != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb count launch failed"); break; }
+        std::vector<int> h(nbins), hs(nbins), hl(nbins), hc((size_t)p.NCB + 1);
+        if (hipMemcpyAsync(h.data(), bins, sizeof(int) * nbins, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb count failed"); break; }
+        // exclusive scan in storage order [cb][sub]; wave-major copies [sub][cb] for phase 2
+        int64_t run = 0;
+        for (int c = 0; c < p.NCB; c++) {
+            hc[(size_t)c] = (int)run;
+            for (int s = 0; s < p.NSUB; s++) {
+                const size_t i = (size_t)c * p.NSUB + s;
+                const int cnt = h[i];
+                h[i] = (int)run;
+                hs[(size_t)s * p.NCB + c] = (int)run;
+                hl[(size_t)s * p.NCB + c] = cnt;
+                run += cnt;
+            }
+        }
+        hc[(size_t)p.NCB] = (int)run;
+        if (run != nnz) { rc = CUDAMAT_ERR_ARG; set_error("pb_build: counted %lld entries, expected %lld", (long long)run, (long long)nnz); break; }
+        if (hipMemcpyAsync(bins, h.data(), sizeof(int) * nbins, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(p.sstart, hs.data(), sizeof(int) * nbins, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(p.slen, hl.data(), sizeof(int) * nbins, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(p.cstart, hc.data(), sizeof(int) * ((size_t)p.NCB + 1), hipMemcpyHostToDevice, st) != hipSuccess) {
+            rc = CUDAMAT_ERR_HIP; set_error("pb table upload failed"); break;
+        }
+        hipLaunchKernelGGL(k_pb_rows<true>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, p.CB,
+                           p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rc = CUDAMAT_ERR_HIP; set_error("pb fill failed"); break;
+        }
+    } while (0);
+    if (bins) hipFree(bins);
+    if (rc) {
+        pb_free(&p);
+        return rc;
+    }
+    p.build_seconds = now_s() - t0;
+    *out = p;
+    return CUDAMAT_OK;
+}
+
+// ------------------------------------------------------------------ phase 1
+__global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, long long n_cols, int CB,
+                                                          const int *cstart, const double *pv, const u16 *pc,
+                                                          double *P, const LoopState *st)
+{
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    if (st && st->state != 0) return;
+    const int cb = blockIdx.x;
+    const long long c0 = (long long)cb * CB;
+    const int cn = (int)(n_cols - c0 < CB ? n_cols - c0 : CB);
+    for (int i = threadIdx.x; i < cn; i += kP1Threads) xs[i] = x[c0 + i];
+    __syncthreads();
+    const int s = cstart[cb], e = cstart[cb + 1];
+    // two entries per lane per step (16-byte value loads), four steps in flight
+    const int k0 = (s & ~1) + 2 * (int)threadIdx.x;
+    constexpr int STEP = 2 * kP1Threads;
+    for (int k = k0; k < e; k += 4 * STEP) {
+        double2 v[4];
+        ushort2 c[4];
+        bool full[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int kk = k + u * STEP;
+            full[u] = kk >= s && kk + 1 < e;
+            if (full[u]) {
+                v[u] = *(const double2 *)(pv + kk);
+                c[u] = *(const ushort2 *)(pc + kk);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int kk = k + u * STEP;
+            if (full[u]) {
+                double2 o;
+                o.x = v[u].x * xs[c[u].x];
+                o.y = v[u].y * xs[c[u].y];
+                *(double2 *)(P + kk) = o;
+            } else {
+                if (kk >= s && kk < e) P[kk] = pv[kk] * xs[pc[kk]];
+                if (kk + 1 >= s && kk + 1 < e) P[kk + 1] = pv[kk + 1] * xs[pc[kk + 1]];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ phase 2
+struct Pb2Args {
+    int n, NCB, SR;
+    const int *sstart, *slen;
+    const double *P;
+    const u16 *pr;
+    const double *d, *xd;
+    double alpha, beta;
+    double *y;
+    int dot;
+    const double *w;
+    double *parts;
+    const LoopState *st;
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) double yt[];   // NW * SR, then 2 * NW for the reduction
+    if (a.st && a.st->state != 0) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub = blockIdx.x * NW + wave;
+    double *my = yt + (size_t)wave * a.SR;
+    for (int i = lane; i < a.SR; i += 64) my[i] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int *ss = a.sstart + (size_t)sub * a.NCB;
+    const int *sl = a.slen + (size_t)sub * a.NCB;
+    for (int cb0 = 0; cb0 < a.NCB; cb0 += 64) {
+        const int c = cb0 + lane;
+        const int mys = c < a.NCB ? ss[c] : 0;
+        const int myl = c < a.NCB ? sl[c] : 0;
+        const int lim = a.NCB - cb0 < 64 ? a.NCB - cb0 : 64;
+        for (int j = 0; j < lim; j += 4) {
+            int s[4], l[4];
+            double pv4[4];
+            int r4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                // lanes past `lim` carry length 0, so j + u may safely run to 63
+                s[u] = __builtin_amdgcn_readlane(mys, (j + u) & 63);
+                l[u] = (j + u) < 64 ? __builtin_amdgcn_readlane(myl, (j + u) & 63) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool on = lane < l[u];
+                pv4[u] = on ? a.P[s[u] + lane] : 0.0;
+                r4[u] = on ? (int)a.pr[s[u] + lane] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (lane < l[u]) unsafeAtomicAdd(&my[r4[u]], pv4[u]);
+                for (int off = 64 + lane; off < l[u]; off += 64)        // segments longer than a wave
+                    unsafeAtomicAdd(&my[a.pr[s[u] + off]], a.P[s[u] + off]);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // epilogue: this wave's rows
+    double acc0 = 0.0, acc1 = 0.0;
+    const long long row0 = (long long)sub * a.SR;
+    for (int i = lane; i < a.SR && row0 + i < a.n; i += 64) {
+#pragma clang fp contract(off)   // one rounding per product and per sum, like cusparse's mult_spec + csrmv(beta=1)
+        const int row = (int)(row0 + i);
+        double sum = my[i];
+        if (a.d) {
+            const double dx = a.d[row] * a.xd[row];
+            sum = sum + dx;
+        }
+        double out = a.alpha * sum;
+        if (a.beta != 0.0) {
+            const double by = a.beta * a.y[row];
+            out = out + by;
+        }
+        a.y[row] = out;
+        if (a.dot) {
+            acc0 += out * a.w[row];
+            acc1 += out * out;
+        }
+    }
+    if (a.dot) {
+        double *red = yt + (size_t)NW * a.SR;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            acc0 += __shfl_xor(acc0, o, 64);
+            acc1 += __shfl_xor(acc1, o, 64);
+        }
+        if (lane == 0) {
+            red[2 * wave] = acc0;
+            red[2 * wave + 1] = acc1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t0 = 0.0, t1 = 0.0;
+            for (int q = 0; q < NW; q++) {
+                t0 += red[2 * q];
+                t1 += red[2 * q + 1];
+            }
+            a.parts[2 * blockIdx.x] = t0;
+            a.parts[2 * blockIdx.x + 1] = t1;
+        }
+    }
+}
+
+int launch_spmv_pb(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
+{
+    if (a.loop.st && a.check == CHECK_HALF) CM_TRY(launch_check(st, a.loop, a.half, CHECK_HALF));
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void *)k_pb_phase1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)k_pb_phase2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)k_pb_phase2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)k_pb_phase2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_pb_phase1, dim3(p.NCB), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x,
+                       (long long)p.n_cols, p.CB, p.cstart, p.pv, p.pc, p.P, a.loop.st);
+    Pb2Args b;
+    b.n = p.n; b.NCB = p.NCB; b.SR = p.SR;
+    b.sstart = p.sstart; b.slen = p.slen;
+    b.P = p.P; b.pr = p.pr;
+    b.d = a.d; b.xd = a.xd;
+    b.alpha = a.alpha; b.beta = a.beta;
+    b.y = a.y; b.dot = a.dot; b.w = a.w; b.parts = a.parts;
+    b.st = a.loop.st;
+    const size_t lds = sizeof(double) * ((size_t)p.NW * p.SR + 2 * (size_t)p.NW);
+    switch (p.NW) {
+    case 4:  hipLaunchKernelGGL(k_pb_phase2<4>, dim3(p.NRB), dim3(256), lds, st, b); break;
+    case 8:  hipLaunchKernelGGL(k_pb_phase2<8>, dim3(p.NRB), dim3(512), lds, st, b); break;
+    default: hipLaunchKernelGGL(k_pb_phase2<16>, dim3(p.NRB), dim3(1024), lds, st, b); break;
+    }
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+}  // namespace cm

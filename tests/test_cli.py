@@ -59,9 +59,11 @@ def test_cli_solves_the_shipped_fixtures(built):
                        capture_output=True, text=True)
     assert r.returncode != 0 and "no diagonal entry" in r.stderr and "method failed" in r.stderr
     # random matrix path (-N -R), ILU(0) with the debug trace of pbicgstab.cu:77,114,145,204
-    r = subprocess.run([built, "-N40", "-R0.5", "-D", "-S1"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
+    # (such a matrix, entries in [1,10] and no dominance, need not converge: only the trace is checked)
+    r = subprocess.run([built, "-N40", "-R0.5", "-D", "-S1", "-I50"], capture_output=True, text=True)
+    assert r.returncode in (0, 1), r.stdout + r.stderr
     assert "N=40, nnz=" in r.stdout and "gpu, init residual:norm" in r.stdout
-    assert "residual norm (before precond)" in r.stdout and "success" in r.stdout
+    assert "residual norm (before precond)" in r.stdout
+    assert ("success" in r.stdout) == (r.returncode == 0)
     r = subprocess.run([built, "-M" + os.path.join(GOLD, "mat900.mtx"), "-C0", "-T1e-8"], capture_output=True, text=True)
     assert r.returncode == 0 and "iterations = " in r.stdout

@@ -397,3 +397,69 @@ def test_ilu0_rejects_missing_diagonal_and_lu_drop_in(cm, ctx, oracle, golden_di
     assert np.linalg.norm(x - xs) / np.linalg.norm(xs) <= 5e-6
     ok, x, dt, st = cm.bicgstab_lu_precond(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 2, 1e-8)
     assert ok and not st.converged       # the reference returns true regardless (pbicgstab.cu:408)
+
+
+# ------------------------------------------------- blocked (propagation blocking) SpMV
+def _spmv_via_solver(cm, ctx, A, x, d=None):
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val, n_cols=A.m)
+    if d is not None:
+        s.set_shift(ctx.array(d))
+    dx, dy = ctx.array(x), ctx.empty(A.n)
+    s.spmv(dx, dy)
+    y = dy.download()
+    s.close()
+    return y
+
+
+@pytest.mark.parametrize("case", ["rand_real", "rand_int_base1", "poisson", "ragged", "tiny"])
+def test_blocked_spmv_is_bit_exact(cm, ctx, oracle, case, monkeypatch):
+    """the two-phase kernels (csrc/spmv_pb.hip) add each row's products in increasing column order,
+    one rounding per product and per addition: the SAME sequence of roundings as the reference CPU
+    loop b[i] += A.Value[j] * x[A.Col[j]] (bicstab.cpp:72-77) => bit-exact even on real-valued data."""
+    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "pb")
+    rng = np.random.default_rng(9)
+    if case == "rand_real":
+        A = oracle.rand_rows(20000, 50, 0x5EED)
+        A.val[:] = rng.standard_normal(A.nnz)
+    elif case == "rand_int_base1":
+        A = oracle.rand_rows(30011, 33, 5, base=1)
+    elif case == "poisson":
+        A = oracle.poisson5(173, 59, base=0)
+        A.val[:] = rng.standard_normal(A.nnz)
+    elif case == "tiny":
+        A = oracle.rand_rows(7, 50, 1)
+    else:
+        import scipy.sparse as sp
+        n = 5000
+        S = sp.random(n, n, density=0.004, random_state=3, format="lil")
+        S[5, :] = 0
+        S[17, :] = 1.0            # one dense row: segments longer than a wavefront
+        S[n - 1, :] = 0
+        S = S.tocsr()
+        S.data[:] = rng.standard_normal(S.nnz)
+        S.sort_indices()
+        A = oracle.Csr(n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), n)
+    x = rng.standard_normal(A.n)
+    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
+    d = rng.standard_normal(A.n)
+    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
+
+
+def test_blocked_spmv_in_the_solver_loop(cm, ctx, oracle, golden_dir, monkeypatch):
+    """same solves as above with the blocked kernels forced: fused dots, freeze prologue, ILU path"""
+    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "pb")
+    A = oracle.rand_rows(20000, 50, 0x5EED)
+    xs = oracle.xstar(20000, 0x5EEE)
+    b = oracle.spmv(A, xs)
+    xo, so, ho = oracle.pbicgstab(A, b, maxit=200, tol=1e-8, want_hist=True)
+    x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8)
+    assert st.converged and abs(st.iters - so.iters) <= 1
+    np.testing.assert_allclose(x, xs, rtol=1e-7)
+    np.testing.assert_allclose(h[:4], ho[:4], rtol=1e-9)
+    A9 = _load(oracle, golden_dir, "mat900")
+    b9 = oracle.spmv(A9, 1.0 + np.sin(np.arange(A9.n)))
+    for precond in (cm.PRECOND_NONE, cm.PRECOND_ILU0):
+        x1, st1, _ = _solve_dev(cm, ctx, A9, b9, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=2000, tol=1e-8)
+        xo, so = oracle.pbicgstab(A9, b9, vm=oracle.ilu0(A9) if precond else None, maxit=2000, tol=1e-8)
+        assert st1.converged and abs(st1.iters - so.iters) <= max(2, 0.1 * so.iters)
+        assert np.linalg.norm(x1 - xo) / np.linalg.norm(xo) <= 1e-5
