@@ -192,6 +192,20 @@ def main():
     b_spmv = 12.0 * nnz + 4.0 * (nloc + 1) + 8.0 * n + 8.0 * nloc
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     vec_bytes = 144.0 * nloc
+    blocked = solver.spmv_mode() == 1
+    kernel = "k_pb_phase1 + k_pb_phase2 (one SpMV = the pair)" if blocked else "k_spmv"
+    # HBM bytes per SpMV launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # FETCH_SIZE doubled per the gfx950 calibration); only for the exact workload they were taken on
+    traffic, traffic_src = None, None
+    if world == 1 and args.workload == "rand50" and args.rows == 10_000_000 and args.per_row == 50:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_fetch_write.json")), reverse=True):
+            pm = json.load(open(f))
+            keys = ["cm::k_pb_phase1", "cm::k_pb_phase2<16>"] if blocked else ["cm::k_spmv<32>"]
+            if all(k in pm and "hbm_bytes_per_launch_corrected" in pm[k] for k in keys):
+                traffic = sum(pm[k]["hbm_bytes_per_launch_corrected"] for k in keys)
+                traffic_src = os.path.relpath(f, ROOT)
+                break
     if rank == 0:
         out = {
             "metric": "BiCGSTAB iterations/s (1e7-row CSR, 50 nnz/row, fp64)" if args.workload == "rand50"
@@ -205,8 +219,9 @@ def main():
                                       "ILU(0)" if precond else "no preconditioner", world),
                        "rows": n, "nnz_per_rank": nnz, "parallelism": "rows/%d" % world,
                        "converges_in_iters": conv_iters},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_spmv, "avg_launch_ms": spmv_ms,
                          "launches_timed": n_spmv,
                          "iteration_bytes": 2 * b_spmv + vec_bytes,

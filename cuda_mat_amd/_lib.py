@@ -87,6 +87,7 @@ _SIGS = {
     "cudamat_solver_ilu0_values": (C.c_int, [_P, _P]),
     "cudamat_solver_precond_apply": (C.c_int, [_P, _P, _P]),
     "cudamat_solver_set_comm": (C.c_int, [_P, C.POINTER(Comm)]),
+    "cudamat_solver_spmv_mode": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "cudamat_solver_spmv": (C.c_int, [_P, _P, _P]),
     "cudamat_solver_solve": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                        C.POINTER(Stats)]),

@@ -288,6 +288,12 @@ class Solver:
     def spmv(self, x, y):
         check(_lib.lib().cudamat_solver_spmv(self.h, _ptr(x), _ptr(y)))
 
+    def spmv_mode(self):
+        """0: lanes-per-row CSR kernel, 1: blocked two-phase kernels (chosen by the analysis)"""
+        m = C.c_int()
+        check(_lib.lib().cudamat_solver_spmv_mode(self.h, C.byref(m)))
+        return m.value
+
     def solve(self, b, x, precond=PRECOND_NONE, loop=LOOP_PBICGSTAB, maxit=2000, tol=1e-8, flags=0):
         st = Stats()
         check(_lib.lib().cudamat_solver_solve(self.h, _ptr(b), _ptr(x), precond, loop, maxit, tol, flags,

@@ -280,6 +280,16 @@ static int allreduce(cudamat_solver *s, double *buf, int count)
     return CUDAMAT_OK;
 }
 
+extern "C" int cudamat_solver_spmv_mode(cudamat_solver *s, int *mode)
+{
+    CM_ARG(s && mode, "null pointer");
+    CM_HIP(hipSetDevice(s->ctx->device));
+    CM_TRY(ensure_work(s));
+    CM_TRY(ensure_spmv_mode(s));
+    *mode = s->spmv_mode;
+    return CUDAMAT_OK;
+}
+
 extern "C" int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, double *y_local)
 {
     CM_ARG(s && x_local && y_local, "null pointer");

@@ -172,6 +172,9 @@ int cudamat_solver_precond_apply(cudamat_solver *s, const double *in, double *ou
 /* row-sharded operation; comm is copied.  world == 1 or NULL => single GPU (unless the
  * environment sets CUDAMAT_FORCE_SHARDED=1, which keeps the collective path for testing). */
 int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *comm);
+/* which SpMV implementation the analysis chose for this matrix: 0 = one group of lanes per row on
+ * the CSR arrays, 1 = blocked two-phase kernels (x / y tiles in LDS); decided at the first use.   */
+int cudamat_solver_spmv_mode(cudamat_solver *s, int *mode);
 /* y_local = (A + diag(d)) x ; x is the LOCAL slice, gathered through comm if sharded  */
 int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, double *y_local);
 /* Solve.  b, x: device vectors of n_local doubles; x holds the initial guess on entry
