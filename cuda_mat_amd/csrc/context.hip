@@ -212,6 +212,7 @@ extern "C" int cudamat_spmv(cudamat_ctx *ctx, int n, const int *rowptr, const in
     CM_HIP(hipMemcpyAsync(&last, rowptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CM_HIP(hipStreamSynchronize(ctx->stream));
     SpmvPlan plan = plan_spmv(n, (int64_t)last - base);
+    CM_TRY(plan_spmv_refine(ctx->stream, n, (int64_t)last - base, rowptr, base, &plan));
     SpmvArgs a{};
     a.n = n;
     a.rp = rowptr;

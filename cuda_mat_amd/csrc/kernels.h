@@ -16,8 +16,12 @@ struct SpmvPlan {
     int lanes;            // lanes cooperating on one row (2..64)
     int grid;             // workgroups
     int rows_per_block;   // contiguous rows owned by a workgroup
+    int stream_rows;      // > 0: LDS-staged stream kernel, this many rows per LDS tile (short rows)
 };
 SpmvPlan plan_spmv(int n_rows, int64_t nnz);
+// short rows (mean <= 12): switch the plan to the LDS-staged stream kernel when every tile of
+// `stream_rows` consecutive rows holds at most kStreamNnz entries (checked on the device)
+int plan_spmv_refine(hipStream_t s, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan);
 
 // y = alpha*(A x + d .* xd) + beta*y  on 0- or 1-based CSR (base folded into the
 // pointers by the caller).  dot: 0 none, 1: parts[2b] = sum y*w, 2: also

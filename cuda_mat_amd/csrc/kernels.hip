@@ -210,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a, int rows_per_block)
 SpmvPlan plan_spmv(int n_rows, int64_t nnz)
 {
     SpmvPlan p;
+    p.stream_rows = 0;
     const double mean = n_rows > 0 ? (double)nnz / n_rows : 1.0;
     int L = 64;
     if (mean <= 3.0) L = 2;
@@ -235,9 +236,123 @@ SpmvPlan plan_spmv(int n_rows, int64_t nnz)
     return p;
 }
 
+// ------------------------------------------------------------ SpMV, short rows
+// Rows of ~5 entries (stencils) leave most of a lanes-per-row group idle and pay a shuffle tree
+// per row.  Here a workgroup takes a tile of R consecutive rows: their entries are one contiguous
+// piece of val/colidx, streamed with every lane busy; the products land in LDS; one thread per row
+// then adds its products in column order (the rounding sequence of the CPU loop,
+// bicstab.cpp:72-77 => bit-exact).  LDS: kStreamNnz products + R+1 row pointers.
+constexpr int kStreamNnz = 2048;
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a, int tiles_per_block)
+{
+    __shared__ double prod[kStreamNnz];
+    __shared__ int srp[R + 1];
+    __shared__ double lds[8];
+    if (a.loop.st) {
+        if (a.check == CHECK_HALF) {
+            if (check_half(a.loop, a.half, lds)) return;
+        } else if (a.loop.st->state != 0) {
+            return;
+        }
+    }
+    const int tid = threadIdx.x;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int cid = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+    double acc[2] = {0.0, 0.0};
+    for (int t = 0; t < tiles_per_block; t++) {
+        const long long r0l = ((long long)cid * tiles_per_block + t) * R;
+        if (r0l >= a.n) break;
+        const int r0 = (int)r0l;
+        const int nr = a.n - r0 < R ? a.n - r0 : R;
+        for (int i = tid; i <= nr; i += kBlock) srp[i] = a.rp[r0 + i];
+        __syncthreads();
+        const int base = srp[0];
+        const int cnt = srp[nr] - base;
+        for (int k = tid; k < cnt; k += kBlock)
+            prod[k] = __builtin_nontemporal_load(a.val + base + k) * a.x[__builtin_nontemporal_load(a.ci + base + k)];
+        __syncthreads();
+        if (tid < nr) {
+            const int row = r0 + tid;
+            const int s = srp[tid] - base, e = srp[tid + 1] - base;
+            double sum = 0.0;
+            for (int j = s; j < e; j++) sum += prod[j];
+            if (a.d) sum += a.d[row] * a.xd[row];
+            double out = a.alpha * sum;
+            if (a.beta != 0.0) out += a.beta * a.y[row];
+            a.y[row] = out;
+            if (a.dot) {
+                acc[0] += out * a.w[row];
+                acc[1] += out * out;
+            }
+        }
+        __syncthreads();
+    }
+    if (a.dot) {
+        block_sum<2>(acc, lds);
+        if (tid == 0) {
+            a.parts[2 * b] = acc[0];
+            a.parts[2 * b + 1] = acc[1];
+        }
+    }
+}
+
+// max over tiles of R rows of the number of entries in the tile, for R = 64, 128, 256
+__global__ __launch_bounds__(kBlock) void k_tile_nnz_max(int n, const int *rp, int *out)
+{
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;   // 64-row tile index
+    const long long r0 = t * 64;
+    if (r0 >= n) return;
+    const int b0 = rp[r0];
+    auto at = [&](long long r) { return rp[r < n ? r : n]; };
+    atomicMax(&out[0], at(r0 + 64) - b0);
+    if ((t & 1) == 0) atomicMax(&out[1], at(r0 + 128) - b0);
+    if ((t & 3) == 0) atomicMax(&out[2], at(r0 + 256) - b0);
+}
+
+int plan_spmv_refine(hipStream_t s, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan)
+{
+    (void)base;
+    plan->stream_rows = 0;
+    if (getenv("CUDAMAT_SPMV_LANES")) return CUDAMAT_OK;          // explicit lanes-per-row request
+    const double mean = n_rows > 0 ? (double)nnz / n_rows : 0.0;
+    if (n_rows < 64 || mean > 12.0) return CUDAMAT_OK;
+    int *d = nullptr, h[3] = {0, 0, 0};
+    CM_HIP(hipMalloc((void **)&d, 3 * sizeof(int)));
+    hipMemsetAsync(d, 0, 3 * sizeof(int), s);
+    const long long tiles = ((long long)n_rows + 63) / 64;
+    hipLaunchKernelGGL(k_tile_nnz_max, dim3((unsigned)((tiles + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp, d);
+    hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "tile scan", __FILE__, __LINE__);
+    int R = 0;
+    if (h[2] <= kStreamNnz) R = 256;
+    else if (h[1] <= kStreamNnz) R = 128;
+    else if (h[0] <= kStreamNnz) R = 64;
+    if (!R) return CUDAMAT_OK;
+    const long long tiles_r = ((long long)n_rows + R - 1) / R;
+    int grid = (int)(tiles_r < kSpmvGridMax ? tiles_r : kSpmvGridMax);
+    const long long per = (tiles_r + grid - 1) / grid;
+    plan->stream_rows = R;
+    plan->rows_per_block = (int)per;                               // tiles per workgroup
+    plan->grid = (int)((tiles_r + per - 1) / per);
+    return CUDAMAT_OK;
+}
+
 int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a)
 {
     dim3 g(plan.grid), b(kBlock);
+    if (plan.stream_rows) {
+        switch (plan.stream_rows) {
+        case 64:  hipLaunchKernelGGL(k_spmv_stream<64>, g, b, 0, s, a, plan.rows_per_block); break;
+        case 128: hipLaunchKernelGGL(k_spmv_stream<128>, g, b, 0, s, a, plan.rows_per_block); break;
+        default:  hipLaunchKernelGGL(k_spmv_stream<256>, g, b, 0, s, a, plan.rows_per_block); break;
+        }
+        CM_HIP(hipGetLastError());
+        return CUDAMAT_OK;
+    }
     switch (plan.lanes) {
     case 2:  hipLaunchKernelGGL(k_spmv<2>, g, b, 0, s, a, plan.rows_per_block); break;
     case 4:  hipLaunchKernelGGL(k_spmv<4>, g, b, 0, s, a, plan.rows_per_block); break;

@@ -119,6 +119,10 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
         return rc;
     }
     s->plan = plan_spmv(n_local, nnz);
+    if (int rc2 = plan_spmv_refine(st, n_local, nnz, s->rp, 0, &s->plan)) {
+        cudamat_solver_destroy(s);
+        return rc2;
+    }
     *out = s;
     return CUDAMAT_OK;
 }
