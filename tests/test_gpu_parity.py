@@ -27,6 +27,16 @@ def ctx(cm):
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _serial_oracle(oracle):
+    """one OpenMP thread for the checker: its `reduction(+)` dots are then summed in one fixed order,
+    so oracle iteration counts do not wander from run to run (the HIP path is deterministic already)"""
+    before = oracle.num_threads()
+    oracle.set_num_threads(1)
+    yield
+    oracle.set_num_threads(before)
+
+
 def _load(oracle, golden_dir, name):
     return oracle.mtx_load(os.path.join(golden_dir, name + ".mtx"))
 
