@@ -164,17 +164,29 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     p.NCB = round_blocks(n_cols, kTileMax);
     p.CB = (int)((n_cols + p.NCB - 1) / p.NCB);
     p.NCB = (int)((n_cols + p.CB - 1) / p.CB);
-    p.NRB = round_blocks(n, kTileMax);
+    // Sub-blocks (one wave each): ~48 entries per (sub-block, column block) segment keeps a wave's
+    // lanes busy, but never fewer than 4096 waves (16 per CU) -- a shard of a row-partitioned matrix
+    // has few entries per column block and would otherwise be latency-bound.
+    double nsub_t = (double)nnz / ((double)p.NCB * 48.0);
+    if (nsub_t < 4096.0) nsub_t = 4096.0;
+    if (nsub_t > (double)n / 16.0) nsub_t = (double)n / 16.0;
+    if (nsub_t < 4.0) nsub_t = 4.0;
+    p.NW = nsub_t >= 4096.0 ? 16 : nsub_t >= 2048.0 ? 8 : 4;
+    int nrb = (int)(nsub_t / p.NW / 256.0 + 0.5) * 256;          // whole rounds of workgroups
+    if (nrb < 256) nrb = 256;
+    const int nrb_min = (int)(((int64_t)n + kTileMax - 1) / kTileMax);
+    while (nrb < nrb_min) nrb += 256;
+    if (nrb > kMaxParts) nrb = kMaxParts;
+    p.NRB = nrb;
     p.RB = (int)(((int64_t)n + p.NRB - 1) / p.NRB);
-    p.NRB = (int)(((int64_t)n + p.RB - 1) / p.RB);
-    // waves per row block: aim at ~56 entries per (sub-block, column block) segment
-    const double per_rb_cb = (double)nnz / ((double)p.NRB * p.NCB);
-    p.NW = per_rb_cb >= 640 ? 16 : per_rb_cb >= 320 ? 8 : 4;
     p.SR = (p.RB + p.NW - 1) / p.NW;
+    if (p.SR < 1) p.SR = 1;
     p.RB = p.SR * p.NW;
     p.NRB = (int)(((int64_t)n + p.RB - 1) / p.RB);
     p.NSUB = p.NRB * p.NW;
-    if (p.NRB > kMaxParts || p.CB > 65536 || p.SR > 65536) {
+    const double seg = (double)nnz / ((double)p.NCB * p.NSUB);      // mean entries per segment
+    p.LPS = seg <= 6.0 ? 16 : seg <= 22.0 ? 32 : 64;
+    if (p.NRB > kMaxParts || p.CB > 65536 || p.SR > 65536 || (size_t)p.RB * 8 > 150 * 1024) {
         set_error("pb_build: matrix shape outside the blocked kernel's limits");
         return CUDAMAT_ERR_ARG;
     }
@@ -297,7 +309,7 @@ struct Pb2Args {
     const LoopState *st;
 };
 
-template <int NW>
+template <int NW, int LPS>
 __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) double yt[];   // NW * SR, then 2 * NW for the reduction
@@ -315,27 +327,57 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
         const int mys = c < a.NCB ? ss[c] : 0;
         const int myl = c < a.NCB ? sl[c] : 0;
         const int lim = a.NCB - cb0 < 64 ? a.NCB - cb0 : 64;
-        for (int j = 0; j < lim; j += 4) {
-            int s[4], l[4];
-            double pv4[4];
-            int r4[4];
+        // LPS < 64: 64/LPS segments share one wave instruction (lane group g takes column block j+g).
+        // Groups are ordered by column block and ds_add_f64 serves equal addresses in lane order, so a
+        // row still receives its products in increasing column order -- unless a segment is longer than
+        // LPS (its tail would land after the next block's head): such chunks take the 64-lane path.
+        const bool grouped = LPS < 64 && !__any(myl > LPS);
+        if (!grouped) {
+            for (int j = 0; j < lim; j += 4) {
+                int s[4], l[4];
+                double pv4[4];
+                int r4[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                // lanes past `lim` carry length 0, so j + u may safely run to 63
-                s[u] = __builtin_amdgcn_readlane(mys, (j + u) & 63);
-                l[u] = (j + u) < 64 ? __builtin_amdgcn_readlane(myl, (j + u) & 63) : 0;
+                for (int u = 0; u < 4; u++) {
+                    // lanes past `lim` carry length 0, so j + u may safely run to 63
+                    s[u] = __builtin_amdgcn_readlane(mys, (j + u) & 63);
+                    l[u] = __builtin_amdgcn_readlane(myl, (j + u) & 63);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool on = lane < l[u];
+                    pv4[u] = on ? a.P[s[u] + lane] : 0.0;
+                    r4[u] = on ? (int)a.pr[s[u] + lane] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (lane < l[u]) unsafeAtomicAdd(&my[r4[u]], pv4[u]);
+                    for (int off = 64 + lane; off < l[u]; off += 64)        // segments longer than a wave
+                        unsafeAtomicAdd(&my[a.pr[s[u] + off]], a.P[s[u] + off]);
+                }
             }
+        } else {
+            constexpr int G = 64 / LPS;
+            const int g = lane / LPS, li = lane % LPS;
+            for (int j = 0; j < lim; j += 4 * G) {
+                int s[4], l[4];
+                double pv4[4];
+                int r4[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool on = lane < l[u];
-                pv4[u] = on ? a.P[s[u] + lane] : 0.0;
-                r4[u] = on ? (int)a.pr[s[u] + lane] : 0;
-            }
+                for (int u = 0; u < 4; u++) {
+                    const int cbi = j + u * G + g;
+                    s[u] = __shfl(mys, cbi & 63, 64);
+                    l[u] = cbi < 64 ? __shfl(myl, cbi & 63, 64) : 0;
+                }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (lane < l[u]) unsafeAtomicAdd(&my[r4[u]], pv4[u]);
-                for (int off = 64 + lane; off < l[u]; off += 64)        // segments longer than a wave
-                    unsafeAtomicAdd(&my[a.pr[s[u] + off]], a.P[s[u] + off]);
+                for (int u = 0; u < 4; u++) {
+                    const bool on = li < l[u];
+                    pv4[u] = on ? a.P[s[u] + li] : 0.0;
+                    r4[u] = on ? (int)a.pr[s[u] + li] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (li < l[u]) unsafeAtomicAdd(&my[r4[u]], pv4[u]);
             }
         }
     }
@@ -393,9 +435,6 @@ int launch_spmv_pb(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute((const void *)k_pb_phase1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void *)k_pb_phase2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void *)k_pb_phase2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void *)k_pb_phase2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     hipLaunchKernelGGL(k_pb_phase1, dim3(p.NCB), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x,
@@ -409,11 +448,28 @@ int launch_spmv_pb(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
     b.y = a.y; b.dot = a.dot; b.w = a.w; b.parts = a.parts;
     b.st = a.loop.st;
     const size_t lds = sizeof(double) * ((size_t)p.NW * p.SR + 2 * (size_t)p.NW);
+#define CM_P2(NWV, LPSV)                                                                                  \
+    do {                                                                                                  \
+        static bool attr = false;                                                                         \
+        if (!attr) {                                                                                      \
+            hipFuncSetAttribute((const void *)k_pb_phase2<NWV, LPSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr = true;                                                                                  \
+        }                                                                                                 \
+        hipLaunchKernelGGL((k_pb_phase2<NWV, LPSV>), dim3(p.NRB), dim3(64 * NWV), lds, st, b);           \
+    } while (0)
+#define CM_P2_LPS(NWV)                                           \
+    do {                                                         \
+        if (p.LPS == 16) CM_P2(NWV, 16);                         \
+        else if (p.LPS == 32) CM_P2(NWV, 32);                    \
+        else CM_P2(NWV, 64);                                     \
+    } while (0)
     switch (p.NW) {
-    case 4:  hipLaunchKernelGGL(k_pb_phase2<4>, dim3(p.NRB), dim3(256), lds, st, b); break;
-    case 8:  hipLaunchKernelGGL(k_pb_phase2<8>, dim3(p.NRB), dim3(512), lds, st, b); break;
-    default: hipLaunchKernelGGL(k_pb_phase2<16>, dim3(p.NRB), dim3(1024), lds, st, b); break;
+    case 4:  CM_P2_LPS(4); break;
+    case 8:  CM_P2_LPS(8); break;
+    default: CM_P2_LPS(16); break;
     }
+#undef CM_P2_LPS
+#undef CM_P2
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }
