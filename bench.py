@@ -201,9 +201,11 @@ def main():
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_fetch_write.json")), reverse=True):
             pm = json.load(open(f))
-            keys = ["cm::k_pb_phase1", "cm::k_pb_phase2<16>"] if blocked else ["cm::k_spmv<32>"]
-            if all(k in pm and "hbm_bytes_per_launch_corrected" in pm[k] for k in keys):
-                traffic = sum(pm[k]["hbm_bytes_per_launch_corrected"] for k in keys)
+            want = ["cm::k_pb_phase1", "cm::k_pb_phase2"] if blocked else ["cm::k_spmv<"]
+            got = [next((v for k, v in pm.items() if k.startswith(w) and isinstance(v, dict)
+                         and "hbm_bytes_per_launch_corrected" in v), None) for w in want]
+            if all(g is not None for g in got):
+                traffic = sum(g["hbm_bytes_per_launch_corrected"] for g in got)
                 traffic_src = os.path.relpath(f, ROOT)
                 break
     if rank == 0:
