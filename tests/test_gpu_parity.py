@@ -473,3 +473,50 @@ def test_blocked_spmv_in_the_solver_loop(cm, ctx, oracle, golden_dir, monkeypatc
         xo, so = oracle.pbicgstab(A9, b9, vm=oracle.ilu0(A9) if precond else None, maxit=2000, tol=1e-8)
         assert st1.converged and abs(st1.iters - so.iters) <= max(2, 0.1 * so.iters)
         assert np.linalg.norm(x1 - xo) / np.linalg.norm(xo) <= 1e-5
+
+
+# ------------------------------------------------------------------- degenerate inputs
+def test_degenerate_systems(cm, ctx, oracle):
+    """1x1, diagonal, empty rows, zero right-hand side, exact initial guess, argument errors"""
+    # 1 x 1
+    ok, x, dt, st = cm.bicgstab(1, 1, np.array([4.0]), np.array([1, 2], np.int32), np.array([1], np.int32),
+                                np.array([2.0]), 10, 1e-10)
+    assert ok and abs(x[0] - 0.5) < 1e-12
+    # diagonal matrix, base 0: converges in one iteration
+    n = 1000
+    dg = 1.0 + np.arange(n) % 7
+    rp, ci = np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32)
+    b = dg * (1.0 + np.arange(n) % 3)
+    ok, x, dt, st = cm.bicgstab(n, n, dg, rp, ci, b, 50, 1e-12)
+    assert ok and np.allclose(x, b / dg, rtol=1e-10)
+    ok, x, dt, st = cm.bicgstab_lu_precond(n, n, dg, rp, ci, b, 50, 1e-12)
+    assert st.converged and st.iters <= 1 and np.allclose(x, b / dg, rtol=1e-12)
+    # x0 already solves the system: r0 = 0, tol*||r0|| = 0, rho = 0 -> the reference's loop divides
+    # 0/0 and runs to maxit (pbicgstab.cu:81,107 have no guard); it must terminate and report failure
+    A = oracle.poisson5(20, 20)
+    b1 = oracle.spmv(A, np.ones(A.n))
+    x, st, h = _solve_dev(cm, ctx, A, b1, loop=cm.LOOP_PBICGSTAB, maxit=7, tol=1e-8)
+    assert st.iters == 7 and not st.converged and st.nrm0 == 0.0
+    x, st, h = _solve_dev(cm, ctx, A, b1, loop=cm.LOOP_PBICGSTAB2, maxit=7, tol=1e-8)
+    assert not st.converged and st.breakdown and st.iters == 1          # NaN omega trips the guard (:735)
+    # rows without entries (singular, but SpMV and the loop must not misbehave)
+    E = oracle.Csr(4, np.array([0, 1, 1, 2, 2], np.int32), np.array([0, 2], np.int32), np.array([2.0, 3.0]), 4)
+    s = cm.Solver.from_host_csr(ctx, E.rowptr, E.colidx, E.val)
+    dx, dy = ctx.array(np.array([1.0, 2.0, 3.0, 4.0])), ctx.empty(4)
+    s.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), [2.0, 0.0, 9.0, 0.0])
+    s.close()
+    # a matrix with no entries at all
+    Z = cm.Solver.from_host_csr(ctx, np.zeros(6, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    dz = ctx.array(np.ones(5))
+    do = ctx.array(np.ones(5))
+    Z.spmv(dz, do)
+    np.testing.assert_array_equal(do.download(), np.zeros(5))
+    Z.close()
+    # argument errors come back as codes, never as exit()
+    with pytest.raises(cm.CudamatError) as e:
+        cm.bicgstab(3, 5, np.ones(5), np.array([1, 2, 3, 4], np.int32), np.ones(5, np.int32), np.ones(3), 10, 1e-8)
+    assert e.value.code == 2          # nnz != iA[n] - iA[0]
+    with pytest.raises(cm.CudamatError) as e:
+        cm.bicgstab(2, 2, np.ones(2), np.array([5, 6, 7], np.int32), np.ones(2, np.int32), np.ones(2), 10, 1e-8)
+    assert e.value.code == 2          # index base must be 0 or 1
