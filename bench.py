@@ -33,7 +33,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="rand50", choices=["rand50", "poisson5"])
+    ap.add_argument("--workload", default="rand50", choices=["rand50", "poisson5", "mat10000"],
+                    help="mat10000 = BASELINE configs[1]: the 100x100 5-point Laplacian of mat10000.mtx "
+                         "(the generator reproduces the file bit for bit, tests/test_oracle_golden.py)")
+    ap.add_argument("--nx", type=int, default=4000, help="grid width of the poisson5 workload")
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--per-row", type=int, default=50)
     ap.add_argument("--precond", default="none", choices=["none", "ilu0"])
@@ -53,7 +56,8 @@ def cpu_baseline(args):
     from oracle import oracle as O
     n = args.cpu_rows
     if args.workload == "poisson5":
-        nx = 1000
+        nx = min(1000, args.nx)
+        n = min(n, args.rows)
         A = O.poisson5(nx, n // nx)
         n = A.n
     else:
@@ -94,9 +98,11 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.workload == "mat10000":
+        args.workload, args.rows, args.nx = "poisson5", 10000, 100
     n = args.rows
     if args.workload == "poisson5":
-        nx = 4000
+        nx = args.nx
         ny = n // nx
         n = nx * ny
     row0, row1, per = shard_rows(n, world, rank)

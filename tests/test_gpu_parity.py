@@ -479,9 +479,14 @@ def test_blocked_spmv_in_the_solver_loop(cm, ctx, oracle, golden_dir, monkeypatc
 def test_degenerate_systems(cm, ctx, oracle):
     """1x1, diagonal, empty rows, zero right-hand side, exact initial guess, argument errors"""
     # 1 x 1
-    ok, x, dt, st = cm.bicgstab(1, 1, np.array([4.0]), np.array([1, 2], np.int32), np.array([1], np.int32),
-                                np.array([2.0]), 10, 1e-10)
-    assert ok and abs(x[0] - 0.5) < 1e-12
+    A1 = oracle.Csr(1, np.array([1, 2], np.int32), np.array([1], np.int32), np.array([4.0]), 1)
+    # gpu_pbicgstab (half-step exit, pbicgstab.cu:116) stops at the exact answer after half an iteration
+    x, st, h = _solve_dev(cm, ctx, A1, np.array([2.0]), loop=cm.LOOP_PBICGSTAB, maxit=10, tol=1e-10)
+    assert st.converged and st.half_exit and st.iters == 0 and abs(x[0] - 0.5) < 1e-15
+    # gpu_pbicgstab2 has no half-step test: s = 0 => omega = 0/0 => NaN guard (:735), like the oracle
+    ok, x, dt, st = cm.bicgstab(1, 1, A1.val, A1.rowptr, A1.colidx, np.array([2.0]), 10, 1e-10)
+    oko, xo, so = oracle.pbicgstab2(A1, np.array([2.0]), maxit=10, tol=1e-10)
+    assert ok == oko == False and st.breakdown == so.breakdown == 1 and st.iters == so.iters  # noqa: E712
     # diagonal matrix, base 0: converges in one iteration
     n = 1000
     dg = 1.0 + np.arange(n) % 7
