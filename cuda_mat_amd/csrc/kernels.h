@@ -73,10 +73,5 @@ int launch_axpy(hipStream_t s, int64_t n, double alpha, const double *x, double 
 int launch_scal(hipStream_t s, int64_t n, double alpha, double *x);
 int launch_fill(hipStream_t s, int64_t n, double value, double *x);
 int launch_rebase(hipStream_t s, int64_t n, const int *in, int shift, int *out);
-// whole solve in one single-workgroup launch (small.hip); work vectors r, rw, p, v, t of n doubles
-int launch_bicgstab_small(hipStream_t s, int n, int64_t nnz, const int *rp, const int *ci, const double *val,
-                          const double *d, const double *b, double *x, double *r, double *rw, double *p, double *v,
-                          double *t, int maxit, double tol, int loop, int no_exit, int x0_ones, double *hist,
-                          int hist_cap, LoopState *st);
 
 }  // namespace cm

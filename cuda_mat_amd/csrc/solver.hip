@@ -369,105 +369,93 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
     size_t pe = 0;   // profiling events used
 
     const double t_loop0 = now_s();
-    // Systems that fit one CU's reach run the whole loop in a single workgroup (csrc/small.hip):
-    // at this size the five launches per iteration, not the matrix, set the pace.
-    const char *small_env = getenv("CUDAMAT_SMALL");
-    const bool small = !precond && !sharded && !profile && n > 0 && n <= 16384 && s->nnz <= 400000 &&
-                       !(small_env && small_env[0] == '0');
-    if (small) {
-        CM_TRY(launch_bicgstab_small(st, n, s->nnz, s->rp, s->ci, s->val, s->d, b, x, s->r, s->rw, s->p, s->v, s->t,
-                                     maxit, tol, loop, (flags & CUDAMAT_FLAG_NO_EXIT) ? 1 : 0,
-                                     (flags & CUDAMAT_FLAG_X0_ONES) ? 1 : 0, s->hist, s->hist_cap, s->st));
-    } else {
-        if (flags & CUDAMAT_FLAG_X0_ONES) CM_TRY(launch_fill(st, n, 1.0, x));
-        // r = A x0 (pbicgstab.cu:67 / :645-646); x may be a caller buffer without pad
-        CM_HIP(hipMemcpyAsync(s->pw, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
-        CM_TRY(spmv_local(s, s->pw, s->r, 0, nullptr, nullptr, la_none, CHECK_NONE, nosrc));
-        int np_full = 0, np_half = 0;
-        CM_TRY(launch_init(st, n, b, s->r, s->rw, s->p, s->parts_full, &np_full));   // :69-74
-        ScalarSrc full_src{s->parts_full, np_full, 2};
+    if (flags & CUDAMAT_FLAG_X0_ONES) CM_TRY(launch_fill(st, n, 1.0, x));
+    // r = A x0 (pbicgstab.cu:67 / :645-646); x may be a caller buffer without pad
+    CM_HIP(hipMemcpyAsync(s->pw, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    CM_TRY(spmv_local(s, s->pw, s->r, 0, nullptr, nullptr, la_none, CHECK_NONE, nosrc));
+    int np_full = 0, np_half = 0;
+    CM_TRY(launch_init(st, n, b, s->r, s->rw, s->p, s->parts_full, &np_full));   // :69-74
+    ScalarSrc full_src{s->parts_full, np_full, 2};
+    if (sharded) {
+        CM_TRY(launch_reduce_parts(st, full_src, 2, s->red + 4, 0));
+        CM_TRY(allreduce(s, s->red + 4, 2));
+        full_src = ScalarSrc{s->red + 4, 0, 1};
+    }
+    CM_TRY(launch_init_finish(st, s->st, full_src, tol));
+
+    int k = 0;
+    for (; k < maxit; k++) {
+        if (k >= kLag) {   // lagged, deterministic look at the device state
+            const int slot = (k - kLag) % kRing;
+            CM_HIP(hipEventSynchronize(s->ev[slot]));
+            if (s->st_ring[slot].state != 0) break;
+        }
+        // rho, beta, p = r + beta (p - omega v)                     :80-89
+        CM_TRY(launch_update_p(st, la, full_src, n, s->r, s->p, s->v));
+        const double *pw = s->p;
+        if (precond) {                                            // :92-98
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            CM_TRY(precond_apply(s, s->p, s->t, s->pw));
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            pw = s->pw;
+        }
+        // v = A pw, rw.v                                            :104-106
+        if (profile) hipEventRecord(prof_event(s, pe++), st);
+        CM_TRY(spmv_local(s, pw, s->v, 1, s->rw, s->parts_rv, la, CHECK_NONE, nosrc));
+        if (profile) hipEventRecord(prof_event(s, pe++), st);
+        ScalarSrc rv_src{s->parts_rv, spmv_parts(s), 2};
+        if (sharded) {
+            CM_TRY(launch_reduce_parts(st, rv_src, 1, s->red + 0, 0));
+            CM_TRY(allreduce(s, s->red + 0, 1));
+            rv_src = ScalarSrc{s->red + 0, 0, 1};
+        }
+        // alpha, r -= alpha v, x += alpha pw, ||r||                 :107-111
+        CM_TRY(launch_half(st, la, rv_src, n, s->r, s->v, x, pw, s->parts_half, &np_half));
+        const ScalarSrc half_src{s->parts_half, np_half, 1};
+        const double *sv = s->r;
+        ScalarSrc tt_src{s->parts_tt, spmv_parts(s), 2};
+        if (!sharded) {
+            if (precond) {                                        // :116, :121-127
+                CM_TRY(launch_check(st, la, half_src, CHECK_HALF));
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+                CM_TRY(precond_apply(s, s->r, s->t, s->s));
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+                sv = s->s;
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+                CM_TRY(spmv_local(s, sv, s->t, 2, s->r, s->parts_tt, la, CHECK_NONE, nosrc));
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+            } else {
+                // half-step test fused into the SpMV prologue      :116, :132-136
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+                CM_TRY(spmv_local(s, sv, s->t, 2, s->r, s->parts_tt, la, CHECK_HALF, half_src));
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+            }
+        } else {
+            // The SpMV changes only t, so the half-step test may ride with the
+            // (t.r, t.t) all-reduce: one collective instead of two.
+            CM_TRY(launch_reduce_parts(st, half_src, 1, s->red + 1, 0));
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            CM_TRY(spmv_local(s, sv, s->t, 2, s->r, s->parts_tt, la, CHECK_NONE, nosrc));
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            CM_TRY(launch_reduce_parts(st, tt_src, 2, s->red + 2, 0));
+            CM_TRY(allreduce(s, s->red + 1, 3));
+            CM_TRY(launch_check(st, la, ScalarSrc{s->red + 1, 0, 1}, CHECK_HALF));
+            tt_src = ScalarSrc{s->red + 2, 0, 1};
+        }
+        // omega, x += omega s, r -= omega t, (rw.r, ||r||), i++     :137-151
+        CM_TRY(launch_full(st, la, tt_src, n, x, sv, s->r, s->t, s->rw, s->parts_full, &np_full));
+        full_src = ScalarSrc{s->parts_full, np_full, 2};
         if (sharded) {
             CM_TRY(launch_reduce_parts(st, full_src, 2, s->red + 4, 0));
             CM_TRY(allreduce(s, s->red + 4, 2));
             full_src = ScalarSrc{s->red + 4, 0, 1};
         }
-        CM_TRY(launch_init_finish(st, s->st, full_src, tol));
-
-        int k = 0;
-        for (; k < maxit; k++) {
-            if (k >= kLag) {   // lagged, deterministic look at the device state
-                const int slot = (k - kLag) % kRing;
-                CM_HIP(hipEventSynchronize(s->ev[slot]));
-                if (s->st_ring[slot].state != 0) break;
-            }
-            // rho, beta, p = r + beta (p - omega v)                     :80-89
-            CM_TRY(launch_update_p(st, la, full_src, n, s->r, s->p, s->v));
-            const double *pw = s->p;
-            if (precond) {                                            // :92-98
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                CM_TRY(precond_apply(s, s->p, s->t, s->pw));
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                pw = s->pw;
-            }
-            // v = A pw, rw.v                                            :104-106
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(spmv_local(s, pw, s->v, 1, s->rw, s->parts_rv, la, CHECK_NONE, nosrc));
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            ScalarSrc rv_src{s->parts_rv, spmv_parts(s), 2};
-            if (sharded) {
-                CM_TRY(launch_reduce_parts(st, rv_src, 1, s->red + 0, 0));
-                CM_TRY(allreduce(s, s->red + 0, 1));
-                rv_src = ScalarSrc{s->red + 0, 0, 1};
-            }
-            // alpha, r -= alpha v, x += alpha pw, ||r||                 :107-111
-            CM_TRY(launch_half(st, la, rv_src, n, s->r, s->v, x, pw, s->parts_half, &np_half));
-            const ScalarSrc half_src{s->parts_half, np_half, 1};
-            const double *sv = s->r;
-            ScalarSrc tt_src{s->parts_tt, spmv_parts(s), 2};
-            if (!sharded) {
-                if (precond) {                                        // :116, :121-127
-                    CM_TRY(launch_check(st, la, half_src, CHECK_HALF));
-                    if (profile) hipEventRecord(prof_event(s, pe++), st);
-                    CM_TRY(precond_apply(s, s->r, s->t, s->s));
-                    if (profile) hipEventRecord(prof_event(s, pe++), st);
-                    sv = s->s;
-                    if (profile) hipEventRecord(prof_event(s, pe++), st);
-                    CM_TRY(spmv_local(s, sv, s->t, 2, s->r, s->parts_tt, la, CHECK_NONE, nosrc));
-                    if (profile) hipEventRecord(prof_event(s, pe++), st);
-                } else {
-                    // half-step test fused into the SpMV prologue      :116, :132-136
-                    if (profile) hipEventRecord(prof_event(s, pe++), st);
-                    CM_TRY(spmv_local(s, sv, s->t, 2, s->r, s->parts_tt, la, CHECK_HALF, half_src));
-                    if (profile) hipEventRecord(prof_event(s, pe++), st);
-                }
-            } else {
-                // The SpMV changes only t, so the half-step test may ride with the
-                // (t.r, t.t) all-reduce: one collective instead of two.
-                CM_TRY(launch_reduce_parts(st, half_src, 1, s->red + 1, 0));
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                CM_TRY(spmv_local(s, sv, s->t, 2, s->r, s->parts_tt, la, CHECK_NONE, nosrc));
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                CM_TRY(launch_reduce_parts(st, tt_src, 2, s->red + 2, 0));
-                CM_TRY(allreduce(s, s->red + 1, 3));
-                CM_TRY(launch_check(st, la, ScalarSrc{s->red + 1, 0, 1}, CHECK_HALF));
-                tt_src = ScalarSrc{s->red + 2, 0, 1};
-            }
-            // omega, x += omega s, r -= omega t, (rw.r, ||r||), i++     :137-151
-            CM_TRY(launch_full(st, la, tt_src, n, x, sv, s->r, s->t, s->rw, s->parts_full, &np_full));
-            full_src = ScalarSrc{s->parts_full, np_full, 2};
-            if (sharded) {
-                CM_TRY(launch_reduce_parts(st, full_src, 2, s->red + 4, 0));
-                CM_TRY(allreduce(s, s->red + 4, 2));
-                full_src = ScalarSrc{s->red + 4, 0, 1};
-            }
-            const int slot = k % kRing;
-            CM_HIP(hipMemcpyAsync(&s->st_ring[slot], s->st, sizeof(LoopState), hipMemcpyDeviceToHost, st));
-            CM_HIP(hipEventRecord(s->ev[slot], st));
-        }
-        // the full-step test of the last iteration has not been looked at yet
-        CM_TRY(launch_check(st, la, full_src, CHECK_FULL));
-
+        const int slot = k % kRing;
+        CM_HIP(hipMemcpyAsync(&s->st_ring[slot], s->st, sizeof(LoopState), hipMemcpyDeviceToHost, st));
+        CM_HIP(hipEventRecord(s->ev[slot], st));
     }
+    // the full-step test of the last iteration has not been looked at yet
+    CM_TRY(launch_check(st, la, full_src, CHECK_FULL));
     CM_HIP(hipMemcpyAsync(&s->st_ring[0], s->st, sizeof(LoopState), hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));                              // :372
     const double t_loop1 = now_s();

@@ -228,12 +228,7 @@ def test_pbicgstab_no_precond_vs_oracle(cm, ctx, oracle, golden_dir, name, tol):
     assert h[-1] < tol * st.nrm0 and np.all(h[:-1] >= tol * st.nrm0)
 
 
-def test_freeze_on_exit_is_exact(cm, ctx, oracle, golden_dir, monkeypatch):
-    monkeypatch.setenv("CUDAMAT_SMALL", "0")     # the multi-kernel loop, not the single-workgroup solver
-    _freeze_on_exit_is_exact(cm, ctx, oracle, golden_dir)
-
-
-def _freeze_on_exit_is_exact(cm, ctx, oracle, golden_dir):
+def test_freeze_on_exit_is_exact(cm, ctx, oracle, golden_dir):
     """kernels enqueued past the stopping point must not change x: the result with a huge
     maxit is bit-identical to the result when the loop is cut at the converged iteration."""
     A = _load(oracle, golden_dir, "mat900")
@@ -530,35 +525,3 @@ def test_degenerate_systems(cm, ctx, oracle):
     with pytest.raises(cm.CudamatError) as e:
         cm.bicgstab(2, 2, np.ones(2), np.array([5, 6, 7], np.int32), np.ones(2, np.int32), np.ones(2), 10, 1e-8)
     assert e.value.code == 2          # index base must be 0 or 1
-
-
-# ------------------------------------------------- single-workgroup solver vs multi-kernel loop
-@pytest.mark.parametrize("name,loop", [("mat900", 0), ("mat10000", 0), ("mat900", 1), ("mat10000", 1)])
-def test_single_workgroup_solver_matches_multi_kernel_loop(cm, ctx, oracle, golden_dir, name, loop, monkeypatch):
-    """systems up to 16384 rows run the whole loop in ONE launch of one workgroup (csrc/small.hip); it
-    must take the same decisions as the five-kernel loop and agree with the oracle"""
-    A = _load(oracle, golden_dir, name)
-    xs = 1.0 + np.sin(np.arange(A.n))
-    b = oracle.spmv(A, xs)
-    res = {}
-    for small in ("0", "1"):
-        monkeypatch.setenv("CUDAMAT_SMALL", small)
-        res[small] = _solve_dev(cm, ctx, A, b, loop=loop, maxit=2000, tol=1e-8)
-    (x0, st0, h0), (x1, st1, h1) = res["0"], res["1"]
-    assert st0.converged and st1.converged and st0.half_exit == st1.half_exit
-    assert abs(st0.iters - st1.iters) <= max(2, 0.1 * st0.iters) and len(h1) == (2 if loop == 0 else 1) * st1.iters + st1.half_exit
-    assert np.linalg.norm(x0 - x1) / np.linalg.norm(x0) <= 1e-6
-    np.testing.assert_allclose(h0[:8], h1[:8], rtol=1e-9)
-    if loop == 0:
-        xo, so, ho = oracle.pbicgstab(A, b, maxit=2000, tol=1e-8, want_hist=True)
-    else:
-        ok, xo, so, ho = oracle.pbicgstab2(A, b, maxit=2000, tol=1e-8, want_hist=True)
-    assert abs(st1.iters - so.iters) <= max(2, 0.1 * so.iters)
-    assert np.linalg.norm(x1 - xo) / np.linalg.norm(xo) <= 1e-5
-    np.testing.assert_allclose(h1[:8], ho[:8], rtol=1e-9)
-    assert np.linalg.norm(b - oracle.spmv(A, x1)) <= 1e-7 * so.nrm0
-    # deterministic
-    monkeypatch.setenv("CUDAMAT_SMALL", "1")
-    x2, st2, h2 = _solve_dev(cm, ctx, A, b, loop=loop, maxit=2000, tol=1e-8)
-    np.testing.assert_array_equal(x1, x2)
-    np.testing.assert_array_equal(h1, h2)
