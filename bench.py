@@ -177,7 +177,8 @@ def main():
             "parity gate failed: true residual %g vs loop residual %g" % (true_res, st.nrm)
         err = float((x - xs).abs().max().item())
         if st.converged:
-            assert err < 1e-6, "parity gate failed: converged but max|x-x*|=%g" % err
+            # 1e-5 relative; x* lies in [1, 2)
+            assert err < 2e-5, "parity gate failed: converged but max|x-x*|=%g" % err
         conv_iters = st.iters if st.converged else None
         del ax
 
