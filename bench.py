@@ -185,7 +185,11 @@ def main():
         run(args.warmup, flags)
         barrier()
         t0 = time.perf_counter()
-        ms_spmv, n_spmv, ms_trsv, n_trsv, st = run(args.steps, flags | cm.FLAG_PROFILE)
+        # per-launch SpMV timing = HIP events around every SpMV inside the loop; on L2-resident systems
+        # (C2) the four event records per iteration would dominate the ~28 us iteration, and no roofline
+        # is quoted for that latency-bound case anyway
+        latency_bound = n <= 200_000
+        ms_spmv, n_spmv, ms_trsv, n_trsv, st = run(args.steps, flags | (0 if latency_bound else cm.FLAG_PROFILE))
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -201,6 +205,8 @@ def main():
     vec_bytes = 144.0 * nloc
     blocked = solver.spmv_mode() == 1
     kernel = "k_pb_phase1 + k_pb_phase2 (one SpMV = the pair)" if blocked else "k_spmv"
+    if n_spmv == 0:
+        kernel += " (L2-resident, launch-latency-bound: per-launch timing off, no roofline quoted)"
     # HBM bytes per SpMV launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     # FETCH_SIZE doubled per the gfx950 calibration); only for the exact workload they were taken on
     traffic, traffic_src = None, None
