@@ -117,3 +117,30 @@ def test_torch_nccl_world1_forced_sharded():
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nccl_world1_worker.py")
     r = subprocess.run([sys.executable, worker, str(port)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_cpp_sharded_loop_with_blocked_spmv(cm, oracle, monkeypatch):
+    """the row-sharded loop with the blocked two-phase SpMV forced on every (rectangular) shard:
+    n_local x n column blocks over the gathered vector, 8 emulated ranks, uneven last block"""
+    import dist_sim
+    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "pb")
+    world, n, per_row = 8, 30011, 24
+    A = oracle.rand_rows(n, per_row, 0xBEEF)
+    xs = oracle.xstar(n, 0x5EEE)
+    b = oracle.spmv(A, xs)
+    group = dist_sim.ThreadGroup(world)
+    out = [None] * world
+    th = [threading.Thread(target=_run_rank, args=(cm, group, r, n, A, b, out),
+                           kwargs=dict(loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    for o in out:
+        assert not isinstance(o, Exception) and o is not None, o
+    x = np.concatenate([o[2] for o in out])
+    y = np.concatenate([o[5] for o in out])
+    np.testing.assert_array_equal(y, oracle.spmv(A, b))
+    xo, so = oracle.pbicgstab(A, b, maxit=200, tol=1e-8)
+    assert out[0][3]["converged"] and abs(out[0][3]["iters"] - so.iters) <= 1
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
