@@ -1,119 +1,136 @@
 /*
- * pbicgstab.h -- drop-in C++ interface of the solver library (libcuda_mat.so).
+ * pbicgstab.h -- C++ interface of libcuda_mat.so on MI355X.
  *
- * Same entry points, argument order and meaning as the reference header
- * (/root/reference/pbicgstab.h:23-30,78,91,113-120), so a caller such as the reference's
- * example.cpp compiles against this header unchanged -- minus the CUDA / <conio.h> includes,
- * which this header does not need.  The three solvers are thin shims over the C ABI
- * (include/cudamat.h: cudamat_solve); all arithmetic runs in hand-written gfx950 kernels.
+ * Drop-in for the header of the same name in Russoul/cuda-mat: every declaration a caller of the
+ * reference library uses is here with the same name, parameter order and meaning
+ *   enum Base                                  reference pbicgstab.h:23-26
+ *   rand_float_0_1 / rand_float                :28-30
+ *   gen_rand_csr_matrix<Base> / fill_csr_matrix<Base>   :32-76
+ *   gen_rand_vector, dump_vector<T>, toDenseVector      :78-91
+ *   bicgstab (2 overloads), bicgstab_lu_precond         :113-120
+ * but none of the CUDA / Windows includes (<cuda_runtime.h>, <conio.h>), which this implementation does
+ * not need.  The solvers are shims over the C ABI of include/cudamat.h (cudamat_solve); the arithmetic
+ * runs in hand-written gfx950 kernels.
  *
- * Differences a caller can observe (all deliberate):
- *   - bicgstab(A, b) works: the reference's version never forms r0 = b - A x0
- *     (pbicgstab.cu:471-478 is commented out) and fails on iteration 0.
- *   - no call ever exit()s the process; device errors make the solvers return false.
- *   - cudamat_last_stats() exposes iterations / residuals, which the reference discards.
+ * Observable differences, all deliberate: bicgstab(A, b) works (upstream never forms
+ * r0 = b - A x0, pbicgstab.cu:471-478); nothing calls exit(); cudamat_last_stats() reports what the
+ * reference throws away (iterations, residual norms, phase times).
  */
 #pragma once
 
 #include <cmath>
 #include <cstdlib>
 #include <functional>
-#include <iostream>
 #include <sstream>
 #include <string>
 #include <vector>
 
 #include "cudamat.h"
 
-enum Base {
-    Base0 = 0,
-    Base1 = 1
-};
+enum Base { Base0 = 0, Base1 = 1 };
 
-/* uniform draws from libc rand(), exactly the reference's recipe (pbicgstab.cu:413-423) so that a
- * caller who seeds srand() sees the same matrices and vectors */
+/* libc rand() scaled to [0,1] / [min,max]; seeding with srand() reproduces the reference's draws */
 double rand_float_0_1();
 double rand_float(double min, double max);
 
-/* dense-scan random CSR (pbicgstab.h:32-55 of the reference): every (i,j) draws one uniform to decide
- * "zero", non-zeros draw values until |value| >= eps.  O(n*m) by construction. */
+namespace cudamat_detail {
+/* shared body of the two dense-scan CSR builders: visit (i, j) row-major, ask `entry` whether the
+ * position holds a value, append it with its column index in the requested base */
+template <Base base, typename Entry>
+int dense_scan_to_csr(int rows, int cols, std::vector<double> *values, std::vector<int> *row_ptr,
+                      std::vector<int> *col_idx, Entry entry)
+{
+    int cursor = static_cast<int>(base);
+    row_ptr->push_back(cursor);
+    for (int i = 0; i < rows; ++i) {
+        for (int j = 0; j < cols; ++j) {
+            double value = 0.0;
+            if (!entry(i, j, &value)) continue;
+            values->push_back(value);
+            col_idx->push_back(j + static_cast<int>(base));
+            ++cursor;
+        }
+        row_ptr->push_back(cursor);
+    }
+    return static_cast<int>(values->size());
+}
+}  // namespace cudamat_detail
+
+/* random CSR by dense scan: a position is zero with the given probability, otherwise uniform in
+ * [min,max], redrawn while |value| < eps.  O(n*m) rand() calls -- meant for small demos. */
 template <Base base>
 int gen_rand_csr_matrix(int n, int m, std::vector<double> *A, std::vector<int> *IA, std::vector<int> *JA,
                         double probability_of_zero, double min, double max, double eps)
 {
-    int next = base;
-    IA->push_back(next);
-    for (int i = 0; i < n; ++i) {
-        for (int j = 0; j < m; ++j) {
-            if (rand_float_0_1() <= probability_of_zero) continue;
-            double r = rand_float(min, max);
-            while (std::fabs(r) < eps) r = rand_float(min, max);
-            A->push_back(r);
-            JA->push_back(j + base);
-            ++next;
-        }
-        IA->push_back(next);
-    }
-    return (int)A->size();
+    return cudamat_detail::dense_scan_to_csr<base>(n, m, A, IA, JA, [&](int, int, double *out) {
+        if (rand_float_0_1() <= probability_of_zero) return false;
+        double r = rand_float(min, max);
+        while (std::fabs(r) < eps) r = rand_float(min, max);
+        *out = r;
+        return true;
+    });
 }
 
-/* CSR from a dense generator f(i,j), keeping |f| > eps (reference pbicgstab.h:57-76) */
+/* CSR of the dense function f(i,j), keeping the positions with |f| > eps */
 template <Base base>
 int fill_csr_matrix(int n, int m, std::vector<double> *A, std::vector<int> *IA, std::vector<int> *JA,
                     std::function<double(int, int)> f, double eps)
 {
-    int next = base;
-    IA->push_back(next);
-    for (int i = 0; i < n; ++i) {
-        for (int j = 0; j < m; ++j) {
-            const double el = f(i, j);
-            if (std::fabs(el) > eps) {
-                A->push_back(el);
-                JA->push_back(j + base);
-                ++next;
-            }
-        }
-        IA->push_back(next);
-    }
-    return (int)A->size();
+    return cudamat_detail::dense_scan_to_csr<base>(n, m, A, IA, JA, [&](int i, int j, double *out) {
+        *out = f(i, j);
+        return std::fabs(*out) > eps;
+    });
 }
 
 void gen_rand_vector(int n, double *vector, double probability_of_zero, double min, double max);
 
-/* "(v0 v1 ... )" with std::to_string formatting, as the reference prints results */
+/* "(v0 v1 ... )", elements formatted by std::to_string */
 template <typename T>
 void dump_vector(std::ostringstream &stream, int n, T *vector)
 {
-    stream << "(";
-    for (int i = 0; i < n; ++i) stream << std::to_string(vector[i]) << " ";
-    stream << ")";
+    std::string text = "(";
+    for (int i = 0; i < n; ++i) text += std::to_string(vector[i]) + " ";
+    stream << text << ")";
 }
 
-/* n x 1 CSR "column vector" (as loadMMSparseMatrix returns for a vector file) -> dense */
+/* an n x 1 CSR matrix (what loadMMSparseMatrix returns for a vector file) to a dense array */
 void toDenseVector(int n, int nnz, double *A, int *IA, double *out);
 
-/* wall-clock seconds (helper_cusolver.h:148-153 of the reference) */
+/* wall-clock seconds since the epoch */
 double second(void);
 
+/* argument direction markers kept for source compatibility */
 #define IN
 #define OUT
 
-/* Common arguments (reference pbicgstab.h:96-110): n dimension; nnz non-zeros; A values; iA row
- * pointers (iA[0] = index base 0 or 1); jA column indices in that base; b right-hand side; maxit;
- * tol relative to the initial residual; debug prints the reference's trace; x solution (written even
- * when not converged); dtAlg seconds spent in the device iteration loop. */
+/*
+ * Arguments shared by the three solvers: n = dimension, nnz = stored entries, A/iA/jA = CSR values,
+ * row pointers (iA[0] is the index base, 0 or 1) and column indices in that base, b = right-hand side,
+ * maxit / tol = iteration limit and tolerance relative to the initial residual, debug = print the
+ * residual trace, x = result (written also when the method does not converge), dtAlg = seconds spent
+ * in the device iteration loop (uploads and analysis excluded).
+ */
 
-/* solve A x = b, no preconditioner, x0 = 1 */
-bool bicgstab(int n, int nnz, double IN(*A), int IN(*iA), int IN(*jA), double IN(*b), int maxit, double tol,
-              bool debug, double OUT(*x), double OUT(*dtAlg));
+/* A x = b, no preconditioner, x0 = 1 */
+bool bicgstab(int n, int nnz,
+              double IN(*A), int IN(*iA), int IN(*jA),
+              double IN(*b),
+              int maxit, double tol, bool debug,
+              double OUT(*x), double OUT(*dtAlg));
 
-/* solve (A0 + I*d) x = b from x0, no preconditioner */
-bool bicgstab(int n, int nnz, double IN(*A0), int IN(*iA0), int IN(*jA0), double IN(*d), double IN(*x0),
-              double IN(*b), int maxit, double tol, bool debug, double OUT(*x), double OUT(*dtAlg));
+/* (A0 + I*d) x = b from the initial guess x0, no preconditioner */
+bool bicgstab(int n, int nnz,
+              double IN(*A0), int IN(*iA0), int IN(*jA0),
+              double IN(*d), double IN(*x0), double IN(*b),
+              int maxit, double tol, bool debug,
+              double OUT(*x), double OUT(*dtAlg));
 
-/* solve A x = b with the ILU(0) preconditioner; requires A[i,i] != 0 */
-bool bicgstab_lu_precond(int n, int nnz, double IN(*A), int IN(*iA), int IN(*jA), double IN(*b), int maxit,
-                         double tol, bool debug, double OUT(*x), double OUT(*dtAlg));
+/* A x = b with the ILU(0) preconditioner; every diagonal entry A[i,i] must be stored and non-zero */
+bool bicgstab_lu_precond(int n, int nnz,
+                         double IN(*A), int IN(*iA), int IN(*jA),
+                         double IN(*b),
+                         int maxit, double tol, bool debug,
+                         double OUT(*x), double OUT(*dtAlg));
 
-/* what the last solve on this thread did (iterations, residual norms, phase times) */
+/* statistics of the last solve issued by the calling thread */
 const cudamat_stats *cudamat_last_stats();
