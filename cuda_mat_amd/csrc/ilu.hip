@@ -316,6 +316,10 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
     CM_TRY(dalloc(&H.level_ptr_dev, (size_t)nlev + 1));
     CM_HIP(hipMemcpy(H.level_ptr_dev, F.level_ptr.data(), sizeof(int) * ((size_t)nlev + 1), hipMemcpyHostToDevice));
     H.lanes = pick_lanes(n ? (double)F.nnz / n : 1.0);
+    if (const char *e = getenv("CUDAMAT_TRSV_LANES")) {
+        const int v = atoi(e);
+        if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) H.lanes = v;
+    }
     // launch plan: a big level is its own segment; consecutive small levels are merged
     H.seg_begin.clear();
     H.seg_end.clear();

@@ -525,3 +525,33 @@ def test_degenerate_systems(cm, ctx, oracle):
     with pytest.raises(cm.CudamatError) as e:
         cm.bicgstab(2, 2, np.ones(2), np.array([5, 6, 7], np.int32), np.ones(2, np.int32), np.ones(2), 10, 1e-8)
     assert e.value.code == 2          # index base must be 0 or 1
+
+
+# ------------------------------------------------- randomized shapes through every SpMV form
+@pytest.mark.parametrize("seed", range(12))
+def test_spmv_random_shapes_all_forms(cm, ctx, oracle, seed, monkeypatch):
+    """random rectangular-free CSR shapes (ragged rows, empty rows, 0/1 base) through the lanes-per-row,
+    the LDS-staged stream and the blocked two-phase kernels: integer data => all bit-exact vs the oracle"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 6000))
+    density = float(rng.choice([0.0005, 0.003, 0.02, 0.2])) if n > 50 else 0.5
+    S = sp.random(n, n, density=density, random_state=seed, format="csr")
+    S.data[:] = rng.integers(-4, 5, S.nnz)
+    S.eliminate_zeros()
+    S.sort_indices()
+    base = int(rng.integers(0, 2))
+    A = oracle.Csr(n, (S.indptr + base).astype(np.int32), (S.indices + base).astype(np.int32),
+                   S.data.astype(np.float64), n)
+    x = rng.integers(-8, 9, n).astype(np.float64)
+    d = rng.integers(-2, 3, n).astype(np.float64)
+    want = oracle.spmv(A, x)
+    want_d = oracle.csrmv(A, 1.0, x, 1.0, x * d)
+    for mode in ("csr", "pb"):
+        monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), want_d)
+    monkeypatch.delenv("CUDAMAT_SPMV_MODE")
+    for lanes in ("4", "32"):
+        monkeypatch.setenv("CUDAMAT_SPMV_LANES", lanes)     # forces the lanes-per-row kernel (no stream tiles)
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
