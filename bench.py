@@ -94,7 +94,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback exists)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CUDAMAT_FORCE_SHARDED=1 under torchrun --nproc-per-node 1 exercises the whole N > 1 code path
+    # (process group, TorchComm callbacks, sharded loop) on a single GPU
+    use_dist = world > 1 or (os.environ.get("CUDAMAT_FORCE_SHARDED") == "1" and "MASTER_ADDR" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -130,7 +133,7 @@ def main():
         del rp, ci, va
         torch.cuda.empty_cache()
         comm = None
-        if world > 1:
+        if use_dist:
             comm = TorchComm(device=dev)
             solver.set_comm(comm.struct)
         xs = torch.empty(nloc, dtype=torch.float64, device=dev)
@@ -159,7 +162,7 @@ def main():
 
         def barrier():
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -170,7 +173,7 @@ def main():
         ax = torch.empty(nloc, dtype=torch.float64, device=dev)
         solver.spmv(x, ax)
         res2 = ((b - ax) ** 2).sum()
-        if world > 1:
+        if use_dist:
             dist.all_reduce(res2)
         true_res = float(res2.sqrt().item())
         assert abs(true_res - st.nrm) <= 1e-6 * st.nrm0 + 1e-3 * st.nrm, \
@@ -192,7 +195,7 @@ def main():
         ms_spmv, n_spmv, ms_trsv, n_trsv, st = run(args.steps, flags | (0 if latency_bound else cm.FLAG_PROFILE))
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -251,7 +254,7 @@ def main():
         print(json.dumps(out), flush=True)
     solver.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
