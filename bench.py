@@ -80,6 +80,22 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (RCCL prints its library
+    # path when a communicator is created) are sent to stderr until the result is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        out = run_bench(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def run_bench(args):
     import torch
     import cuda_mat_amd as cm
     from cuda_mat_amd.dist import TorchComm, shard_rows
@@ -224,6 +240,7 @@ def main():
                 traffic = sum(g["hbm_bytes_per_launch_corrected"] for g in got)
                 traffic_src = os.path.relpath(f, ROOT)
                 break
+    out = None
     if rank == 0:
         out = {
             "metric": "BiCGSTAB iterations/s (1e7-row CSR, 50 nnz/row, fp64)" if args.workload == "rand50"
@@ -251,11 +268,11 @@ def main():
             out["levels"] = [st.n_levels_l, st.n_levels_u]
         if world == 1 and args.cpu_baseline != "off":
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
     solver.close()
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":
