@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "solver.h"
+#include "spmv_pb.h"
 
 using namespace cm;
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ilu0_level(int row_begin, int ro
 template <int LANES>
 __device__ __forceinline__ void trsv_rows(int r0, int r1, int first, int stride, const int *frp, const int *fci,
                                           const double *fval, const int *row_of, const double *dinv,
-                                          const double *rhs, double *out)
+                                          const double *far, const double *rhs, double *out)
 {
     const int lane = threadIdx.x & (LANES - 1);
     for (int pr = r0 + first; pr < r1; pr += stride) {
@@ -175,6 +176,7 @@ __device__ __forceinline__ void trsv_rows(int r0, int r1, int first, int stride,
         if (lane == 0) {
             const int r = row_of[pr];
             double v = rhs[r] - sum;
+            if (far) v -= far[pr];              // entries whose column lies in an earlier group
             if (dinv) v *= dinv[pr];
             out[r] = v;
         }
@@ -184,11 +186,12 @@ __device__ __forceinline__ void trsv_rows(int r0, int r1, int first, int stride,
 template <int LANES>
 __global__ __launch_bounds__(kBlock) void k_trsv_level(int r0, int r1, const int *frp, const int *fci,
                                                        const double *fval, const int *row_of,
-                                                       const double *dinv, const double *rhs, double *out)
+                                                       const double *dinv, const double *far, const double *rhs,
+                                                       double *out)
 {
     constexpr int RPB = kBlock / LANES;
     trsv_rows<LANES>(r0, r1, blockIdx.x * RPB + threadIdx.x / LANES, gridDim.x * RPB, frp, fci, fval, row_of,
-                     dinv, rhs, out);
+                     dinv, far, rhs, out);
 }
 
 // several consecutive small levels in ONE workgroup: a workgroup-scope fence + barrier publishes a
@@ -197,12 +200,12 @@ template <int LANES>
 __global__ __launch_bounds__(kBlock) void k_trsv_small_levels(int l0, int l1, const int *level_ptr,
                                                               const int *frp, const int *fci, const double *fval,
                                                               const int *row_of, const double *dinv,
-                                                              const double *rhs, double *out)
+                                                              const double *far, const double *rhs, double *out)
 {
     constexpr int RPB = kBlock / LANES;
     for (int l = l0; l < l1; l++) {
         trsv_rows<LANES>(level_ptr[l], level_ptr[l + 1], threadIdx.x / LANES, RPB, frp, fci, fval, row_of, dinv,
-                         rhs, out);
+                         far, rhs, out);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -221,8 +224,17 @@ static int pick_lanes(double mean)
 
 struct TriHost {   // host-side launch plan kept next to the TriFactor
     std::vector<int> seg_begin, seg_end;   // level ranges; a segment with end-begin > 1 is a small-level run
+    std::vector<int> seg_group;            // group of every segment (segments never straddle groups)
     int *level_ptr_dev = nullptr;
     int lanes = 8;
+    // hybrid solve (see split_factor): levels are cut into a few consecutive GROUPS; entries whose column
+    // belongs to an EARLIER group ("far") are applied per group by one blocked two-phase SpMV, only the
+    // entries inside the group ("near") stay in the gather-based level kernels
+    bool hybrid = false;
+    std::vector<int> grp_level;            // K+1 level boundaries of the groups
+    std::vector<PbPlan> far;               // far[g]: rows of group g x columns of groups < g
+    double *far_buf = nullptr;             // n doubles in level-major row order: far_g . out
+    std::vector<int> lev_host;             // level of every original row (kept until the split)
 };
 
 }  // namespace cm
@@ -260,6 +272,10 @@ int ilu0_release(cudamat_solver *s)
     if (IluPlans *pl = (IluPlans *)s->ilu_plans) {
         if (pl->L.level_ptr_dev) hipFree(pl->L.level_ptr_dev);
         if (pl->U.level_ptr_dev) hipFree(pl->U.level_ptr_dev);
+        for (TriHost *h : {&pl->L, &pl->U}) {
+            for (PbPlan &fp : h->far) pb_free(&fp);
+            if (h->far_buf) hipFree(h->far_buf);
+        }
         delete pl;
         s->ilu_plans = nullptr;
     }
@@ -320,23 +336,150 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
         const int v = atoi(e);
         if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) H.lanes = v;
     }
-    // launch plan: a big level is its own segment; consecutive small levels are merged
+    // groups of consecutive levels for the hybrid solve: only for big factors with many wide levels whose
+    // columns are scattered (the gather-bound case); ~16 levels per group leaves ~10 % of the entries near
+    H.lev_host.swap(lev);
+    const char *hy = getenv("CUDAMAT_TRSV_HYBRID");
+    const bool want = hy ? hy[0] == '1' : (n >= 500000 && F.nnz >= (8 << 20) && nlev >= 16 && n / nlev >= 16384);
+    int K = 1;
+    if (want && nlev >= 4) {
+        K = nlev / 16;
+        if (K < 2) K = 2;
+        if (K > 16) K = 16;
+        if (const char *e = getenv("CUDAMAT_TRSV_GROUPS")) {
+            const int v = atoi(e);
+            if (v >= 2 && v <= 128 && v <= nlev) K = v;
+        }
+    }
+    H.hybrid = K > 1;
+    H.grp_level.assign((size_t)K + 1, 0);
+    for (int g = 0; g <= K; g++) H.grp_level[(size_t)g] = (int)((long long)nlev * g / K);
+    // launch plan: a big level is its own segment; consecutive small levels are merged (inside a group)
     H.seg_begin.clear();
     H.seg_end.clear();
-    int l = 0;
-    while (l < nlev) {
-        const int rows = F.level_ptr[(size_t)l + 1] - F.level_ptr[(size_t)l];
-        if (rows > kSmallLevel) {
-            H.seg_begin.push_back(l);
-            H.seg_end.push_back(l + 1);
-            l++;
-        } else {
-            int e = l;
-            while (e < nlev && F.level_ptr[(size_t)e + 1] - F.level_ptr[(size_t)e] <= kSmallLevel) e++;
+    H.seg_group.clear();
+    for (int g = 0; g < K; g++) {
+        int l = H.grp_level[(size_t)g];
+        const int lend = H.grp_level[(size_t)g + 1];
+        while (l < lend) {
+            const int rows = F.level_ptr[(size_t)l + 1] - F.level_ptr[(size_t)l];
+            int e = l + 1;
+            if (rows <= kSmallLevel)
+                while (e < lend && F.level_ptr[(size_t)e + 1] - F.level_ptr[(size_t)e] <= kSmallLevel) e++;
             H.seg_begin.push_back(l);
             H.seg_end.push_back(e);
+            H.seg_group.push_back(g);
             l = e;
         }
+    }
+    return CUDAMAT_OK;
+}
+
+// ---- hybrid split of a level-major factor into near (same group) and far (earlier groups) entries
+__global__ __launch_bounds__(kBlock) void k_split_count(int n, const int *frp, const int *fci, const int *row_of,
+                                                        const unsigned char *grp, int *cnt_near, int *cnt_far)
+{
+    const int pr = blockIdx.x * kBlock + threadIdx.x;
+    if (pr >= n) return;
+    const int g = grp[row_of[pr]];
+    int nn = 0, nf = 0;
+    for (int k = frp[pr]; k < frp[pr + 1]; k++) {
+        if (grp[fci[k]] == g) nn++; else nf++;
+    }
+    cnt_near[pr] = nn;
+    cnt_far[pr] = nf;
+}
+
+__global__ __launch_bounds__(kBlock) void k_split_fill(int n, const int *frp, const int *fci, const double *fval,
+                                                       const int *row_of, const unsigned char *grp,
+                                                       const int *nrp, int *nci, double *nval, const int *qrp,
+                                                       int *qci, double *qval)
+{
+    const int pr = blockIdx.x * kBlock + threadIdx.x;
+    if (pr >= n) return;
+    const int g = grp[row_of[pr]];
+    int on = nrp[pr], of = qrp[pr];
+    for (int k = frp[pr]; k < frp[pr + 1]; k++) {
+        const int c = fci[k];
+        if (grp[c] == g) { nci[on] = c; nval[on++] = fval[k]; }
+        else { qci[of] = c; qval[of++] = fval[k]; }
+    }
+}
+
+static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H)
+{
+    if (!H.hybrid) return CUDAMAT_OK;
+    hipStream_t st = s->ctx->stream;
+    const int n = s->n;
+    const int K = (int)H.grp_level.size() - 1;
+    // group of every original row
+    std::vector<unsigned char> hg((size_t)n);
+    {
+        std::vector<unsigned char> g_of_level((size_t)F.nlevels);
+        for (int g = 0; g < K; g++)
+            for (int l = H.grp_level[(size_t)g]; l < H.grp_level[(size_t)g + 1]; l++) g_of_level[(size_t)l] = (unsigned char)g;
+        for (int i = 0; i < n; i++) hg[(size_t)i] = g_of_level[(size_t)H.lev_host[(size_t)i]];
+    }
+    unsigned char *d_grp = nullptr;
+    int *d_cn = nullptr, *d_cf = nullptr, *nrp = nullptr, *qrp = nullptr, *nci = nullptr, *qci = nullptr;
+    double *nval = nullptr, *qval = nullptr;
+    int rc = CUDAMAT_OK;
+    do {
+        if ((rc = dalloc(&d_grp, (size_t)n))) break;
+        if ((rc = dalloc(&d_cn, (size_t)n))) break;
+        if ((rc = dalloc(&d_cf, (size_t)n))) break;
+        if (hipMemcpy(d_grp, hg.data(), (size_t)n, hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_split_count, dim3(grid), dim3(kBlock), 0, st, n, F.rp, F.ci, F.row_of, d_grp, d_cn, d_cf);
+        std::vector<int> cn((size_t)n), cf((size_t)n), hn((size_t)n + 1, 0), hf((size_t)n + 1, 0);
+        if (hipMemcpyAsync(cn.data(), d_cn, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(cf.data(), d_cf, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("factor split count failed"); break; }
+        for (int i = 0; i < n; i++) {
+            hn[(size_t)i + 1] = hn[(size_t)i] + cn[(size_t)i];
+            hf[(size_t)i + 1] = hf[(size_t)i] + cf[(size_t)i];
+        }
+        const int64_t nnz_near = hn[(size_t)n], nnz_far = hf[(size_t)n];
+        if ((rc = dalloc(&nrp, (size_t)n + 1))) break;
+        if ((rc = dalloc(&qrp, (size_t)n + 1))) break;
+        if ((rc = dalloc(&nci, (size_t)nnz_near))) break;
+        if ((rc = dalloc(&nval, (size_t)nnz_near))) break;
+        if ((rc = dalloc(&qci, (size_t)nnz_far))) break;
+        if ((rc = dalloc(&qval, (size_t)nnz_far))) break;
+        if (hipMemcpy(nrp, hn.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(qrp, hf.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        hipLaunchKernelGGL(k_split_fill, dim3(grid), dim3(kBlock), 0, st, n, F.rp, F.ci, F.val, F.row_of, d_grp, nrp, nci,
+                           nval, qrp, qci, qval);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("factor split failed"); break; }
+        // one blocked SpMV plan per group: rows of the group (level-major, contiguous) x all columns
+        H.far.assign((size_t)K, PbPlan());
+        for (int g = 1; g < K && !rc; g++) {
+            const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)g]], r1 = F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]];
+            const int64_t cnt = (int64_t)hf[(size_t)r1] - hf[(size_t)r0];
+            if (r1 <= r0 || cnt <= 0) continue;
+            rc = pb_build(st, r1 - r0, s->n_cols, cnt, qrp + r0, qci, qval, &H.far[(size_t)g]);
+        }
+        if (rc) break;
+        if ((rc = dalloc(&H.far_buf, (size_t)n))) break;
+        if (hipMemsetAsync(H.far_buf, 0, sizeof(double) * (size_t)n, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        // the level kernels keep only the near entries
+        hipFree(F.rp); hipFree(F.ci); hipFree(F.val);
+        F.rp = nrp; F.ci = nci; F.val = nval;
+        F.nnz = nnz_near;
+        nrp = nullptr; nci = nullptr; nval = nullptr;
+        H.lanes = pick_lanes(n ? (double)F.nnz / n : 1.0);
+    } while (0);
+    void *tmp[] = {d_grp, d_cn, d_cf, nrp, qrp, nci, qci, nval, qval};
+    for (void *q : tmp)
+        if (q) hipFree(q);
+    H.lev_host.clear();
+    H.lev_host.shrink_to_fit();
+    if (rc) {   // e.g. not enough memory for the blocked copies: keep the pure level solve (F is intact)
+        for (PbPlan &pl : H.far) pb_free(&pl);
+        H.far.clear();
+        if (H.far_buf) { hipFree(H.far_buf); H.far_buf = nullptr; }
+        H.hybrid = false;
+        return rc == CUDAMAT_ERR_NOMEM ? CUDAMAT_OK : rc;
     }
     return CUDAMAT_OK;
 }
@@ -430,6 +573,8 @@ int ilu0_setup(cudamat_solver *s)
         if ((rc = fill_factor(s, false, s->L))) break;
         if ((rc = fill_factor(s, true, s->U))) break;
         if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("factor fill failed"); break; }
+        if ((rc = split_factor(s, s->L, pl->L))) break;
+        if ((rc = split_factor(s, s->U, pl->U))) break;
         s->t_factor = now_s() - t1;
         s->has_ilu = true;
     } while (0);
@@ -445,10 +590,31 @@ int ilu0_setup(cudamat_solver *s)
 }
 
 template <int LANES>
-static void launch_trsv_segments(hipStream_t st, const TriFactor &F, const TriHost &H, const double *rhs, double *out)
+static int launch_trsv_segments(hipStream_t st, const TriFactor &F, const TriHost &H, const double *rhs, double *out)
 {
     constexpr int RPB = kBlock / LANES;
+    int cur_group = -1;
     for (size_t g = 0; g < H.seg_begin.size(); g++) {
+        const int grp = H.seg_group.empty() ? 0 : H.seg_group[g];
+        const double *far = nullptr;
+        if (H.hybrid && grp > 0 && H.far[(size_t)grp].nnz > 0) {
+            if (grp != cur_group) {   // far_g . out for the rows of this group: one blocked SpMV
+                const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)grp]];
+                SpmvArgs a{};
+                a.n = H.far[(size_t)grp].n;
+                a.x = out;
+                a.alpha = 1.0;
+                a.beta = 0.0;
+                a.y = H.far_buf + r0;
+                a.dot = 0;
+                a.loop = LoopArgs{nullptr, nullptr, 0, 0, 0};
+                a.check = CHECK_NONE;
+                a.half = ScalarSrc{nullptr, 0, 1};
+                CM_TRY(launch_spmv_pb(st, H.far[(size_t)grp], a));
+            }
+            far = H.far_buf;
+        }
+        cur_group = grp;
         const int l0 = H.seg_begin[g], l1 = H.seg_end[g];
         const int r0 = F.level_ptr[(size_t)l0], r1 = F.level_ptr[(size_t)l1];
         const bool big = (l1 - l0 == 1) && (r1 - r0 > kSmallLevel);
@@ -456,12 +622,13 @@ static void launch_trsv_segments(hipStream_t st, const TriFactor &F, const TriHo
             int grid = (r1 - r0 + RPB - 1) / RPB;
             if (grid > 4096) grid = 4096;
             hipLaunchKernelGGL(k_trsv_level<LANES>, dim3(grid), dim3(kBlock), 0, st, r0, r1, F.rp, F.ci, F.val,
-                               F.row_of, F.dinv, rhs, out);
+                               F.row_of, F.dinv, far, rhs, out);
         } else {
             hipLaunchKernelGGL(k_trsv_small_levels<LANES>, dim3(1), dim3(kBlock), 0, st, l0, l1, H.level_ptr_dev,
-                               F.rp, F.ci, F.val, F.row_of, F.dinv, rhs, out);
+                               F.rp, F.ci, F.val, F.row_of, F.dinv, far, rhs, out);
         }
     }
+    return CUDAMAT_OK;
 }
 
 int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *rhs, double *out)
@@ -470,14 +637,16 @@ int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *
     if (!pl || !s->has_ilu) { set_error("ILU(0) factors missing"); return CUDAMAT_ERR_ARG; }
     const TriHost &H = upper ? pl->U : pl->L;
     hipStream_t st = s->ctx->stream;
+    int rc;
     switch (H.lanes) {
-    case 2:  launch_trsv_segments<2>(st, F, H, rhs, out); break;
-    case 4:  launch_trsv_segments<4>(st, F, H, rhs, out); break;
-    case 8:  launch_trsv_segments<8>(st, F, H, rhs, out); break;
-    case 16: launch_trsv_segments<16>(st, F, H, rhs, out); break;
-    case 32: launch_trsv_segments<32>(st, F, H, rhs, out); break;
-    default: launch_trsv_segments<64>(st, F, H, rhs, out); break;
+    case 2:  rc = launch_trsv_segments<2>(st, F, H, rhs, out); break;
+    case 4:  rc = launch_trsv_segments<4>(st, F, H, rhs, out); break;
+    case 8:  rc = launch_trsv_segments<8>(st, F, H, rhs, out); break;
+    case 16: rc = launch_trsv_segments<16>(st, F, H, rhs, out); break;
+    case 32: rc = launch_trsv_segments<32>(st, F, H, rhs, out); break;
+    default: rc = launch_trsv_segments<64>(st, F, H, rhs, out); break;
     }
+    CM_TRY(rc);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }

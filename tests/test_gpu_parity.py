@@ -555,3 +555,34 @@ def test_spmv_random_shapes_all_forms(cm, ctx, oracle, seed, monkeypatch):
     for lanes in ("4", "32"):
         monkeypatch.setenv("CUDAMAT_SPMV_LANES", lanes)     # forces the lanes-per-row kernel (no stream tiles)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
+
+
+@pytest.mark.parametrize("name", ["rand20000x50", "real3000", "mat10000"])
+def test_hybrid_triangular_solve_vs_oracle(cm, ctx, oracle, golden_dir, name, monkeypatch):
+    """the group-split triangular solve (far entries through the blocked SpMV, near entries through the
+    level kernels; csrc/ilu.hip split_factor) forced on small systems: same L^-1 U^-1 as the oracle"""
+    monkeypatch.setenv("CUDAMAT_TRSV_HYBRID", "1")
+    if name == "rand20000x50":
+        A = oracle.rand_rows(20000, 50, 0x5EED)
+    elif name == "real3000":
+        A = _real_sparse(oracle, 3000, 0.004, 11, base=1)
+    else:
+        A = _load(oracle, golden_dir, name)
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+    s.ilu0()
+    want = oracle.ilu0(A)
+    np.testing.assert_allclose(s.ilu0_values(), want, rtol=1e-12, atol=1e-14)
+    rng = np.random.default_rng(0)
+    for rep in range(2):                       # twice: the far buffer and the product stream are reused
+        rhs = rng.standard_normal(A.n)
+        dr, do = ctx.array(rhs), ctx.empty(A.n)
+        s.precond_apply(dr, do)
+        ref = oracle.trsv_upper(A, want, oracle.trsv_lower_unit(A, want, rhs))
+        np.testing.assert_allclose(do.download(), ref, rtol=1e-10, atol=1e-12)
+    s.close()
+    xs = 1.0 + np.sin(np.arange(A.n))
+    b = oracle.spmv(A, xs)
+    xo, so = oracle.pbicgstab(A, b, vm=want, maxit=500, tol=1e-8)
+    x, st, h = _solve_dev(cm, ctx, A, b, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PBICGSTAB, maxit=500, tol=1e-8)
+    assert st.converged and abs(st.iters - so.iters) <= max(2, 0.1 * so.iters)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5
