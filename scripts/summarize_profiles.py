@@ -16,7 +16,7 @@ def main(tag):
         for r in csv.DictReader(open(tr)):
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            if d > 20000 and not k.startswith("at::") and "rocclr" not in k:
+            if (d > 20000 or "trsv" in k) and not k.startswith("at::") and "rocclr" not in k:
                 dur[k].append(d)
         out = {"_note": "rocprofv3 --kernel-trace (durations of launches > 20 us: the rest are frozen no-ops past the stopping "
                         "point) and separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; counters in KB per launch; on gfx950 "
@@ -32,7 +32,7 @@ def main(tag):
             for r in csv.DictReader(open(fs[0])):
                 d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
                 k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-                if d > 20000 and k in out:
+                if (d > 20000 or "trsv" in k) and k in out:
                     acc[k].append(float(r["Counter_Value"]))
             for k, v in acc.items():
                 out[k][cn + "_KB_avg"] = sum(v) / len(v)
