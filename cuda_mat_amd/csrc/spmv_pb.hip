@@ -73,8 +73,10 @@ __global__ __launch_bounds__(kBlock) void k_pb_span(int n, int samples, const in
 
 bool pb_candidate(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci)
 {
-    if (n < 65536 || nnz < (1 << 22) || n_cols * 8 < (8 << 20)) return false;   // x within ~2 L2s: CSR is fine
-    if ((double)nnz / n < 8.0) return false;
+    // x comfortably inside one 4 MiB L2: gathers hit, the CSR kernels are fine.  Beyond that the blocked
+    // form wins from ~250 K columns on (scripts/size_probe.py); the final choice is timed anyway.
+    if (n < 65536 || nnz < (1 << 21) || n_cols * 8 < (2 << 20)) return false;
+    if ((double)nnz / n < 4.0) return false;
     if ((int64_t)n > (int64_t)kMaxParts * kTileMax) return false;
     unsigned long long *acc = nullptr, h[2] = {0, 0};
     if (hipMalloc((void **)&acc, 16) != hipSuccess) return false;
@@ -86,7 +88,7 @@ bool pb_candidate(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int 
     hipFree(acc);
     if (!h[1]) return false;
     const double span_bytes = 8.0 * (double)h[0] / (double)h[1];
-    return span_bytes > (double)(16 << 20);      // a row's gathers spread over more than 4 L2s
+    return span_bytes > (double)(2 << 20);       // a row's gathers spread over more than half an L2
 }
 
 // ------------------------------------------------------------------ analysis (one-off)
