@@ -10,6 +10,11 @@ struct LoopArgs {
     int hist_cap;
     int loop;          // CUDAMAT_LOOP_*
     int no_exit;
+    // per-iteration progress word in PINNED HOST memory: k_full publishes (k+1) << 32 | state with one
+    // 8-byte system-scope store, so the host can look at a lagged state without a copy or an event
+    unsigned long long *snap;
+    int snap_slots;
+    int k;             // the host's iteration index of this launch
 };
 
 struct SpmvPlan {

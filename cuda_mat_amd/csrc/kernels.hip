@@ -67,6 +67,14 @@ __device__ __forceinline__ void load_scalars(const ScalarSrc &s, double (&out)[K
 
 __device__ __forceinline__ bool leader() { return blockIdx.x == 0 && threadIdx.x == 0; }
 
+__device__ __forceinline__ void publish_progress(const LoopArgs &la, int state)
+{
+    if (la.snap && leader())
+        __hip_atomic_store(&la.snap[la.k % la.snap_slots],
+                           ((unsigned long long)(unsigned)(la.k + 1) << 32) | (unsigned long long)(unsigned)state,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------- stopping tests
 // half-step test, pbicgstab.cu:111-118.  Returns true when the caller must return.
 __device__ __forceinline__ bool check_half(const LoopArgs &la, const ScalarSrc &half, double *lds)
@@ -559,7 +567,10 @@ __global__ __launch_bounds__(kBlock) void k_full(LoopArgs la, ScalarSrc tt, int6
 {
     __shared__ double lds[8];
     LoopState *st = la.st;
-    if (st->state != 0) return;
+    if (st->state != 0) {             // frozen: still tell the host this iteration's launches have drained
+        publish_progress(la, st->state);
+        return;
+    }
     double sc[2];
     load_scalars<2>(tt, sc, lds);
     const double omega = sc[0] / sc[1];                    // :137
@@ -595,6 +606,7 @@ __global__ __launch_bounds__(kBlock) void k_full(LoopArgs la, ScalarSrc tt, int6
         st->omega = omega;
         st->it = st->it + 1;                               // :148 / :151
     }
+    publish_progress(la, 0);
 }
 
 int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, const double *sv,

@@ -48,6 +48,8 @@ struct cudamat_solver {
     cm::LoopState *st = nullptr;       // device
     cm::LoopState *st_ring = nullptr;  // pinned host, kRing slots
     hipEvent_t ev[cm::kRing] = {};
+    unsigned long long *snap_host = nullptr;   // pinned: per-iteration progress words written by k_full
+    unsigned long long *snap_dev = nullptr;    // the same memory as the device sees it
     double *hist = nullptr;    // device
     int hist_cap = 0;
     int hist_count = 0;

@@ -108,9 +108,10 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
         if (hipHostMalloc((void **)&s->st_ring, sizeof(LoopState) * kRing, hipHostMallocDefault) != hipSuccess) {
             rc = CUDAMAT_ERR_HIP; set_error("hipHostMalloc failed"); break;
         }
-        for (int i = 0; i < kRing; i++)
-            if (hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
-        if (rc) break;
+        if (hipHostMalloc((void **)&s->snap_host, sizeof(unsigned long long) * kRing, hipHostMallocDefault) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&s->snap_dev, s->snap_host, 0) != hipSuccess) {
+            rc = CUDAMAT_ERR_HIP; set_error("pinned progress words unavailable"); break;
+        }
         if (hipMemsetAsync(s->st, 0, sizeof(LoopState), st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
         if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("sync after upload failed"); break; }
     } while (0);
@@ -140,6 +141,7 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (s->st_ring) hipHostFree(s->st_ring);
+    if (s->snap_host) hipHostFree(s->snap_host);
     for (int i = 0; i < kRing; i++)
         if (s->ev[i]) hipEventDestroy(s->ev[i]);
     for (hipEvent_t e : s->prof_ev) hipEventDestroy(e);
@@ -363,7 +365,8 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
     const bool profile = (flags & CUDAMAT_FLAG_PROFILE) != 0;
     const bool sharded = s->sharded;
     const int n = s->n;
-    LoopArgs la{s->st, s->hist, s->hist_cap, loop, (flags & CUDAMAT_FLAG_NO_EXIT) ? 1 : 0};
+    LoopArgs la{s->st, s->hist, s->hist_cap, loop, (flags & CUDAMAT_FLAG_NO_EXIT) ? 1 : 0, s->snap_dev, kRing, 0};
+    for (int i = 0; i < kRing; i++) s->snap_host[i] = 0ULL;
     const LoopArgs la_none{nullptr, nullptr, 0, 0, 0};
     const ScalarSrc nosrc{nullptr, 0, 1};
     size_t pe = 0;   // profiling events used
@@ -385,11 +388,23 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
 
     int k = 0;
     for (; k < maxit; k++) {
-        if (k >= kLag) {   // lagged, deterministic look at the device state
-            const int slot = (k - kLag) % kRing;
-            CM_HIP(hipEventSynchronize(s->ev[slot]));
-            if (s->st_ring[slot].state != 0) break;
+        if (k >= kLag) {   // lagged, deterministic look at the device state: the progress word of
+            const int j = k - kLag;   // iteration j, published by its k_full through pinned memory
+            volatile unsigned long long *slot = &s->snap_host[j % kRing];
+            unsigned long long w = *slot;
+            if ((unsigned)(w >> 32) != (unsigned)(j + 1)) {
+                const double t_wait = now_s();
+                while ((unsigned)((w = *slot) >> 32) != (unsigned)(j + 1)) {
+                    __builtin_ia32_pause();
+                    if (now_s() - t_wait > 30.0) {
+                        set_error("iteration %d did not report progress within 30 s", j);
+                        return CUDAMAT_ERR_HIP;
+                    }
+                }
+            }
+            if ((unsigned)(w & 0xffffffffULL) != 0u) break;
         }
+        la.k = k;
         // rho, beta, p = r + beta (p - omega v)                     :80-89
         CM_TRY(launch_update_p(st, la, full_src, n, s->r, s->p, s->v));
         const double *pw = s->p;
@@ -450,9 +465,6 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
             CM_TRY(allreduce(s, s->red + 4, 2));
             full_src = ScalarSrc{s->red + 4, 0, 1};
         }
-        const int slot = k % kRing;
-        CM_HIP(hipMemcpyAsync(&s->st_ring[slot], s->st, sizeof(LoopState), hipMemcpyDeviceToHost, st));
-        CM_HIP(hipEventRecord(s->ev[slot], st));
     }
     // the full-step test of the last iteration has not been looked at yet
     CM_TRY(launch_check(st, la, full_src, CHECK_FULL));
