@@ -108,6 +108,11 @@ def run_bench(args):
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback exists)"
+    # rehearsal knobs (not used by the driver): all ranks on device 0 and/or the gloo backend, so that a
+    # one-GPU box can run the real multi-process path (RCCL itself refuses two ranks on one device)
+    if os.environ.get("CUDAMAT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("CUDAMAT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # CUDAMAT_FORCE_SHARDED=1 under torchrun --nproc-per-node 1 exercises the whole N > 1 code path
@@ -115,7 +120,10 @@ def run_bench(args):
     use_dist = world > 1 or (os.environ.get("CUDAMAT_FORCE_SHARDED") == "1" and "MASTER_ADDR" in os.environ)
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.workload == "mat10000":
         args.workload, args.rows, args.nx = "poisson5", 10000, 100
