@@ -144,3 +144,29 @@ def test_cpp_sharded_loop_with_blocked_spmv(cm, oracle, monkeypatch):
     xo, so = oracle.pbicgstab(A, b, maxit=200, tol=1e-8)
     assert out[0][3]["converged"] and abs(out[0][3]["iters"] - so.iters) <= 1
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
+
+
+def test_bench_two_processes_share_the_gpu_over_gloo():
+    """the REAL multi-process path of bench.py (torch.distributed.run, one rank per process, row shards
+    generated per rank, TorchComm on device buffers, lagged stop decisions across processes) with two
+    ranks on this box's single GPU.  RCCL refuses two ranks on one device, so the rehearsal uses gloo;
+    bench.py's own gate (solve converges to x*, recursive = true residual) must pass on both ranks."""
+    import json
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CUDAMAT_BENCH_ONE_DEVICE="1", CUDAMAT_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--rows", "600000", "--steps", "6", "--warmup", "1", "--cpu-baseline", "off"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["converges_in_iters"] <= 10
+    assert out["scaling"] == "strong" and "roofline" in out
