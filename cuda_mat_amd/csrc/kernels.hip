@@ -168,6 +168,9 @@ int launch_reduce_parts(hipStream_t s, ScalarSrc in, int K, double *out, int sqr
 // contiguous chunk of rows so that its 4 waves stream one contiguous piece of
 // val/colidx; chunks are dealt to XCDs in contiguous eighths so neighbouring rows
 // (which share x entries for banded matrices) meet in the same 4 MiB L2.
+constexpr int kLongRow = 4096;        // entries: rows beyond this are swept by the whole workgroup
+constexpr int kLongRowSlots = 32;
+
 template <int L>
 __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a, int rows_per_block)
 {
@@ -188,9 +191,27 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a, int rows_per_block)
     const int row_begin = (int)(r0 < a.n ? r0 : a.n);
     const int row_end = (int)(r0 + rows_per_block < a.n ? r0 + rows_per_block : a.n);
 
+    // Rows far longer than the rest (skewed .mtx inputs) would leave one group of L lanes walking
+    // tens of thousands of entries while the chip idles: a group only NOTES such a row; afterwards
+    // the whole workgroup sweeps each noted row with all 256 lanes (fixed reduction tree, rows taken
+    // in increasing order => deterministic).
+    __shared__ int long_rows[kLongRowSlots];
+    __shared__ int n_long;
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+
     double acc[2] = {0.0, 0.0};
     for (int row = row_begin + group; row < row_end; row += RPB) {
         const int s = a.rp[row], e = a.rp[row + 1];
+        if (e - s > kLongRow) {
+            int took = 0;
+            if (lane == 0) {
+                const int slot = atomicAdd(&n_long, 1);
+                if (slot < kLongRowSlots) { long_rows[slot] = row; took = 1; }
+            }
+            took = __shfl(took, (int)(threadIdx.x & 63) & ~(L - 1), 64);   // from the group's first lane
+            if (took) continue;            // (a full table leaves the row to the group itself)
+        }
         double sum = 0.0;
         for (int k = s + lane; k < e; k += L)
             sum += __builtin_nontemporal_load(a.val + k) * a.x[__builtin_nontemporal_load(a.ci + k)];
@@ -203,6 +224,38 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a, int rows_per_block)
             if (a.dot) {
                 acc[0] += out * a.w[row];
                 acc[1] += out * out;
+            }
+        }
+    }
+    __syncthreads();
+    const int nl = n_long < kLongRowSlots ? n_long : kLongRowSlots;
+    if (nl > 0) {
+        if (threadIdx.x == 0) {            // increasing row order (insertion sort of a handful of ids)
+            for (int i = 1; i < nl; i++) {
+                const int r = long_rows[i];
+                int j = i - 1;
+                while (j >= 0 && long_rows[j] > r) { long_rows[j + 1] = long_rows[j]; j--; }
+                long_rows[j + 1] = r;
+            }
+        }
+        __syncthreads();
+        for (int i = 0; i < nl; i++) {
+            const int row = long_rows[i];
+            const int s = a.rp[row], e = a.rp[row + 1];
+            double part[1] = {0.0};
+            for (int k = s + (int)threadIdx.x; k < e; k += kBlock)
+                part[0] += __builtin_nontemporal_load(a.val + k) * a.x[__builtin_nontemporal_load(a.ci + k)];
+            block_sum<1>(part, lds);
+            if (threadIdx.x == 0) {
+                double sum = part[0];
+                if (a.d) sum += a.d[row] * a.xd[row];
+                double out = a.alpha * sum;
+                if (a.beta != 0.0) out += a.beta * a.y[row];
+                a.y[row] = out;
+                if (a.dot) {
+                    acc[0] += out * a.w[row];
+                    acc[1] += out * out;
+                }
             }
         }
     }

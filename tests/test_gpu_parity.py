@@ -586,3 +586,50 @@ def test_hybrid_triangular_solve_vs_oracle(cm, ctx, oracle, golden_dir, name, mo
     x, st, h = _solve_dev(cm, ctx, A, b, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PBICGSTAB, maxit=500, tol=1e-8)
     assert st.converged and abs(st.iters - so.iters) <= max(2, 0.1 * so.iters)
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5
+
+
+def test_spmv_skewed_rows(cm, ctx, oracle, monkeypatch):
+    """a few rows with tens of thousands of entries among short ones: the lanes-per-row
+    kernel hands them to the whole workgroup; results stay exact, the fused dots stay right"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    n = 70000
+    ri = np.repeat(np.arange(n), 8)
+    cj = rng.integers(0, n, ri.size)
+    for r in (3, 4, 5000, 69999):                  # two adjacent long rows, one mid, the last row
+        cols = rng.choice(n, size=30000 if r != 4 else 5000, replace=False)
+        ri = np.concatenate([ri, np.full(cols.size, r)])
+        cj = np.concatenate([cj, cols])
+    S = sp.csr_matrix((np.ones(ri.size), (ri, cj)), shape=(n, n))
+    S.sum_duplicates()
+    S.data[:] = rng.integers(1, 4, S.nnz)
+    S.sort_indices()
+    A = oracle.Csr(n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), n)
+    x = rng.integers(-3, 4, n).astype(np.float64)
+    want = oracle.spmv(A, x)
+    rp, ci, v = _dev_csr(ctx, A)
+    dx, dy = ctx.array(x), ctx.empty(n)
+    for lanes in (None, "4", "64"):
+        if lanes:
+            monkeypatch.setenv("CUDAMAT_SPMV_LANES", lanes)
+        dy.zero()
+        ctx.spmv(n, rp, ci, v, 0, dx, dy)
+        np.testing.assert_array_equal(dy.download(), want)
+    monkeypatch.delenv("CUDAMAT_SPMV_LANES")
+    for mode in ("csr", "pb"):
+        monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
+    # inside a solve (fused dot partials include the long rows): make the system dominant and solve it
+    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
+    S2 = (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() + 1.0)).tocsr()
+    S2.sort_indices()
+    A2 = oracle.Csr(n, S2.indptr.astype(np.int32), S2.indices.astype(np.int32), S2.data.astype(np.float64), n)
+    xs = oracle.xstar(n, 5)
+    b = oracle.spmv(A2, xs)
+    xg, st, h = _solve_dev(cm, ctx, A2, b, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-10)
+    xo, so = oracle.pbicgstab(A2, b, maxit=200, tol=1e-10)
+    # (diagonals of 6e4 next to 17: erratic BiCGSTAB convergence, histories agree to 1e-9 for five
+    #  iterations and then drift with the rounding order of the 30000-term dots -- both converge)
+    assert st.converged and so.converged and abs(st.iters - so.iters) <= max(3, 0.3 * so.iters)
+    np.testing.assert_allclose(h[:8], oracle.pbicgstab(A2, b, maxit=4, tol=1e-30, want_hist=True)[2][:8], rtol=1e-7)
+    np.testing.assert_allclose(xg, xs, rtol=1e-6)
