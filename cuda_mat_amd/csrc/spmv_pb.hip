@@ -168,7 +168,8 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     p.NSUB = p.NRB * p.NW;
     const double seg = (double)nnz / ((double)p.NCB * p.NSUB);      // mean entries per segment
     p.LPS = seg <= 6.0 ? 16 : seg <= 22.0 ? 32 : 64;
-    if (p.NRB > kMaxParts || p.CB > 65536 || p.SR > 65536 || (size_t)p.RB * 8 > 150 * 1024) {
+    if (p.NRB > kMaxParts || p.CB > 65536 || p.SR > 65536 || (size_t)p.RB * 8 > 150 * 1024 ||
+        sizeof(int) * (size_t)kPbBuildWaves * p.NCB > 150 * 1024) {     // the analysis keeps one cursor per column block in LDS
         set_error("pb_build: matrix shape outside the blocked kernel's limits");
         return CUDAMAT_ERR_ARG;
     }
