@@ -251,8 +251,11 @@ def run_bench(args):
     out = None
     if rank == 0:
         out = {
-            "metric": "BiCGSTAB iterations/s (1e7-row CSR, 50 nnz/row, fp64)" if args.workload == "rand50"
-                      else "BiCGSTAB iterations/s (5-pt Poisson CSR)",
+            # BASELINE.json's metric; `value` is its first component (iterations/s), the second one
+            # (SpMV effective HBM GB/s) is `spmv_gbs` = roofline.achieved
+            "metric": "BiCGSTAB iters/sec + SpMV effective HBM GB/s, 10M-row CSR at 1/2/4/8 GPUs"
+                      if (args.workload == "rand50" and args.rows == 10_000_000 and args.per_row == 50)
+                      else "BiCGSTAB iters/sec + SpMV effective HBM GB/s (%s, %d rows)" % (args.workload, n),
             "value": its, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
