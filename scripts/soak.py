@@ -1,0 +1,60 @@
+"""soak test (not part of the suite): many random systems through every path, against the oracle"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, scipy.sparse as sp
+import cuda_mat_amd as cm
+from oracle import oracle as O
+O.set_num_threads(1)
+ctx = cm.Context(0)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+bad = 0
+for case in range(ncase):
+    n = int(rng.integers(1, 40000))
+    per = float(rng.choice([1.5, 4, 9, 30, 80]))
+    nnz_t = int(min(n * per, 3e6))
+    ri = rng.integers(0, n, nnz_t); cj = rng.integers(0, n, nnz_t)
+    S = sp.csr_matrix((rng.uniform(-1, 1, nnz_t), (ri, cj)), shape=(n, n)); S.sum_duplicates()
+    S.setdiag(0); S.eliminate_zeros()
+    S = (S + sp.diags(1.0 + rng.random(n) + np.asarray(abs(S).sum(axis=1)).ravel())).tocsr(); S.sort_indices()
+    base = int(rng.integers(0, 2))
+    A = O.Csr(n, (S.indptr + base).astype(np.int32), (S.indices + base).astype(np.int32), S.data.copy(), n)
+    x = rng.standard_normal(n); want = O.spmv(A, x)
+    msgs = []
+    for mode in ("csr", "pb", None):
+        if mode: os.environ["CUDAMAT_SPMV_MODE"] = mode
+        else: os.environ.pop("CUDAMAT_SPMV_MODE", None)
+        s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+        dx, dy = ctx.array(x), ctx.empty(n)
+        s.spmv(dx, dy); y = dy.download()
+        if mode == "pb":
+            if not np.array_equal(y, want): msgs.append("pb spmv not bit-exact")
+        else:
+            absA = O.Csr(n, A.rowptr, A.colidx, np.abs(A.val), n)
+            bound = 4 * (np.diff(A.rowptr).max() + 1) * 2.3e-16 * O.spmv(absA, np.abs(x)) + 1e-300
+            if not np.all(np.abs(y - want) <= bound): msgs.append("%s spmv out of tolerance" % mode)
+        for a in (dx, dy): a.free()
+        s.close()
+    xs = 1.0 + rng.random(n); b = O.spmv(A, xs)
+    for loop in (0, 1):
+        for precond in ((0, 1) if loop == 0 else (0,)):
+            s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+            db, dxx = ctx.array(b), ctx.array(np.ones(n))
+            try:
+                st = s.solve(db, dxx, precond=precond, loop=loop, maxit=500, tol=1e-9)
+            except cm.CudamatError as e:
+                msgs.append("solve error %s" % e); s.close(); continue
+            xg = dxx.download()
+            if loop == 0: xo, so = O.pbicgstab(A, b, vm=O.ilu0(A) if precond else None, maxit=500, tol=1e-9)
+            else: ok, xo, so = O.pbicgstab2(A, b, maxit=500, tol=1e-9)
+            if bool(st.converged) != bool(so.converged): msgs.append("loop%d pc%d converged %d vs %d" % (loop, precond, st.converged, so.converged))
+            elif st.converged:
+                if abs(st.iters - so.iters) > max(2, 0.15 * so.iters): msgs.append("loop%d pc%d iters %d vs %d" % (loop, precond, st.iters, so.iters))
+                if np.linalg.norm(xg - xo) > 1e-5 * np.linalg.norm(xo): msgs.append("loop%d pc%d x differs" % (loop, precond))
+                if np.linalg.norm(b - O.spmv(A, xg)) > 1e-7 * so.nrm0 + 1e-300: msgs.append("loop%d pc%d residual" % (loop, precond))
+            for a in (db, dxx): a.free()
+            s.close()
+    if msgs:
+        bad += 1
+        print("case %d n=%d per=%g base=%d: %s" % (case, n, per, base, "; ".join(msgs)), flush=True)
+print("soak: %d cases, %d with findings" % (ncase, bad))
