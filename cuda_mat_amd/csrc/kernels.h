@@ -5,16 +5,16 @@
 namespace cm {
 
 struct LoopArgs {
-    LoopState *st;     // NULL: kernel used outside a solve (no freeze / checks)
-    double *hist;
-    int hist_cap;
-    int loop;          // CUDAMAT_LOOP_*
-    int no_exit;
+    LoopState *st = nullptr;   // NULL: kernel used outside a solve (no freeze / checks)
+    double *hist = nullptr;
+    int hist_cap = 0;
+    int loop = 0;              // CUDAMAT_LOOP_*
+    int no_exit = 0;
     // per-iteration progress word in PINNED HOST memory: k_full publishes (k+1) << 32 | state with one
     // 8-byte system-scope store, so the host can look at a lagged state without a copy or an event
-    unsigned long long *snap;
-    int snap_slots;
-    int k;             // the host's iteration index of this launch
+    unsigned long long *snap = nullptr;
+    int snap_slots = 0;
+    int k = 0;                 // the host's iteration index of this launch
 };
 
 struct SpmvPlan {
