@@ -210,6 +210,8 @@ def run_bench(args):
         del ax
 
         run(args.warmup, flags)
+        if comm is not None:
+            comm.reset_timing(True)       # events around every collective of the timed region
         barrier()
         t0 = time.perf_counter()
         # per-launch SpMV timing = HIP events around every SpMV inside the loop; on L2-resident systems
@@ -248,6 +250,7 @@ def run_bench(args):
                 traffic = sum(g["hbm_bytes_per_launch_corrected"] for g in got)
                 traffic_src = os.path.relpath(f, ROOT)
                 break
+    comm_ms = comm.elapsed_ms() if comm is not None else None
     out = None
     if rank == 0:
         out = {
@@ -274,6 +277,10 @@ def run_bench(args):
                          "iteration_frac": (2 * b_spmv + vec_bytes) * its / 1e9 / HBM_PEAK_GBS},
             "spmv_gbs": achieved,
         }
+        if comm_ms is not None:
+            # time the rank-0 stream spent inside the collectives of the timed region (HIP events)
+            out["comm"] = {"allgather_ms_per_step": comm_ms[0] / args.steps, "allreduce_ms_per_step": comm_ms[1] / args.steps,
+                           "allgathers": comm.n_allgather, "allreduces": comm.n_allreduce, "backend": backend}
         if precond:
             out["trsv_ms_per_apply"] = ms_trsv / max(n_trsv / 2, 1)
             out["levels"] = [st.n_levels_l, st.n_levels_u]

@@ -46,6 +46,8 @@ class TorchComm:
         self.n_allgather = 0
         self.n_allreduce = 0
         self.error = None
+        self.timing = False           # bracket every collective with events on the current stream
+        self._ev = {"allgather": [], "allreduce": []}
         self._ag = ALLGATHER_FN(self._allgather)
         self._ar = ALLREDUCE_FN(self._allreduce)
         self.struct = Comm(self.rank, self.world, None, self._ag, self._ar)
@@ -66,10 +68,32 @@ class TorchComm:
     # on this device (Context(stream=torch.cuda.current_stream().cuda_stream)): the NCCL
     # backend orders its collective after the work already queued on the current stream and
     # makes the current stream wait for it; no host synchronisation happens here.
+    def _mark(self, kind, first):
+        if self.timing and self.device is not None:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            if first:
+                self._ev[kind].append([e, None])
+            else:
+                self._ev[kind][-1][1] = e
+
+    def reset_timing(self, on=True):
+        self.timing = on
+        self._ev = {"allgather": [], "allreduce": []}
+        self.n_allgather = self.n_allreduce = 0
+
+    def elapsed_ms(self):
+        """(all-gather ms, all-reduce ms) spent on the stream since reset_timing(); synchronises"""
+        if self.device is not None:
+            self.torch.cuda.synchronize(self.device)
+        return tuple(sum(a.elapsed_time(b) for a, b in self._ev[k] if b is not None) for k in ("allgather", "allreduce"))
+
     def _allgather(self, user, send, recv, count):
         try:
+            self._mark("allgather", True)
             self.dist.all_gather_into_tensor(self._view(recv, count * self.world), self._view(send, count),
                                              group=self.group)
+            self._mark("allgather", False)
             self.n_allgather += 1
             return 0
         except Exception as e:  # noqa: BLE001 - must not unwind through the C frame
@@ -78,7 +102,9 @@ class TorchComm:
 
     def _allreduce(self, user, buf, count):
         try:
+            self._mark("allreduce", True)
             self.dist.all_reduce(self._view(buf, count), op=self.dist.ReduceOp.SUM, group=self.group)
+            self._mark("allreduce", False)
             self.n_allreduce += 1
             return 0
         except Exception as e:  # noqa: BLE001
