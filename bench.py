@@ -275,7 +275,7 @@ def run_bench(args):
                          "launches_timed": n_spmv,
                          "iteration_bytes": 2 * b_spmv + vec_bytes,
                          "iteration_frac": (2 * b_spmv + vec_bytes) * its / 1e9 / HBM_PEAK_GBS},
-            "spmv_gbs": achieved,
+            "spmv_gbs": achieved, "spmv_form": "blocked two-phase" if blocked else "csr (lanes-per-row / stream tiles)",
         }
         if comm_ms is not None:
             # time the rank-0 stream spent inside the collectives of the timed region (HIP events)
