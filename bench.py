@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--precond", default="none", choices=["none", "ilu0"])
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--cpu-iters", type=int, default=25)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     return ap.parse_args()
 
