@@ -532,7 +532,10 @@ int ilu0_setup(cudamat_solver *s)
         }
         // ---- analysis (pbicgstab.cu:336-347)
         if ((rc = build_levels(s, false, d_lev, d_flags, s->L, pl->L, h_rp, h_diag))) break;
+        s->t_analysis_l = now_s() - t0;
+        const double tu = now_s();
         if ((rc = build_levels(s, true, d_lev, d_flags, s->U, pl->U, h_rp, h_diag))) break;
+        s->t_analysis_u = now_s() - tu;
         s->t_analysis = now_s() - t0;
         // ---- factorisation on a copy of A's values (pbicgstab.cu:316, :356-363)
         const double t1 = now_s();

@@ -68,7 +68,7 @@ struct cudamat_solver {
     int *diag_pos = nullptr;   // position of the diagonal in each row
     cm::TriFactor L, U;
     void *ilu_plans = nullptr;  // launch plans owned by ilu.hip
-    double t_analysis = 0.0, t_factor = 0.0;
+    double t_analysis = 0.0, t_factor = 0.0, t_analysis_l = 0.0, t_analysis_u = 0.0;
 };
 
 namespace cm {

@@ -580,8 +580,8 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
         if (precond == CUDAMAT_PRECOND_ILU0) {
             if ((rc = cudamat_solver_ilu0(s))) break;
             if (debug) {
-                printf("analysis lower+upper %f (s) \n", s->t_analysis);                  // :349
-                printf("ILU(0) (HIP, level-scheduled) time(s) = %10.8f \n", s->t_factor);  // :355,363
+                printf("analysis lower %f (s), upper %f (s) \n", s->t_analysis_l, s->t_analysis_u);     // :349
+                printf("csrilu0 (HIP, level-scheduled) time(s) = %10.8f \n", s->t_factor);            // :355,363
             }
         }
         int flags = (debug ? CUDAMAT_FLAG_DEBUG : 0) | (x0 ? 0 : CUDAMAT_FLAG_X0_ONES);
