@@ -132,7 +132,10 @@ def run_bench(args):
         nx = args.nx
         ny = n // nx
         n = nx * ny
-    row0, row1, per = shard_rows(n, world, rank)
+    # The ILU(0) path does not shard (dependencies cross row blocks; block-Jacobi would be different maths,
+    # DESIGN.md section 7): with --precond ilu0 on N > 1 GPUs every rank solves the WHOLE system = N replicas.
+    replicas = world > 1 and args.precond == "ilu0"
+    row0, row1, per = (0, n, n) if replicas else shard_rows(n, world, rank)
     nloc = row1 - row0
 
     stream = torch.cuda.Stream(device=dev)
@@ -157,7 +160,7 @@ def run_bench(args):
         del rp, ci, va
         torch.cuda.empty_cache()
         comm = None
-        if use_dist:
+        if use_dist and not replicas:
             comm = TorchComm(device=dev)
             solver.set_comm(comm.struct)
         xs = torch.empty(nloc, dtype=torch.float64, device=dev)
@@ -197,7 +200,7 @@ def run_bench(args):
         ax = torch.empty(nloc, dtype=torch.float64, device=dev)
         solver.spmv(x, ax)
         res2 = ((b - ax) ** 2).sum()
-        if use_dist:
+        if use_dist and not replicas:
             dist.all_reduce(res2)
         true_res = float(res2.sqrt().item())
         assert abs(true_res - st.nrm) <= 1e-6 * st.nrm0 + 1e-3 * st.nrm, \
@@ -226,7 +229,7 @@ def run_bench(args):
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
 
-    its = args.steps / dt
+    its = args.steps / dt * (world if replicas else 1)      # replicas: N independent solves in the same time
     spmv_ms = ms_spmv / max(n_spmv, 1)
     # algorithmic bytes of one local SpMV launch: values+colidx, rowptr, x once, y once
     b_spmv = 12.0 * nnz + 4.0 * (nloc + 1) + 8.0 * n + 8.0 * nloc
@@ -260,13 +263,14 @@ def run_bench(args):
                       if (args.workload == "rand50" and args.rows == 10_000_000 and args.per_row == 50)
                       else "BiCGSTAB iters/sec + SpMV effective HBM GB/s (%s, %d rows)" % (args.workload, n),
             "value": its, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if replicas else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s n=%d nnz=%d%s, x0=1, b=A*xstar, %s, row-sharded x%d"
                                    % (args.workload, n, nnz * world if args.workload == "rand50" else nnz,
                                       "/rank" if (world > 1 and args.workload != "rand50") else "",
                                       "ILU(0)" if precond else "no preconditioner", world),
-                       "rows": n, "nnz_per_rank": nnz, "parallelism": "rows/%d" % world,
+                       "rows": n, "nnz_per_rank": nnz,
+                       "parallelism": ("replicas x%d (preconditioned path does not shard)" % world) if replicas else "rows/%d" % world,
                        "converges_in_iters": conv_iters},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
