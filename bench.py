@@ -265,10 +265,11 @@ def run_bench(args):
             "value": its, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if replicas else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s n=%d nnz=%d%s, x0=1, b=A*xstar, %s, row-sharded x%d"
-                                   % (args.workload, n, nnz * world if args.workload == "rand50" else nnz,
+            "config": {"workload": "%s n=%d nnz=%d%s, x0=1, b=A*xstar, %s, %s x%d"
+                                   % (args.workload, n, nnz * world if (args.workload == "rand50" and not replicas) else nnz,
                                       "/rank" if (world > 1 and args.workload != "rand50") else "",
-                                      "ILU(0)" if precond else "no preconditioner", world),
+                                      "ILU(0)" if precond else "no preconditioner",
+                                      "independent replicas" if replicas else "row-sharded", world),
                        "rows": n, "nnz_per_rank": nnz,
                        "parallelism": ("replicas x%d (preconditioned path does not shard)" % world) if replicas else "rows/%d" % world,
                        "converges_in_iters": conv_iters},
@@ -278,7 +279,7 @@ def run_bench(args):
                          "algorithmic_bytes_per_launch": b_spmv, "avg_launch_ms": spmv_ms,
                          "launches_timed": n_spmv,
                          "iteration_bytes": 2 * b_spmv + vec_bytes,
-                         "iteration_frac": (2 * b_spmv + vec_bytes) * its / 1e9 / HBM_PEAK_GBS},
+                         "iteration_frac": (2 * b_spmv + vec_bytes) * (args.steps / dt) / 1e9 / HBM_PEAK_GBS},
             "spmv_gbs": achieved, "spmv_form": "blocked two-phase" if blocked else "csr (lanes-per-row / stream tiles)",
         }
         if comm_ms is not None:
