@@ -289,6 +289,8 @@ def run_bench(args):
         if precond:
             out["trsv_ms_per_apply"] = ms_trsv / max(n_trsv / 2, 1)
             out["levels"] = [st.n_levels_l, st.n_levels_u]
+            # one-off setup (outside the timed region): level analysis of L and U; ILU(0) + factor layout + far/near split
+            out["setup_s"] = {"analysis": st.t_analysis, "factor": st.t_factor}
         if world == 1 and args.cpu_baseline != "off":
             out["cpu_baseline"] = cpu_baseline(args)
     solver.close()

@@ -31,6 +31,18 @@ static double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+static bool verbose() { static const bool v = getenv("CUDAMAT_VERBOSE") != nullptr; return v; }
+#define CM_STAMP(label)                                                                       \
+    do {                                                                                      \
+        if (verbose()) {                                                                      \
+            hipStreamSynchronize(st);                                                         \
+            const double t_now = now_s();                                                     \
+            fprintf(stderr, "[cudamat] ilu0 %-28s %8.3f ms\n", label, (t_now - t_stamp) * 1e3); \
+            t_stamp = t_now;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+
 template <typename T>
 static int dalloc(T **p, size_t count)
 {
@@ -88,6 +100,57 @@ __global__ __launch_bounds__(kBlock) void k_level_sweep(int n, const int *rp, co
     if (lane == 0 && m != lev[i]) {
         __hip_atomic_store(&lev[i], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flags[0] = 1;
+    }
+}
+
+// The same fixed point in ONE pass: rows are visited in dependency order (ascending for the lower part,
+// descending for the upper part), a row waits until the levels of its dependencies have been published
+// (lev preset to -1; 4-byte write-through stores, polled with sc1 loads) and publishes its own.  Workgroups
+// are dispatched in index order, so the first unfinished row never waits for a row that has not started;
+// spins are bounded and a timeout (err) sends the caller back to the relaxation sweeps.
+__global__ __launch_bounds__(kBlock) void k_levels_dep(int n, const int *rp, const int *ci, const int *diag_pos,
+                                                       int upper, int *lev, int *err)
+{
+    constexpr int L = 8;
+    const int lane = threadIdx.x & (L - 1);
+    const int team_shift = (threadIdx.x & 63) & ~(L - 1);
+    const long long t = ((long long)blockIdx.x * kBlock + threadIdx.x) / L;
+    const bool valid = t < n;
+    const int i = valid ? (upper ? n - 1 - (int)t : (int)t) : 0;
+    int k = 0, e = 0;
+    if (valid) {
+        k = (upper ? diag_pos[i] + 1 : rp[i]) + lane;
+        e = upper ? rp[i + 1] : diag_pos[i];
+    }
+    bool have = k < e;
+    int c = have ? ci[k] : 0;
+    int m = 0, spins = 0;
+    bool done = !valid;
+    for (;;) {
+        if (have) {
+            const int l = __hip_atomic_load(&lev[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l >= 0 || ++spins > (1 << 21)) {
+                if (l < 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                m = l + 1 > m ? l + 1 : m;
+                spins = 0;
+                k += L;
+                have = k < e;
+                if (have) c = ci[k];
+            }
+        }
+        const unsigned long long pending = __ballot(have);
+        if (!done && ((pending >> team_shift) & 0xFFull) == 0) {
+            int mm = m;
+#pragma unroll
+            for (int o = L / 2; o > 0; o >>= 1) {
+                const int q = __shfl_xor(mm, o, 64);
+                mm = q > mm ? q : mm;
+            }
+            if (lane == 0) __hip_atomic_store(&lev[i], mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            done = true;
+        }
+        if (__ballot(!done) == 0) break;
+        if (pending) __builtin_amdgcn_s_sleep(2);
     }
 }
 
@@ -212,6 +275,98 @@ __global__ __launch_bounds__(kBlock) void k_trsv_small_levels(int l0, int l1, co
     }
 }
 
+// ---- dependency-driven ("sync-free") solve of a whole group of levels in ONE launch
+// Rows are stored level-major, so every dependency of permuted row pr sits at a smaller pr: workgroups are
+// dispatched in index order and a waiting row only ever waits for rows of earlier (already dispatched)
+// workgroups or of its own wave, so the lowest unfinished row can always finish.  Readiness travels with
+// the data: `out` is pre-filled with a SIGNALLING-NaN bit pattern that no arithmetic result can have (every
+// operation quiets a signalling NaN), a producer publishes its value with one 8-byte write-through (sc1)
+// store and consumers poll the value itself with 8-byte sc1 loads -- no flags, no fences (one naturally
+// aligned 8-byte granule written by one store).  Each row is still summed by its own LANES lanes in the
+// level kernel's order, so the result is bit-identical to the level-by-level solve.
+// Every spin is bounded: a lane that gives up sets *err (pinned host word) and proceeds with what it read.
+constexpr unsigned long long kNotReady = 0x7FF4C0DEC0DEC0DEull;
+constexpr int kSpinLimit = 1 << 21;
+
+__global__ __launch_bounds__(kBlock) void k_fill_not_ready(long long n, unsigned long long *out)
+{
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+        out[i] = kNotReady;
+}
+
+template <int LANES>
+__global__ __launch_bounds__(kBlock) void k_trsv_syncfree(int r0, int r1, const int *frp, const int *fci,
+                                                          const double *fval, const int *row_of,
+                                                          const double *dinv, const double *far,
+                                                          const double *rhs, double *out, int *err)
+{
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    constexpr int RPB = kBlock / LANES;
+    const int lane = threadIdx.x & (LANES - 1);
+    const int team_shift = (threadIdx.x & 63) & ~(LANES - 1);
+    constexpr unsigned long long team_bits = LANES == 64 ? ~0ull : ((1ull << LANES) - 1ull);
+    const long long prl = (long long)r0 + (long long)blockIdx.x * RPB + threadIdx.x / LANES;
+    const bool valid = prl < r1;
+    const int pr = valid ? (int)prl : r0;
+    int k = 0, e = 0;
+    if (valid) {
+        k = frp[pr] + lane;
+        e = frp[pr + 1];
+    }
+    bool have = k < e;
+    int c = 0;
+    double a = 0.0;
+    if (have) {
+        c = fci[k];
+        a = fval[k];
+    }
+    // everything the row's last step needs is fetched up front: only the polled values are on the chain
+    int r = 0;
+    double base = 0.0, fr = 0.0, di = 1.0;
+    if (valid && lane == 0) {
+        r = row_of[pr];
+        base = rhs[r];
+        if (far) fr = far[pr];
+        if (dinv) di = dinv[pr];
+    }
+    double sum = 0.0;
+    bool done = !valid;
+    int spins = 0;
+    for (;;) {
+        if (have) {
+            const unsigned long long bits = __hip_atomic_load((gu64 *)(out + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ready = bits != kNotReady;
+            if (ready || ++spins > kSpinLimit) {
+                if (!ready) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                sum += a * __longlong_as_double((long long)bits);
+                spins = 0;
+                k += LANES;
+                have = k < e;
+                if (have) {
+                    c = fci[k];
+                    a = fval[k];
+                }
+            }
+        }
+        const unsigned long long pending = __ballot(have);
+        if (!done && ((pending >> team_shift) & team_bits) == 0) {      // uniform over the row's lanes
+            double tot = sum;
+#pragma unroll
+            for (int o = LANES / 2; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            if (lane == 0) {
+                double v = base - tot;
+                if (far) v -= fr;
+                if (dinv) v *= di;
+                __hip_atomic_store((gu64 *)(out + r), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            done = true;
+        }
+        if (__ballot(!done) == 0) break;
+        if (pending) __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 static int pick_lanes(double mean)
 {
     if (mean <= 3.0) return 2;
@@ -235,6 +390,7 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
     std::vector<PbPlan> far;               // far[g]: rows of group g x columns of groups < g
     double *far_buf = nullptr;             // n doubles in level-major row order: far_g . out
     std::vector<int> lev_host;             // level of every original row (kept until the split)
+    bool syncfree = false;                 // one dependency-driven launch per group instead of one launch per level
 };
 
 }  // namespace cm
@@ -242,6 +398,7 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
 // the launch plans hang off the solver as an opaque pointer (keeps solver.h light)
 struct IluPlans {
     cm::TriHost L, U;
+    int *err_host = nullptr, *err_dev = nullptr;   // pinned word a timed-out spin of k_trsv_syncfree sets
 };
 
 static IluPlans *plans_of(cudamat_solver *s, bool create)
@@ -276,6 +433,7 @@ int ilu0_release(cudamat_solver *s)
             for (PbPlan &fp : h->far) pb_free(&fp);
             if (h->far_buf) hipFree(h->far_buf);
         }
+        if (pl->err_host) hipHostFree(pl->err_host);
         delete pl;
         s->ilu_plans = nullptr;
     }
@@ -284,15 +442,29 @@ int ilu0_release(cudamat_solver *s)
 
 // levels -> level-major permutation (stable: rows of a level stay in increasing order)
 static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags, TriFactor &F, TriHost &H,
-                        std::vector<int> &h_rp, std::vector<int> &h_diag)
+                        std::vector<int> &h_rp, std::vector<int> &h_diag, int *err_host, int *err_dev)
 {
     hipStream_t st = s->ctx->stream;
     const int n = s->n;
-    CM_HIP(hipMemsetAsync(d_lev, 0, sizeof(int) * (size_t)(n ? n : 1), st));
+    double t_stamp = now_s();
     const long long threads = (long long)n * 8;
     const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
+    // one dependency-driven pass; the relaxation sweeps below remain as the fallback (CUDAMAT_LEVELS_SWEEP=1
+    // or a timed-out wait)
+    bool have_levels = false;
+    const char *force_sweep = getenv("CUDAMAT_LEVELS_SWEEP");
+    if (n > 0 && err_host && !(force_sweep && force_sweep[0] == '1')) {
+        CM_HIP(hipMemsetAsync(d_lev, 0xFF, sizeof(int) * (size_t)n, st));
+        hipLaunchKernelGGL(k_levels_dep, dim3(grid), dim3(kBlock), 0, st, n, s->rp, s->ci, s->diag_pos, upper ? 1 : 0,
+                           d_lev, err_dev);
+        CM_HIP(hipGetLastError());
+        CM_HIP(hipStreamSynchronize(st));
+        have_levels = *err_host == 0;
+        *err_host = 0;
+    }
+    if (!have_levels) CM_HIP(hipMemsetAsync(d_lev, 0, sizeof(int) * (size_t)(n ? n : 1), st));
     int sweeps = 0;
-    while (n > 0) {
+    while (n > 0 && !have_levels) {
         CM_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_level_sweep, dim3(grid ? grid : 1), dim3(kBlock), 0, st, n, s->rp, s->ci,
                            s->diag_pos, upper ? 1 : 0, d_lev, d_flags);
@@ -304,6 +476,7 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
         if (!changed) break;
         if (sweeps > n + 1) { set_error("level analysis did not converge"); return CUDAMAT_ERR_HIP; }
     }
+    CM_STAMP(upper ? "U levels (device)" : "L levels (device)");
     std::vector<int> lev((size_t)n);
     if (n) CM_HIP(hipMemcpy(lev.data(), d_lev, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     int nlev = 0;
@@ -322,6 +495,7 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
         frp[(size_t)pr + 1] = frp[(size_t)pr] + cnt;
     }
     F.nnz = n ? frp[(size_t)n] : 0;
+    CM_STAMP("level sort (host)");
     CM_TRY(dalloc(&F.rp, (size_t)n + 1));
     CM_TRY(dalloc(&F.ci, (size_t)F.nnz));
     CM_TRY(dalloc(&F.val, (size_t)F.nnz));
@@ -331,6 +505,7 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
     if (n) CM_HIP(hipMemcpy(F.row_of, row_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     CM_TRY(dalloc(&H.level_ptr_dev, (size_t)nlev + 1));
     CM_HIP(hipMemcpy(H.level_ptr_dev, F.level_ptr.data(), sizeof(int) * ((size_t)nlev + 1), hipMemcpyHostToDevice));
+    CM_STAMP("factor arrays alloc + upload");
     H.lanes = pick_lanes(n ? (double)F.nnz / n : 1.0);
     if (const char *e = getenv("CUDAMAT_TRSV_LANES")) {
         const int v = atoi(e);
@@ -412,6 +587,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H)
     hipStream_t st = s->ctx->stream;
     const int n = s->n;
     const int K = (int)H.grp_level.size() - 1;
+    double t_stamp = now_s();
     // group of every original row
     std::vector<unsigned char> hg((size_t)n);
     {
@@ -440,6 +616,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H)
             hf[(size_t)i + 1] = hf[(size_t)i] + cf[(size_t)i];
         }
         const int64_t nnz_near = hn[(size_t)n], nnz_far = hf[(size_t)n];
+        CM_STAMP("split count + host scan");
         if ((rc = dalloc(&nrp, (size_t)n + 1))) break;
         if ((rc = dalloc(&qrp, (size_t)n + 1))) break;
         if ((rc = dalloc(&nci, (size_t)nnz_near))) break;
@@ -451,6 +628,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H)
         hipLaunchKernelGGL(k_split_fill, dim3(grid), dim3(kBlock), 0, st, n, F.rp, F.ci, F.val, F.row_of, d_grp, nrp, nci,
                            nval, qrp, qci, qval);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("factor split failed"); break; }
+        CM_STAMP("split fill");
         // one blocked SpMV plan per group: rows of the group (level-major, contiguous) x all columns
         H.far.assign((size_t)K, PbPlan());
         for (int g = 1; g < K && !rc; g++) {
@@ -459,6 +637,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H)
             if (r1 <= r0 || cnt <= 0) continue;
             rc = pb_build(st, r1 - r0, s->n_cols, cnt, qrp + r0, qci, qval, &H.far[(size_t)g]);
         }
+        CM_STAMP("far plans (pb_build)");
         if (rc) break;
         if ((rc = dalloc(&H.far_buf, (size_t)n))) break;
         if (hipMemsetAsync(H.far_buf, 0, sizeof(double) * (size_t)n, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
@@ -507,9 +686,15 @@ int ilu0_setup(cudamat_solver *s)
     int *d_flags = nullptr, *d_lev = nullptr;
     int rc = CUDAMAT_OK;
     const double t0 = now_s();
+    double t_stamp = t0;
     do {
         if ((rc = dalloc(&d_flags, 2))) break;
         if ((rc = dalloc(&d_lev, (size_t)n))) break;
+        if (hipHostMalloc((void **)&pl->err_host, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&pl->err_dev, pl->err_host, 0) != hipSuccess) {
+            rc = CUDAMAT_ERR_HIP; set_error("pinned status word allocation failed"); break;
+        }
+        *pl->err_host = 0;
         if ((rc = dalloc(&s->diag_pos, (size_t)n))) break;
         if ((rc = dalloc(&s->lu, (size_t)s->nnz))) break;
         if (hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
@@ -530,15 +715,17 @@ int ilu0_setup(cudamat_solver *s)
             (n && hipMemcpy(h_diag.data(), s->diag_pos, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)) {
             rc = CUDAMAT_ERR_HIP; set_error("D2H of the pattern failed"); break;
         }
+        CM_STAMP("find diag + pattern D2H");
         // ---- analysis (pbicgstab.cu:336-347)
-        if ((rc = build_levels(s, false, d_lev, d_flags, s->L, pl->L, h_rp, h_diag))) break;
+        if ((rc = build_levels(s, false, d_lev, d_flags, s->L, pl->L, h_rp, h_diag, pl->err_host, pl->err_dev))) break;
         s->t_analysis_l = now_s() - t0;
         const double tu = now_s();
-        if ((rc = build_levels(s, true, d_lev, d_flags, s->U, pl->U, h_rp, h_diag))) break;
+        if ((rc = build_levels(s, true, d_lev, d_flags, s->U, pl->U, h_rp, h_diag, pl->err_host, pl->err_dev))) break;
         s->t_analysis_u = now_s() - tu;
         s->t_analysis = now_s() - t0;
         // ---- factorisation on a copy of A's values (pbicgstab.cu:316, :356-363)
         const double t1 = now_s();
+        t_stamp = t1;
         if (hipMemcpyAsync(s->lu, s->val, sizeof(double) * (size_t)s->nnz, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             rc = CUDAMAT_ERR_HIP; set_error("copy of A values failed"); break;
         }
@@ -573,12 +760,22 @@ int ilu0_setup(cudamat_solver *s)
             rc = CUDAMAT_ERR_ZERO_PIVOT;
             break;
         }
+        CM_STAMP("numeric ILU(0)");
         if ((rc = fill_factor(s, false, s->L))) break;
         if ((rc = fill_factor(s, true, s->U))) break;
         if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("factor fill failed"); break; }
+        CM_STAMP("factor fill");
         if ((rc = split_factor(s, s->L, pl->L))) break;
         if ((rc = split_factor(s, s->U, pl->U))) break;
         s->t_factor = now_s() - t1;
+        // solve form: one dependency-driven launch per group (default whenever there is more than one level
+        // to chain), or one launch per level / run of small levels (CUDAMAT_TRSV_SYNCFREE=0)
+        {
+            const char *sf = getenv("CUDAMAT_TRSV_SYNCFREE");
+            const bool on = sf ? sf[0] == '1' : true;
+            pl->L.syncfree = on && s->L.nlevels > 1;
+            pl->U.syncfree = on && s->U.nlevels > 1;
+        }
         s->has_ilu = true;
     } while (0);
     if (d_flags) hipFree(d_flags);
@@ -592,6 +789,23 @@ int ilu0_setup(cudamat_solver *s)
     return rc;
 }
 
+// the far SpMV of one group: far_buf[rows of the group] = far_g . out
+static int launch_far(hipStream_t st, const TriFactor &F, const TriHost &H, int grp, const double *out)
+{
+    const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)grp]];
+    SpmvArgs a{};
+    a.n = H.far[(size_t)grp].n;
+    a.x = out;
+    a.alpha = 1.0;
+    a.beta = 0.0;
+    a.y = H.far_buf + r0;
+    a.dot = 0;
+    a.loop = LoopArgs{nullptr, nullptr, 0, 0, 0};
+    a.check = CHECK_NONE;
+    a.half = ScalarSrc{nullptr, 0, 1};
+    return launch_spmv_pb(st, H.far[(size_t)grp], a);
+}
+
 template <int LANES>
 static int launch_trsv_segments(hipStream_t st, const TriFactor &F, const TriHost &H, const double *rhs, double *out)
 {
@@ -601,20 +815,7 @@ static int launch_trsv_segments(hipStream_t st, const TriFactor &F, const TriHos
         const int grp = H.seg_group.empty() ? 0 : H.seg_group[g];
         const double *far = nullptr;
         if (H.hybrid && grp > 0 && H.far[(size_t)grp].nnz > 0) {
-            if (grp != cur_group) {   // far_g . out for the rows of this group: one blocked SpMV
-                const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)grp]];
-                SpmvArgs a{};
-                a.n = H.far[(size_t)grp].n;
-                a.x = out;
-                a.alpha = 1.0;
-                a.beta = 0.0;
-                a.y = H.far_buf + r0;
-                a.dot = 0;
-                a.loop = LoopArgs{nullptr, nullptr, 0, 0, 0};
-                a.check = CHECK_NONE;
-                a.half = ScalarSrc{nullptr, 0, 1};
-                CM_TRY(launch_spmv_pb(st, H.far[(size_t)grp], a));
-            }
+            if (grp != cur_group) CM_TRY(launch_far(st, F, H, grp, out));   // one blocked SpMV per group
             far = H.far_buf;
         }
         cur_group = grp;
@@ -634,6 +835,42 @@ static int launch_trsv_segments(hipStream_t st, const TriFactor &F, const TriHos
     return CUDAMAT_OK;
 }
 
+template <int LANES>
+static int launch_trsv_syncfree(hipStream_t st, const TriFactor &F, const TriHost &H, int n, const double *rhs,
+                                double *out, int *err)
+{
+    constexpr int RPB = kBlock / LANES;
+    int fill_grid = (int)(((long long)n + kBlock - 1) / kBlock);
+    if (fill_grid > kVecGridMax) fill_grid = kVecGridMax;
+    hipLaunchKernelGGL(k_fill_not_ready, dim3(fill_grid ? fill_grid : 1), dim3(kBlock), 0, st, (long long)n,
+                       (unsigned long long *)out);
+    const int K = (int)H.grp_level.size() - 1;
+    for (int g = 0; g < K; g++) {
+        const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)g]], r1 = F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]];
+        if (r1 <= r0) continue;
+        const double *far = nullptr;
+        if (H.hybrid && g > 0 && H.far[(size_t)g].nnz > 0) {
+            CM_TRY(launch_far(st, F, H, g, out));
+            far = H.far_buf;
+        }
+        const unsigned grid = (unsigned)(((long long)(r1 - r0) + RPB - 1) / RPB);
+        hipLaunchKernelGGL(k_trsv_syncfree<LANES>, dim3(grid), dim3(kBlock), 0, st, r0, r1, F.rp, F.ci, F.val, F.row_of,
+                           F.dinv, far, rhs, out, err);
+    }
+    return CUDAMAT_OK;
+}
+
+int trsv_status(cudamat_solver *s)
+{
+    IluPlans *pl = plans_of(s, false);
+    if (pl && pl->err_host && *pl->err_host) {
+        *pl->err_host = 0;
+        set_error("triangular solve: a dependency never became ready (spin limit reached)");
+        return CUDAMAT_ERR_HIP;
+    }
+    return CUDAMAT_OK;
+}
+
 int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *rhs, double *out)
 {
     IluPlans *pl = plans_of(s, false);
@@ -641,6 +878,20 @@ int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *
     const TriHost &H = upper ? pl->U : pl->L;
     hipStream_t st = s->ctx->stream;
     int rc;
+    if (H.syncfree) {
+        if (rhs == out) { set_error("triangular solve: rhs and out must not alias"); return CUDAMAT_ERR_ARG; }
+        switch (H.lanes) {
+        case 2:  rc = launch_trsv_syncfree<2>(st, F, H, s->n, rhs, out, pl->err_dev); break;
+        case 4:  rc = launch_trsv_syncfree<4>(st, F, H, s->n, rhs, out, pl->err_dev); break;
+        case 8:  rc = launch_trsv_syncfree<8>(st, F, H, s->n, rhs, out, pl->err_dev); break;
+        case 16: rc = launch_trsv_syncfree<16>(st, F, H, s->n, rhs, out, pl->err_dev); break;
+        case 32: rc = launch_trsv_syncfree<32>(st, F, H, s->n, rhs, out, pl->err_dev); break;
+        default: rc = launch_trsv_syncfree<64>(st, F, H, s->n, rhs, out, pl->err_dev); break;
+        }
+        CM_TRY(rc);
+        CM_HIP(hipGetLastError());
+        return CUDAMAT_OK;
+    }
     switch (H.lanes) {
     case 2:  rc = launch_trsv_segments<2>(st, F, H, rhs, out); break;
     case 4:  rc = launch_trsv_segments<4>(st, F, H, rhs, out); break;

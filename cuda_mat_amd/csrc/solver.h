@@ -75,4 +75,5 @@ namespace cm {
 int ilu0_setup(cudamat_solver *s);
 int ilu0_release(cudamat_solver *s);
 int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *rhs, double *out);
+int trsv_status(cudamat_solver *s);   // after a stream sync: did a dependency-driven solve give up waiting?
 }  // namespace cm

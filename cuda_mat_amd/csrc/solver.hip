@@ -471,6 +471,7 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
     CM_HIP(hipMemcpyAsync(&s->st_ring[0], s->st, sizeof(LoopState), hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));                              // :372
     const double t_loop1 = now_s();
+    if (precond) CM_TRY(trsv_status(s));
     const LoopState fin = s->st_ring[0];
     s->hist_count = (loop == CUDAMAT_LOOP_PBICGSTAB) ? 2 * fin.it + (fin.state == 1 ? 1 : 0) : fin.it;
     if (s->hist_count > s->hist_cap) s->hist_count = s->hist_cap;

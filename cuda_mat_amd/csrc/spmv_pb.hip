@@ -127,6 +127,87 @@ __global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_rows(int n, const int
         for (int c = lane; c < NCB; c += 64) bins[(size_t)c * NSUB + sub] = cur[c];
 }
 
+// ---- exclusive scan of the segment counts in storage order [column block][sub-block], on the device
+// k_pb_colsum: entries per column block; k_pb_colscan (one workgroup): their exclusive scan -> cstart;
+// k_pb_segscan (one workgroup per column block): running offsets of its NSUB segments -> bins (fill
+// cursors) and the sub-block-major copies phase 2 reads (sstart/slen [sub][cb]).
+__global__ __launch_bounds__(kBlock) void k_pb_colsum(int NSUB, const int *bins, int *colsum)
+{
+    __shared__ int red[kBlock / 64];
+    const int *b = bins + (size_t)blockIdx.x * NSUB;
+    int acc = 0;
+    for (int i = threadIdx.x; i < NSUB; i += kBlock) acc += b[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kBlock / 64; w++) t += red[w];
+        colsum[blockIdx.x] = t;
+    }
+}
+
+// inclusive scan of one value per thread over the workgroup; returns the exclusive prefix, *total = sum
+__device__ __forceinline__ int block_exclusive_scan(int v, int *lds_waves, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();                       // lds_waves may still be read from the previous round
+    if (lane == 63) lds_waves[wave] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+    for (int w = 0; w < kBlock / 64; w++) {
+        const int t = lds_waves[w];
+        if (w < wave) before += t;
+        all += t;
+    }
+    *total = all;
+    return before + inc - v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pb_colscan(int NCB, const int *colsum, int *cstart)
+{
+    __shared__ int lds_waves[kBlock / 64];
+    int run = 0;
+    for (int c0 = 0; c0 < NCB; c0 += kBlock) {
+        const int c = c0 + threadIdx.x;
+        const int v = c < NCB ? colsum[c] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, lds_waves, &total);
+        if (c < NCB) cstart[c] = run + ex;
+        run += total;
+    }
+    if (threadIdx.x == 0) cstart[NCB] = run;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pb_segscan(int NCB, int NSUB, const int *cstart, int *bins, int *sstart,
+                                                       int *slen)
+{
+    __shared__ int lds_waves[kBlock / 64];
+    const int c = blockIdx.x;
+    int *b = bins + (size_t)c * NSUB;
+    int run = cstart[c];
+    for (int s0 = 0; s0 < NSUB; s0 += kBlock) {
+        const int sidx = s0 + threadIdx.x;
+        const int cnt = sidx < NSUB ? b[sidx] : 0;
+        int total;
+        const int ex = block_exclusive_scan(cnt, lds_waves, &total);
+        if (sidx < NSUB) {
+            const int start = run + ex;
+            b[sidx] = start;
+            sstart[(size_t)sidx * NCB + c] = start;
+            slen[(size_t)sidx * NCB + c] = cnt;
+        }
+        run += total;
+    }
+}
+
 static int round_blocks(int64_t n, int tile_max)
 {
     // number of blocks: a multiple of the CU count (whole rounds of workgroups) with tiles <= tile_max
@@ -192,30 +273,14 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
         hipLaunchKernelGGL(k_pb_rows<false>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, p.CB,
                            p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr);
         if (hipGetLastError() != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb count launch failed"); break; }
-        std::vector<int> h(nbins), hs(nbins), hl(nbins), hc((size_t)p.NCB + 1);
-        if (hipMemcpyAsync(h.data(), bins, sizeof(int) * nbins, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb count failed"); break; }
-        // exclusive scan in storage order [cb][sub]; wave-major copies [sub][cb] for phase 2
-        int64_t run = 0;
-        for (int c = 0; c < p.NCB; c++) {
-            hc[(size_t)c] = (int)run;
-            for (int s = 0; s < p.NSUB; s++) {
-                const size_t i = (size_t)c * p.NSUB + s;
-                const int cnt = h[i];
-                h[i] = (int)run;
-                hs[(size_t)s * p.NCB + c] = (int)run;
-                hl[(size_t)s * p.NCB + c] = cnt;
-                run += cnt;
-            }
-        }
-        hc[(size_t)p.NCB] = (int)run;
-        if (run != nnz) { rc = CUDAMAT_ERR_ARG; set_error("pb_build: counted %lld entries, expected %lld", (long long)run, (long long)nnz); break; }
-        if (hipMemcpyAsync(bins, h.data(), sizeof(int) * nbins, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(p.sstart, hs.data(), sizeof(int) * nbins, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(p.slen, hl.data(), sizeof(int) * nbins, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(p.cstart, hc.data(), sizeof(int) * ((size_t)p.NCB + 1), hipMemcpyHostToDevice, st) != hipSuccess) {
-            rc = CUDAMAT_ERR_HIP; set_error("pb table upload failed"); break;
-        }
+        hipLaunchKernelGGL(k_pb_colsum, dim3(p.NCB), dim3(kBlock), 0, st, p.NSUB, bins, p.cstart);   // cstart doubles as scratch
+        hipLaunchKernelGGL(k_pb_colscan, dim3(1), dim3(kBlock), 0, st, p.NCB, p.cstart, p.cstart);
+        hipLaunchKernelGGL(k_pb_segscan, dim3(p.NCB), dim3(kBlock), 0, st, p.NCB, p.NSUB, p.cstart, bins, p.sstart, p.slen);
+        int counted = -1;
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(&counted, p.cstart + p.NCB, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb scan failed"); break; }
+        if ((int64_t)counted != nnz) { rc = CUDAMAT_ERR_ARG; set_error("pb_build: counted %d entries, expected %lld", counted, (long long)nnz); break; }
         hipLaunchKernelGGL(k_pb_rows<true>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, p.CB,
                            p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {

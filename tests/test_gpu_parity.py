@@ -588,6 +588,62 @@ def test_hybrid_triangular_solve_vs_oracle(cm, ctx, oracle, golden_dir, name, mo
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5
 
 
+def _chain_matrix(oracle, n, width, seed):
+    """banded lower+upper coupling: row i depends on rows i-1 .. i-width -> n levels of one row each"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    diags = [rng.integers(1, 4, n - k).astype(np.float64) * 0.25 for k in range(1, width + 1)]
+    S = sp.diags(diags, [-k for k in range(1, width + 1)]) + sp.diags(diags, list(range(1, width + 1)))
+    S = (S + sp.diags(np.full(n, 2.0 * width + 1.0))).tocsr()
+    S.sort_indices()
+    return oracle.Csr(n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy(), n)
+
+
+@pytest.mark.parametrize("name", ["chain3000", "poisson160x90", "rand20000x50", "rand20000x50_hybrid", "longrows",
+                                  "mat10000"])
+def test_dependency_driven_trsv_equals_level_solve(cm, ctx, oracle, golden_dir, name, monkeypatch):
+    """k_trsv_syncfree (one launch per group, rows wait for their dependencies' values) against the
+    level-by-level kernels on the same factors: every row is summed by the same lanes in the same order,
+    so L^-1 U^-1 must be BIT-identical -- deep chains inside one wavefront (chain3000: every row waits for
+    the previous one), wavefront-shaped levels (Poisson), scattered rows, the hybrid far/near split."""
+    if name == "chain3000":
+        A = _chain_matrix(oracle, 3000, 2, 3)
+    elif name == "poisson160x90":
+        A = oracle.poisson5(160, 90)
+    elif name.startswith("rand20000x50"):
+        A = oracle.rand_rows(20000, 50, 0x5EED)
+    elif name == "longrows":
+        A = _real_sparse(oracle, 400, 0.6, 5)
+    else:
+        A = _load(oracle, golden_dir, name)
+    monkeypatch.setenv("CUDAMAT_TRSV_HYBRID", "1" if name.endswith("hybrid") else "0")
+    rng = np.random.default_rng(4)
+    rhs = [rng.standard_normal(A.n) for _ in range(3)]
+    got = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("CUDAMAT_TRSV_SYNCFREE", form)
+        s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+        s.ilu0()
+        outs = []
+        for b in rhs:
+            dr, do = ctx.array(b), ctx.empty(A.n)
+            s.precond_apply(dr, do)
+            outs.append(do.download())
+        got[form] = outs
+        if form == "1":       # and through the solver loop, where a timed-out wait would be reported
+            xs = 1.0 + np.sin(np.arange(A.n))
+            st = s.solve(ctx.array(oracle.spmv(A, xs)), ctx.empty(A.n), precond=cm.PRECOND_ILU0, maxit=50, tol=1e-8,
+                         flags=cm.FLAG_X0_ONES)
+            assert st.converged
+        s.close()
+    for a, b in zip(got["0"], got["1"]):
+        assert np.isfinite(b).all()
+        np.testing.assert_array_equal(a, b)
+    want = oracle.ilu0(A)
+    ref = oracle.trsv_upper(A, want, oracle.trsv_lower_unit(A, want, rhs[0]))
+    np.testing.assert_allclose(got["1"][0], ref, rtol=1e-10, atol=1e-12)
+
+
 def test_spmv_skewed_rows(cm, ctx, oracle, monkeypatch):
     """a few rows with tens of thousands of entries among short ones: the lanes-per-row
     kernel hands them to the whole workgroup; results stay exact, the fused dots stay right"""
