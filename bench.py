@@ -78,6 +78,29 @@ def cpu_baseline(args):
     }
 
 
+def hbm_ceiling(ctx):
+    """measured streaming ceiling of this GPU: the in-repo y += a*x kernel (2 reads + 1 write per
+    element, triad-shaped) on 2^26 doubles per vector (1 GiB of operands, far beyond the 256 MB Infinity Cache),
+    HIP-event timed, median of 7"""
+    n = 1 << 26
+    x, y = ctx.empty(n), ctx.empty(n)
+    x.zero()
+    y.zero()
+    t = ctx.timer()
+    times = []
+    for i in range(9):
+        t.start()
+        ctx.axpy(n, 0.5, x, y)
+        t.stop()
+        if i >= 2:
+            times.append(t.elapsed_ms())
+    t.close()
+    x.free()
+    y.free()
+    ms = sorted(times)[len(times) // 2]
+    return {"kernel": "k_axpy, 2 reads + 1 write, 3 x 512 MiB", "gbs": 24.0 * n / ms / 1e6}
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (RCCL prints its library
@@ -291,6 +314,10 @@ def run_bench(args):
             out["levels"] = [st.n_levels_l, st.n_levels_u]
             # one-off setup (outside the timed region): level analysis of L and U; ILU(0) + factor layout + far/near split
             out["setup_s"] = {"analysis": st.t_analysis, "factor": st.t_factor}
+        if world == 1 and not latency_bound:
+            ceil = hbm_ceiling(ctx)
+            out["roofline"]["measured_stream_ceiling"] = ceil
+            out["roofline"]["frac_of_measured_ceiling"] = achieved / ceil["gbs"]
         if world == 1 and args.cpu_baseline != "off":
             out["cpu_baseline"] = cpu_baseline(args)
     solver.close()

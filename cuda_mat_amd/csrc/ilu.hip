@@ -512,13 +512,13 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
         if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) H.lanes = v;
     }
     // groups of consecutive levels for the hybrid solve: only for big factors with many wide levels whose
-    // columns are scattered (the gather-bound case); ~16 levels per group leaves ~10 % of the entries near
+    // columns are scattered (the gather-bound case); ~24 levels per group leaves ~15-20 % of the entries near
     H.lev_host.swap(lev);
     const char *hy = getenv("CUDAMAT_TRSV_HYBRID");
     const bool want = hy ? hy[0] == '1' : (n >= 500000 && F.nnz >= (8 << 20) && nlev >= 16 && n / nlev >= 16384);
     int K = 1;
     if (want && nlev >= 4) {
-        K = nlev / 16;
+        K = nlev / 24;
         if (K < 2) K = 2;
         if (K > 16) K = 16;
         if (const char *e = getenv("CUDAMAT_TRSV_GROUPS")) {
