@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--nx", type=int, default=4000, help="grid width of the poisson5 workload")
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--per-row", type=int, default=50)
-    ap.add_argument("--precond", default="none", choices=["none", "ilu0"])
+    ap.add_argument("--precond", default="none", choices=["none", "ilu0", "bjilu0"],
+                    help="ilu0: the reference's preconditioner (N > 1: independent replicas); bjilu0: block-Jacobi "
+                         "ILU(0) of each rank's diagonal block, row-sharded (different maths for N > 1, SURVEY 8 f4)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-iters", type=int, default=25)
@@ -102,6 +104,13 @@ def hbm_ceiling(ctx):
 
 
 def main():
+    if os.environ.get("CUDAMAT_BENCH_ONE_DEVICE"):
+        # rehearsal with several ranks on ONE GPU: two dependency-driven (spin-waiting) kernels of different
+        # processes may starve each other of workgroup slots, so use the level-by-level triangular solves
+        os.environ.setdefault("CUDAMAT_TRSV_SYNCFREE", "0")
+    if os.environ.get("CUDAMAT_BENCH_WATCHDOG"):      # dump every thread's Python stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CUDAMAT_BENCH_WATCHDOG"]), exit=True)
     args = parse()
     # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (RCCL prints its library
     # path when a communicator is created) are sent to stderr until the result is ready
@@ -191,9 +200,11 @@ def run_bench(args):
         x = torch.empty(nloc, dtype=torch.float64, device=dev)
         ctx.gen_xstar(row0, row1, args.seed + 1, xs)
         solver.spmv(xs, b)                    # b = A x*
-        precond = cm.PRECOND_ILU0 if args.precond == "ilu0" else cm.PRECOND_NONE
-        if precond:
+        precond = {"none": cm.PRECOND_NONE, "ilu0": cm.PRECOND_ILU0, "bjilu0": cm.PRECOND_BLOCK_ILU0}[args.precond]
+        if precond == cm.PRECOND_ILU0:
             solver.ilu0()
+        elif precond:
+            solver.block_ilu0()
         flags = cm.FLAG_NO_EXIT | cm.FLAG_X0_ONES
 
         def run(steps, fl):
@@ -291,7 +302,7 @@ def run_bench(args):
             "config": {"workload": "%s n=%d nnz=%d%s, x0=1, b=A*xstar, %s, %s x%d"
                                    % (args.workload, n, nnz * world if (args.workload == "rand50" and not replicas) else nnz,
                                       "/rank" if (world > 1 and args.workload != "rand50") else "",
-                                      "ILU(0)" if precond else "no preconditioner",
+                                      {"none": "no preconditioner", "ilu0": "ILU(0)", "bjilu0": "block-Jacobi ILU(0)"}[args.precond],
                                       "independent replicas" if replicas else "row-sharded", world),
                        "rows": n, "nnz_per_rank": nnz,
                        "parallelism": ("replicas x%d (preconditioned path does not shard)" % world) if replicas else "rows/%d" % world,

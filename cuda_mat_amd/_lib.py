@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcudamat_hip.so")
 
 OK = 0
-PRECOND_NONE, PRECOND_ILU0 = 0, 1
+PRECOND_NONE, PRECOND_ILU0, PRECOND_BLOCK_ILU0 = 0, 1, 2
 LOOP_PBICGSTAB, LOOP_PBICGSTAB2 = 0, 1
 FLAG_DEBUG, FLAG_PROFILE, FLAG_NO_EXIT, FLAG_X0_ONES = 1, 2, 4, 8
 
@@ -84,7 +84,10 @@ _SIGS = {
     "cudamat_solver_destroy": (C.c_int, [_P]),
     "cudamat_solver_set_shift": (C.c_int, [_P, _P]),
     "cudamat_solver_ilu0": (C.c_int, [_P]),
+    "cudamat_solver_block_ilu0": (C.c_int, [_P]),
     "cudamat_solver_ilu0_values": (C.c_int, [_P, _P]),
+    "cudamat_solver_ilu0_nnz": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "cudamat_solver_trsv_form": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "cudamat_solver_precond_apply": (C.c_int, [_P, _P, _P]),
     "cudamat_solver_set_comm": (C.c_int, [_P, C.POINTER(Comm)]),
     "cudamat_solver_spmv_mode": (C.c_int, [_P, C.POINTER(C.c_int)]),

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (FLAG_DEBUG, FLAG_NO_EXIT, FLAG_PROFILE, FLAG_X0_ONES, LOOP_PBICGSTAB,
-                   LOOP_PBICGSTAB2, PRECOND_ILU0, PRECOND_NONE, Comm, CudamatError, Stats, check)
+                   LOOP_PBICGSTAB2, PRECOND_BLOCK_ILU0, PRECOND_ILU0, PRECOND_NONE, Comm, CudamatError, Stats, check)
 
 
 def _np(a, dtype):
@@ -275,10 +275,22 @@ class Solver:
     def ilu0(self):
         check(_lib.lib().cudamat_solver_ilu0(self.h))
 
+    def trsv_form(self):
+        """1: dependency-driven triangular solves, 0: one launch per level"""
+        f = C.c_int()
+        check(_lib.lib().cudamat_solver_trsv_form(self.h, C.byref(f)))
+        return f.value
+
+    def block_ilu0(self):
+        """ILU(0) of this rank's diagonal block (block-Jacobi; the only preconditioner of a sharded solver)"""
+        check(_lib.lib().cudamat_solver_block_ilu0(self.h))
+
     def ilu0_values(self):
-        out = self.ctx.empty(max(self.nnz, 1))
+        cnt = C.c_int64()
+        check(_lib.lib().cudamat_solver_ilu0_nnz(self.h, C.byref(cnt)))
+        out = self.ctx.empty(max(cnt.value, 1))
         check(_lib.lib().cudamat_solver_ilu0_values(self.h, out.ptr))
-        v = out.download()[:self.nnz]
+        v = out.download()[:cnt.value]
         out.free()
         return v
 

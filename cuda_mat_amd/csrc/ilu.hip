@@ -129,7 +129,10 @@ __global__ __launch_bounds__(kBlock) void k_levels_dep(int n, const int *rp, con
     for (;;) {
         if (have) {
             const int l = __hip_atomic_load(&lev[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (l >= 0 || ++spins > (1 << 21)) {
+            bool give_up = false;
+            if (l < 0 && (++spins & 1023) == 0)
+                give_up = spins > (1 << 21) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+            if (l >= 0 || give_up) {
                 if (l < 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 m = l + 1 > m ? l + 1 : m;
                 spins = 0;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_trsv_small_levels(int l0, int l1, co
 // level kernel's order, so the result is bit-identical to the level-by-level solve.
 // Every spin is bounded: a lane that gives up sets *err (pinned host word) and proceeds with what it read.
 constexpr unsigned long long kNotReady = 0x7FF4C0DEC0DEC0DEull;
-constexpr int kSpinLimit = 1 << 21;
+constexpr int kSpinLimit = 1 << 21;      // polls of one dependency before a row gives up (CUDAMAT_TRSV_SPIN_LIMIT)
 
 __global__ __launch_bounds__(kBlock) void k_fill_not_ready(long long n, unsigned long long *out)
 {
@@ -298,7 +301,7 @@ template <int LANES>
 __global__ __launch_bounds__(kBlock) void k_trsv_syncfree(int r0, int r1, const int *frp, const int *fci,
                                                           const double *fval, const int *row_of,
                                                           const double *dinv, const double *far,
-                                                          const double *rhs, double *out, int *err)
+                                                          const double *rhs, double *out, int *err, int spin_limit)
 {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     constexpr int RPB = kBlock / LANES;
@@ -336,7 +339,12 @@ __global__ __launch_bounds__(kBlock) void k_trsv_syncfree(int r0, int r1, const 
         if (have) {
             const unsigned long long bits = __hip_atomic_load((gu64 *)(out + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool ready = bits != kNotReady;
-            if (ready || ++spins > kSpinLimit) {
+            // give up after kSpinLimit polls -- or at once when another row already has (checked every 1024 polls),
+            // so that a broken dependency costs one timeout, not one per waiting row
+            bool give_up = false;
+            if (!ready && (++spins & 1023) == 0)
+                give_up = spins > spin_limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+            if (ready || give_up) {
                 if (!ready) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 sum += a * __longlong_as_double((long long)bits);
                 spins = 0;
@@ -391,6 +399,7 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
     double *far_buf = nullptr;             // n doubles in level-major row order: far_g . out
     std::vector<int> lev_host;             // level of every original row (kept until the split)
     bool syncfree = false;                 // one dependency-driven launch per group instead of one launch per level
+    int spin_limit = kSpinLimit;
 };
 
 }  // namespace cm
@@ -423,6 +432,16 @@ int ilu0_release(cudamat_solver *s)
     free_factor(s->U);
     if (s->lu) hipFree(s->lu);
     if (s->diag_pos) hipFree(s->diag_pos);
+    if (s->pm_owned) {
+        if (s->pm_rp) hipFree(s->pm_rp);
+        if (s->pm_ci) hipFree(s->pm_ci);
+        if (s->pm_val) hipFree(s->pm_val);
+    }
+    s->pm_rp = s->pm_ci = nullptr;
+    s->pm_val = nullptr;
+    s->pm_nnz = 0;
+    s->pm_owned = false;
+    s->ilu_block = false;
     s->lu = nullptr;
     s->diag_pos = nullptr;
     s->has_ilu = false;
@@ -455,7 +474,7 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
     const char *force_sweep = getenv("CUDAMAT_LEVELS_SWEEP");
     if (n > 0 && err_host && !(force_sweep && force_sweep[0] == '1')) {
         CM_HIP(hipMemsetAsync(d_lev, 0xFF, sizeof(int) * (size_t)n, st));
-        hipLaunchKernelGGL(k_levels_dep, dim3(grid), dim3(kBlock), 0, st, n, s->rp, s->ci, s->diag_pos, upper ? 1 : 0,
+        hipLaunchKernelGGL(k_levels_dep, dim3(grid), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0,
                            d_lev, err_dev);
         CM_HIP(hipGetLastError());
         CM_HIP(hipStreamSynchronize(st));
@@ -466,7 +485,7 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
     int sweeps = 0;
     while (n > 0 && !have_levels) {
         CM_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_level_sweep, dim3(grid ? grid : 1), dim3(kBlock), 0, st, n, s->rp, s->ci,
+        hipLaunchKernelGGL(k_level_sweep, dim3(grid ? grid : 1), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci,
                            s->diag_pos, upper ? 1 : 0, d_lev, d_flags);
         CM_HIP(hipGetLastError());
         int changed = 0;
@@ -635,7 +654,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H)
             const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)g]], r1 = F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]];
             const int64_t cnt = (int64_t)hf[(size_t)r1] - hf[(size_t)r0];
             if (r1 <= r0 || cnt <= 0) continue;
-            rc = pb_build(st, r1 - r0, s->n_cols, cnt, qrp + r0, qci, qval, &H.far[(size_t)g]);
+            rc = pb_build(st, r1 - r0, s->n, cnt, qrp + r0, qci, qval, &H.far[(size_t)g]);   // square: columns = local rows
         }
         CM_STAMP("far plans (pb_build)");
         if (rc) break;
@@ -669,17 +688,104 @@ static int fill_factor(cudamat_solver *s, bool upper, TriFactor &F)
     if (!n) return CUDAMAT_OK;
     const long long threads = (long long)n * 8;
     const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_fill_factor, dim3(grid), dim3(kBlock), 0, s->ctx->stream, n, s->rp, s->ci, s->lu,
+    hipLaunchKernelGGL(k_fill_factor, dim3(grid), dim3(kBlock), 0, s->ctx->stream, n, s->pm_rp, s->pm_ci, s->lu,
                        s->diag_pos, upper ? 1 : 0, F.row_of, F.rp, F.ci, F.val, F.dinv);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }
 
-int ilu0_setup(cudamat_solver *s)
+// ---- block-Jacobi: the rank's diagonal block (columns [c0, c0 + n) of its rows) with local column ids
+__device__ __forceinline__ int lower_bound_col(const int *ci, int lo, int hi, long long key)
 {
-    CM_ARG(!s->sharded, "ILU(0) is single-GPU only");
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ci[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void k_block_count(int n, const int *rp, const int *ci, long long c0, int *first,
+                                                        int *cnt)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int a = lower_bound_col(ci, rp[i], rp[i + 1], c0);
+    const int b = lower_bound_col(ci, a, rp[i + 1], c0 + n);
+    first[i] = a;
+    cnt[i] = b - a;
+}
+
+__global__ __launch_bounds__(kBlock) void k_block_fill(int n, const int *ci, const double *val, long long c0,
+                                                       const int *first, const int *brp, int *bci, double *bval)
+{
+    constexpr int L = 8;
+    const long long t = ((long long)blockIdx.x * kBlock + threadIdx.x) / L;
+    if (t >= n) return;
+    const int i = (int)t, lane = threadIdx.x & (L - 1);
+    const int src = first[i], dst = brp[i], cnt = brp[i + 1] - dst;
+    for (int k = lane; k < cnt; k += L) {
+        bci[dst + k] = (int)(ci[src + k] - c0);
+        bval[dst + k] = val[src + k];
+    }
+}
+
+static int select_precond_matrix(cudamat_solver *s)
+{
+    if (!s->sharded) {
+        s->pm_rp = s->rp;
+        s->pm_ci = s->ci;
+        s->pm_val = s->val;
+        s->pm_nnz = s->nnz;
+        s->pm_owned = false;
+        return CUDAMAT_OK;
+    }
+    hipStream_t st = s->ctx->stream;
+    const int n = s->n;
+    const long long c0 = (long long)s->comm.rank * s->n_pad;
+    int *first = nullptr, *cnt = nullptr;
+    int rc = CUDAMAT_OK;
+    s->pm_owned = true;
+    do {
+        if ((rc = dalloc(&first, (size_t)n))) break;
+        if ((rc = dalloc(&cnt, (size_t)n))) break;
+        const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+        if (n) hipLaunchKernelGGL(k_block_count, dim3(grid), dim3(kBlock), 0, st, n, s->rp, s->ci, c0, first, cnt);
+        std::vector<int> h((size_t)n), brp((size_t)n + 1, 0);
+        if (n && (hipMemcpyAsync(h.data(), cnt, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                  hipStreamSynchronize(st) != hipSuccess)) { rc = CUDAMAT_ERR_HIP; set_error("block count failed"); break; }
+        for (int i = 0; i < n; i++) brp[(size_t)i + 1] = brp[(size_t)i] + h[(size_t)i];
+        s->pm_nnz = brp[(size_t)n];
+        if ((rc = dalloc(&s->pm_rp, (size_t)n + 1))) break;
+        if ((rc = dalloc(&s->pm_ci, (size_t)s->pm_nnz))) break;
+        if ((rc = dalloc(&s->pm_val, (size_t)s->pm_nnz))) break;
+        if (hipMemcpy(s->pm_rp, brp.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = CUDAMAT_ERR_HIP; set_error("block row pointers upload failed"); break;
+        }
+        const unsigned grid8 = (unsigned)(((long long)n * 8 + kBlock - 1) / kBlock);
+        if (n) hipLaunchKernelGGL(k_block_fill, dim3(grid8), dim3(kBlock), 0, st, n, s->ci, s->val, c0, first, s->pm_rp,
+                                  s->pm_ci, s->pm_val);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rc = CUDAMAT_ERR_HIP; set_error("block extraction failed"); break;
+        }
+    } while (0);
+    if (first) hipFree(first);
+    if (cnt) hipFree(cnt);
+    return rc;       // on failure ilu0_setup's error path releases the partial copy
+}
+
+int ilu0_setup(cudamat_solver *s, bool block)
+{
+    CM_ARG(block || !s->sharded, "ILU(0) of the whole matrix is single-GPU only (use the block variant)");
     CM_HIP(hipSetDevice(s->ctx->device));
     ilu0_release(s);
+    if (int rc0 = select_precond_matrix(s)) {
+        char saved[512];
+        snprintf(saved, sizeof(saved), "%s", cudamat_last_error());
+        ilu0_release(s);
+        set_error("%s", saved);
+        return rc0;
+    }
+    s->ilu_block = block;
     hipStream_t st = s->ctx->stream;
     const int n = s->n;
     IluPlans *pl = plans_of(s, true);
@@ -696,10 +802,10 @@ int ilu0_setup(cudamat_solver *s)
         }
         *pl->err_host = 0;
         if ((rc = dalloc(&s->diag_pos, (size_t)n))) break;
-        if ((rc = dalloc(&s->lu, (size_t)s->nnz))) break;
+        if ((rc = dalloc(&s->lu, (size_t)s->pm_nnz))) break;
         if (hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
         if (n) {
-            hipLaunchKernelGGL(k_find_diag, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, s->rp, s->ci,
+            hipLaunchKernelGGL(k_find_diag, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci,
                                s->diag_pos, d_flags);
         }
         int hflags[2] = {0, 0};
@@ -711,7 +817,7 @@ int ilu0_setup(cudamat_solver *s)
             break;
         }
         std::vector<int> h_rp((size_t)n + 1), h_diag((size_t)n);
-        if (hipMemcpy(h_rp.data(), s->rp, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost) != hipSuccess ||
+        if (hipMemcpy(h_rp.data(), s->pm_rp, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost) != hipSuccess ||
             (n && hipMemcpy(h_diag.data(), s->diag_pos, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)) {
             rc = CUDAMAT_ERR_HIP; set_error("D2H of the pattern failed"); break;
         }
@@ -726,7 +832,7 @@ int ilu0_setup(cudamat_solver *s)
         // ---- factorisation on a copy of A's values (pbicgstab.cu:316, :356-363)
         const double t1 = now_s();
         t_stamp = t1;
-        if (hipMemcpyAsync(s->lu, s->val, sizeof(double) * (size_t)s->nnz, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        if (hipMemcpyAsync(s->lu, s->pm_val, sizeof(double) * (size_t)s->pm_nnz, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             rc = CUDAMAT_ERR_HIP; set_error("copy of A values failed"); break;
         }
         int maxrow = 0;
@@ -746,10 +852,10 @@ int ilu0_setup(cudamat_solver *s)
             const int rows = r1 - r0;
             if (one_wave) {
                 hipLaunchKernelGGL(k_ilu0_level<1>, dim3(rows), dim3(64), sizeof(double) * (size_t)cap, st, r0, r1,
-                                   s->L.row_of, s->rp, s->ci, s->diag_pos, s->lu, cap, d_flags);
+                                   s->L.row_of, s->pm_rp, s->pm_ci, s->diag_pos, s->lu, cap, d_flags);
             } else {
                 hipLaunchKernelGGL(k_ilu0_level<4>, dim3((rows + 3) / 4), dim3(256), sizeof(double) * 4 * (size_t)cap, st,
-                                   r0, r1, s->L.row_of, s->rp, s->ci, s->diag_pos, s->lu, cap, d_flags);
+                                   r0, r1, s->L.row_of, s->pm_rp, s->pm_ci, s->diag_pos, s->lu, cap, d_flags);
             }
         }
         if (hipGetLastError() != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("ilu0 launch failed"); break; }
@@ -775,6 +881,7 @@ int ilu0_setup(cudamat_solver *s)
             const bool on = sf ? sf[0] == '1' : true;
             pl->L.syncfree = on && s->L.nlevels > 1;
             pl->U.syncfree = on && s->U.nlevels > 1;
+            if (const char *lim = getenv("CUDAMAT_TRSV_SPIN_LIMIT")) pl->L.spin_limit = pl->U.spin_limit = atoi(lim);
         }
         s->has_ilu = true;
     } while (0);
@@ -855,9 +962,20 @@ static int launch_trsv_syncfree(hipStream_t st, const TriFactor &F, const TriHos
         }
         const unsigned grid = (unsigned)(((long long)(r1 - r0) + RPB - 1) / RPB);
         hipLaunchKernelGGL(k_trsv_syncfree<LANES>, dim3(grid), dim3(kBlock), 0, st, r0, r1, F.rp, F.ci, F.val, F.row_of,
-                           F.dinv, far, rhs, out, err);
+                           F.dinv, far, rhs, out, err, H.spin_limit);
     }
     return CUDAMAT_OK;
+}
+
+bool trsv_syncfree_active(cudamat_solver *s)
+{
+    IluPlans *pl = plans_of(s, false);
+    return pl && s->has_ilu && (pl->L.syncfree || pl->U.syncfree);
+}
+
+void trsv_disable_syncfree(cudamat_solver *s)
+{
+    if (IluPlans *pl = plans_of(s, false)) pl->L.syncfree = pl->U.syncfree = false;
 }
 
 int trsv_status(cudamat_solver *s)
@@ -910,13 +1028,35 @@ int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *
 extern "C" int cudamat_solver_ilu0(cudamat_solver *s)
 {
     CM_ARG(s, "solver is NULL");
-    return ilu0_setup(s);
+    return ilu0_setup(s, false);
+}
+
+extern "C" int cudamat_solver_ilu0_nnz(cudamat_solver *s, int64_t *count)
+{
+    CM_ARG(s && count, "null pointer");
+    CM_ARG(s->has_ilu, "call cudamat_solver_ilu0 first");
+    *count = s->pm_nnz;
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_solver_trsv_form(cudamat_solver *s, int *form)
+{
+    CM_ARG(s && form, "null pointer");
+    CM_ARG(s->has_ilu, "call cudamat_solver_ilu0 first");
+    *form = trsv_syncfree_active(s) ? 1 : 0;
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_solver_block_ilu0(cudamat_solver *s)
+{
+    CM_ARG(s, "solver is NULL");
+    return ilu0_setup(s, true);
 }
 
 extern "C" int cudamat_solver_ilu0_values(cudamat_solver *s, double *out_dev)
 {
     CM_ARG(s && out_dev, "null pointer");
     CM_ARG(s->has_ilu, "call cudamat_solver_ilu0 first");
-    CM_HIP(hipMemcpyAsync(out_dev, s->lu, sizeof(double) * (size_t)s->nnz, hipMemcpyDeviceToDevice, s->ctx->stream));
+    CM_HIP(hipMemcpyAsync(out_dev, s->lu, sizeof(double) * (size_t)s->pm_nnz, hipMemcpyDeviceToDevice, s->ctx->stream));
     return CUDAMAT_OK;
 }

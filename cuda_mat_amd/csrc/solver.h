@@ -41,6 +41,7 @@ struct cudamat_solver {
     double *r = nullptr, *rw = nullptr, *p = nullptr, *pw = nullptr, *s = nullptr, *t = nullptr,
            *v = nullptr;
     double *gather = nullptr;  // world * n_pad doubles (sharded runs)
+    double *x0_save = nullptr; // the caller's x0, kept while a dependency-driven preconditioner may have to be redone
 
     // reduction workspace: four stages of per-workgroup partials + reduced scalars
     double *parts_full = nullptr, *parts_rv = nullptr, *parts_half = nullptr, *parts_tt = nullptr;
@@ -64,7 +65,14 @@ struct cudamat_solver {
 
     // ILU(0)
     bool has_ilu = false;
-    double *lu = nullptr;      // nnz doubles on A's pattern
+    // the matrix the preconditioner is built from: the solver's own CSR, or -- block-Jacobi in a sharded
+    // run -- a copy of the rank's diagonal block with local column ids
+    int *pm_rp = nullptr, *pm_ci = nullptr;
+    double *pm_val = nullptr;
+    int64_t pm_nnz = 0;
+    bool pm_owned = false;
+    bool ilu_block = false;    // factors belong to CUDAMAT_PRECOND_BLOCK_ILU0
+    double *lu = nullptr;      // pm_nnz doubles on that matrix's pattern
     int *diag_pos = nullptr;   // position of the diagonal in each row
     cm::TriFactor L, U;
     void *ilu_plans = nullptr;  // launch plans owned by ilu.hip
@@ -72,8 +80,10 @@ struct cudamat_solver {
 };
 
 namespace cm {
-int ilu0_setup(cudamat_solver *s);
+int ilu0_setup(cudamat_solver *s, bool block);
 int ilu0_release(cudamat_solver *s);
 int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *rhs, double *out);
 int trsv_status(cudamat_solver *s);   // after a stream sync: did a dependency-driven solve give up waiting?
+bool trsv_syncfree_active(cudamat_solver *s);
+void trsv_disable_syncfree(cudamat_solver *s);   // sticky: level-by-level kernels from now on
 }  // namespace cm

@@ -43,7 +43,7 @@ static int dev_alloc(void **p, size_t bytes)
 
 static void free_work(cudamat_solver *s)
 {
-    double **vs[] = {&s->r, &s->rw, &s->p, &s->pw, &s->s, &s->t, &s->v, &s->gather};
+    double **vs[] = {&s->r, &s->rw, &s->p, &s->pw, &s->s, &s->t, &s->v, &s->gather, &s->x0_save};
     for (double **q : vs) {
         if (*q) hipFree(*q);
         *q = nullptr;
@@ -162,6 +162,7 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     hipStreamSynchronize(s->ctx->stream);
     free_work(s);
     pb_free(&s->pb);
+    ilu0_release(s);           // factors belong to the old partition
     s->spmv_mode = -1;
     const char *force = getenv("CUDAMAT_FORCE_SHARDED");
     const bool forced = comm && comm->world == 1 && force && force[0] == '1';
@@ -332,27 +333,30 @@ static int precond_apply(cudamat_solver *s, const double *in, double *tmp, doubl
 extern "C" int cudamat_solver_precond_apply(cudamat_solver *s, const double *in, double *out)
 {
     CM_ARG(s && in && out, "null pointer");
-    CM_ARG(s->has_ilu, "call cudamat_solver_ilu0 first");
+    CM_ARG(s->has_ilu, "call cudamat_solver_ilu0 / cudamat_solver_block_ilu0 first");
     CM_HIP(hipSetDevice(s->ctx->device));
     CM_TRY(ensure_work(s));
     return precond_apply(s, in, s->t, out);
 }
 
-extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *x, int precond,
-                                    int loop, int maxit, double tol, int flags, cudamat_stats *out)
+static int solve_once(cudamat_solver *s, const double *b, double *x, int precond, int loop, int maxit, double tol,
+                      int flags, cudamat_stats *out, bool *precond_gave_up)
 {
     CM_ARG(s && b && x, "null pointer");
-    CM_ARG(precond == CUDAMAT_PRECOND_NONE || precond == CUDAMAT_PRECOND_ILU0, "precond");
+    CM_ARG(precond == CUDAMAT_PRECOND_NONE || precond == CUDAMAT_PRECOND_ILU0 || precond == CUDAMAT_PRECOND_BLOCK_ILU0,
+           "precond");
     CM_ARG(loop == CUDAMAT_LOOP_PBICGSTAB || loop == CUDAMAT_LOOP_PBICGSTAB2, "loop");
     CM_ARG(maxit >= 0, "maxit");
-    CM_ARG(!(precond && s->sharded), "ILU(0) is single-GPU only (SURVEY 8e): no sharded preconditioner");
+    CM_ARG(!(precond == CUDAMAT_PRECOND_ILU0 && s->sharded),
+           "ILU(0) of the whole matrix is single-GPU only (SURVEY 8e); sharded runs take CUDAMAT_PRECOND_BLOCK_ILU0");
     CM_ARG(!(precond && s->d), "the (A0 + I d) variant has no preconditioner (pbicgstab.h:110)");
     CM_HIP(hipSetDevice(s->ctx->device));
     const double t_begin = now_s();
     hipStream_t st = s->ctx->stream;
     CM_TRY(ensure_work(s));
     CM_TRY(ensure_spmv_mode(s));
-    if (precond && !s->has_ilu) CM_TRY(ilu0_setup(s));
+    if (precond && (!s->has_ilu || (s->sharded && !s->ilu_block)))
+        CM_TRY(ilu0_setup(s, precond == CUDAMAT_PRECOND_BLOCK_ILU0));
 
     const int need_hist = (loop == CUDAMAT_LOOP_PBICGSTAB ? 2 : 1) * (maxit > 0 ? maxit : 1);
     if (need_hist > s->hist_cap) {
@@ -449,6 +453,13 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
             // The SpMV changes only t, so the half-step test may ride with the
             // (t.r, t.t) all-reduce: one collective instead of two.
             CM_TRY(launch_reduce_parts(st, half_src, 1, s->red + 1, 0));
+            if (precond) {   // block-Jacobi: local triangular solves, no collective (they only write s and t, so an
+                             // exit at the half step, noticed after the all-reduce below, leaves x and r untouched)
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+                CM_TRY(precond_apply(s, s->r, s->t, s->s));
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+                sv = s->s;
+            }
             if (profile) hipEventRecord(prof_event(s, pe++), st);
             CM_TRY(spmv_local(s, sv, s->t, 2, s->r, s->parts_tt, la, CHECK_NONE, nosrc));
             if (profile) hipEventRecord(prof_event(s, pe++), st);
@@ -471,7 +482,25 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
     CM_HIP(hipMemcpyAsync(&s->st_ring[0], s->st, sizeof(LoopState), hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));                              // :372
     const double t_loop1 = now_s();
-    if (precond) CM_TRY(trsv_status(s));
+    // A dependency-driven triangular solve that gave up waiting (another spin-waiting kernel shared the GPU,
+    // see DESIGN.md section 4) invalidates this attempt; in a sharded run every rank must learn of it.
+    *precond_gave_up = false;
+    if (precond) {
+        int bad = trsv_status(s) != CUDAMAT_OK ? 1 : 0;
+        if (sharded) {
+            const double mine = (double)bad;
+            double all = 0.0;
+            CM_HIP(hipMemcpy(s->red + 7, &mine, sizeof(double), hipMemcpyHostToDevice));
+            CM_TRY(allreduce(s, s->red + 7, 1));
+            CM_HIP(hipStreamSynchronize(st));
+            CM_HIP(hipMemcpy(&all, s->red + 7, sizeof(double), hipMemcpyDeviceToHost));
+            bad = all != 0.0;
+        }
+        if (bad) {
+            *precond_gave_up = true;
+            return CUDAMAT_OK;
+        }
+    }
     const LoopState fin = s->st_ring[0];
     s->hist_count = (loop == CUDAMAT_LOOP_PBICGSTAB) ? 2 * fin.it + (fin.state == 1 ? 1 : 0) : fin.it;
     if (s->hist_count > s->hist_cap) s->hist_count = s->hist_cap;
@@ -523,6 +552,39 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
     }
     stt.t_total = now_s() - t_begin;
     if (out) *out = stt;
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *x, int precond,
+                                    int loop, int maxit, double tol, int flags, cudamat_stats *out)
+{
+    CM_ARG(s && b && x, "null pointer");
+    // keep the caller's x0 while the dependency-driven preconditioner is in use: if one of its waits times
+    // out, the solve is redone from x0 with the level-by-level kernels (same results, bit for bit)
+    const bool keep_x0 = precond != CUDAMAT_PRECOND_NONE && !(flags & CUDAMAT_FLAG_X0_ONES);
+    if (keep_x0) {
+        CM_HIP(hipSetDevice(s->ctx->device));
+        if (!s->x0_save) CM_TRY(dev_alloc((void **)&s->x0_save, sizeof(double) * (size_t)(s->n > 0 ? s->n : 1)));
+        CM_HIP(hipMemcpyAsync(s->x0_save, x, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
+    }
+    bool gave_up = false;
+    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up));
+    if (!gave_up) return CUDAMAT_OK;
+    if (!trsv_syncfree_active(s)) {
+        set_error("triangular solve reported a timeout although the level-by-level kernels were in use");
+        return CUDAMAT_ERR_HIP;
+    }
+    trsv_disable_syncfree(s);
+    if (getenv("CUDAMAT_VERBOSE"))
+        fprintf(stderr, "cudamat: a dependency-driven triangular solve timed out (GPU shared with another spin-waiting "
+                        "kernel?); redoing the solve with one launch per level\n");
+    if (keep_x0)
+        CM_HIP(hipMemcpyAsync(x, s->x0_save, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
+    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up));
+    if (gave_up) {
+        set_error("triangular solve timed out twice");
+        return CUDAMAT_ERR_HIP;
+    }
     return CUDAMAT_OK;
 }
 
@@ -578,7 +640,7 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
         }
         if ((rc = cudamat_solver_create(ctx, n, n, nnz, d_rp, d_ci, d_val, base, &s))) break;
         if (d_d && (rc = cudamat_solver_set_shift(s, d_d))) break;
-        if (precond == CUDAMAT_PRECOND_ILU0) {
+        if (precond != CUDAMAT_PRECOND_NONE) {
             if ((rc = cudamat_solver_ilu0(s))) break;
             if (debug) {
                 printf("analysis lower %f (s), upper %f (s) \n", s->t_analysis_l, s->t_analysis_u);     // :349

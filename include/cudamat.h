@@ -57,6 +57,10 @@ extern "C" {
 /* preconditioner (cudamat_solve / cudamat_solver_solve) */
 #define CUDAMAT_PRECOND_NONE    0
 #define CUDAMAT_PRECOND_ILU0    1
+#define CUDAMAT_PRECOND_BLOCK_ILU0 2 /* block-Jacobi: ILU(0) of each rank's diagonal block.
+                                       Not in the reference (single GPU); with one rank it IS
+                                       CUDAMAT_PRECOND_ILU0, with more it is a different (weaker)
+                                       preconditioner with its own parity statement.            */
 
 /* which reference loop's stopping rules to follow */
 #define CUDAMAT_LOOP_PBICGSTAB  0   /* pbicgstab.cu:45-154: half-step + full-step exits
@@ -165,8 +169,19 @@ int cudamat_solver_set_shift(cudamat_solver *s, const double *d);
 /* ILU(0) of the local block sharing A's pattern + level analysis of L and U
  * (pbicgstab.cu:336-359).  Single rank only.                                          */
 int cudamat_solver_ilu0(cudamat_solver *s);
-/* copies the LU values (nnz doubles, same ordering as val) to a device buffer         */
+/* the same on the rank's DIAGONAL BLOCK (rows and columns it owns) -- allowed in a sharded solver;
+ * no collective is involved, neither here nor in the preconditioning steps            */
+int cudamat_solver_block_ilu0(cudamat_solver *s);
+/* copies the LU values (nnz doubles, same ordering as val; for the block variant: the
+ * entries of the diagonal block in row order) to a device buffer                       */
 int cudamat_solver_ilu0_values(cudamat_solver *s, double *out_dev);
+/* how many values that is (nnz, or the entry count of the diagonal block)                */
+int cudamat_solver_ilu0_nnz(cudamat_solver *s, int64_t *count);
+/* which triangular-solve kernels the next preconditioning step uses: 1 = dependency-driven (one launch per
+ * group of levels, rows wait for their dependencies inside the launch), 0 = one launch per level.  The first
+ * form assumes no OTHER spin-waiting kernel shares the GPU (one stream per GPU); its waits are bounded, and a
+ * solve that sees a timeout is redone with the second form, which then stays selected.                      */
+int cudamat_solver_trsv_form(cudamat_solver *s, int *form);
 /* out = U^-1 L^-1 in  (what one preconditioning step applies, pbicgstab.cu:92-98)     */
 int cudamat_solver_precond_apply(cudamat_solver *s, const double *in, double *out);
 /* row-sharded operation; comm is copied.  world == 1 or NULL => single GPU (unless the

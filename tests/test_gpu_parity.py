@@ -689,3 +689,30 @@ def test_spmv_skewed_rows(cm, ctx, oracle, monkeypatch):
     assert st.converged and so.converged and abs(st.iters - so.iters) <= max(3, 0.3 * so.iters)
     np.testing.assert_allclose(h[:8], oracle.pbicgstab(A2, b, maxit=4, tol=1e-30, want_hist=True)[2][:8], rtol=1e-7)
     np.testing.assert_allclose(xg, xs, rtol=1e-6)
+
+
+def test_trsv_timeout_redoes_the_solve_with_level_kernels(cm, ctx, oracle, monkeypatch):
+    """a dependency-driven triangular solve whose wait times out (here: an absurdly small spin limit on a matrix
+    whose rows form one long chain) must not produce an answer: the solve is redone from x0 with the
+    level-by-level kernels, which then stay selected; results equal the level-only run bit for bit"""
+    A = _chain_matrix(oracle, 6000, 2, 7)
+    xs = 1.0 + np.cos(np.arange(A.n))
+    b = oracle.spmv(A, xs)
+    x0 = np.full(A.n, 0.5)
+    res = {}
+    for form, limit in (("0", None), ("1", "1")):
+        monkeypatch.setenv("CUDAMAT_TRSV_SYNCFREE", form)
+        if limit:
+            monkeypatch.setenv("CUDAMAT_TRSV_SPIN_LIMIT", limit)
+        s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+        s.ilu0()
+        assert s.trsv_form() == int(form)
+        db, dx = ctx.array(b), ctx.array(x0)
+        st = s.solve(db, dx, precond=cm.PRECOND_ILU0, maxit=100, tol=1e-10)       # caller's x0 (no X0_ONES flag)
+        res[form] = (dx.download(), st.iters, st.converged, s.trsv_form())
+        s.close()
+    monkeypatch.delenv("CUDAMAT_TRSV_SPIN_LIMIT")
+    assert res["1"][3] == 0, "the timeout should have switched the solver to the level kernels"
+    assert res["0"][2] and res["1"][2] and res["0"][1] == res["1"][1]
+    np.testing.assert_array_equal(res["0"][0], res["1"][0])
+    np.testing.assert_allclose(res["1"][0], xs, atol=1e-7)
