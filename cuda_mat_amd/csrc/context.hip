@@ -227,7 +227,12 @@ extern "C" int cudamat_spmv(cudamat_ctx *ctx, int n, const int *rowptr, const in
     a.dot = 0;
     a.loop = LoopArgs{nullptr, nullptr, 0, 0, 0};
     a.check = CHECK_NONE;
-    return launch_spmv(ctx->stream, plan, a);
+    const int rc = launch_spmv(ctx->stream, plan, a);
+    if (plan.tiles) {                      // the tile tables live only for this call
+        hipStreamSynchronize(ctx->stream);
+        plan_spmv_free(&plan);
+    }
+    return rc;
 }
 
 extern "C" int cudamat_dot(cudamat_ctx *ctx, int64_t n, const double *x, const double *y,

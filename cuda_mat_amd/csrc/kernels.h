@@ -22,10 +22,22 @@ struct SpmvPlan {
     int grid;             // workgroups
     int rows_per_block;   // contiguous rows owned by a workgroup
     int stream_rows;      // > 0: LDS-staged stream kernel, this many rows per LDS tile (short rows)
+    // > 0: nnz-balanced tiles of 2048 entries (skewed row lengths); rows_per_block = tiles per workgroup;
+    // the tables are owned by the plan (plan_spmv_free)
+    int tiles = 0;
+    int tile_nspan = 0, tile_fix_grid = 0;
+    int *tile_S = nullptr, *tile_span = nullptr;
+    double *tile_heads = nullptr, *tile_tails = nullptr;
+    double lane_cost = 0.0;   // lane-iterations of the lanes-per-row kernel / nnz (1 = perfectly balanced)
 };
 SpmvPlan plan_spmv(int n_rows, int64_t nnz);
+void plan_spmv_free(SpmvPlan *plan);
+// per-workgroup dot partials one launch leaves behind
+inline int plan_spmv_parts(const SpmvPlan &p) { return p.grid + (p.tiles ? p.tile_fix_grid : 0); }
 // short rows (mean <= 12): switch the plan to the LDS-staged stream kernel when every tile of
-// `stream_rows` consecutive rows holds at most kStreamNnz entries (checked on the device)
+// `stream_rows` consecutive rows holds at most kStreamNnz entries (checked on the device); otherwise, when
+// the lanes-per-row kernel would spend > 2.5 lane-iterations per entry (skewed row lengths), switch it to the
+// nnz-balanced tile kernel.  CUDAMAT_SPMV_FORM=lanes|tiles forces one of the two.
 int plan_spmv_refine(hipStream_t s, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan);
 
 // y = alpha*(A x + d .* xd) + beta*y  on 0- or 1-based CSR (base folded into the

@@ -10,6 +10,10 @@
 // the consumer's prologue (bitwise reproducible, no atomics, no host sync).
 //
 // Scalars (rho, alpha, omega, norms) never leave the device: see LoopState.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
 #include "kernels.h"
 
 namespace cm {
@@ -359,6 +363,285 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a, int tiles_pe
     }
 }
 
+// ------------------------------------------------------------ SpMV, skewed row lengths
+// Tiles of kTileNnz consecutive ENTRIES (not rows): every workgroup streams the same number of entries
+// whatever the row-length distribution (a few rows of 1e5 entries among rows of 8 leave the
+// lanes-per-row kernel at 0.3-0.5 TB/s).  S[t] = first row that STARTS at or after the tile's first entry
+// (lower bound in rowptr, found once per matrix).  Per tile: products -> LDS; rows that start here and have
+// at most kTileShort entries in the tile are summed by one thread in column order; longer ones, the piece of
+// a row that began in an earlier tile ("head") and the piece of a row that continues into the next one
+// ("tail") are summed by one wavefront each.  Rows confined to one tile are finished here; a row spanning
+// tiles is finished by k_spmv_tiles_fix from tails[t] + heads[t+1..] in tile order.  Work lists are built
+// with a prefix sum (no atomics), so every row's summation tree and the dot partials are reproducible.
+constexpr int kTileNnz = 2048;
+constexpr int kTileShort = 32;
+constexpr int kTileItems = kTileNnz / (kTileShort + 1) + 4;
+
+struct TileItem {
+    int j0, j1, row, kind;     // kind 0: whole row, 1: head piece, 2: tail piece
+};
+
+// exclusive prefix of one flag per thread over the 256-thread workgroup (+ the total)
+__device__ __forceinline__ int block_scan_flag(int v, int *lds_waves, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(v != 0);
+    const int before_in_wave = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();                       // lds_waves may still be read from the previous round
+    if (lane == 0) lds_waves[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) {
+        const int c = lds_waves[w];
+        if (w < wave) before += c;
+        all += c;
+    }
+    *total = all;
+    return before + before_in_wave;
+}
+
+__device__ __forceinline__ void spmv_finish_row(const SpmvArgs &a, int row, double sum, double (&acc)[2])
+{
+    if (a.d) sum += a.d[row] * a.xd[row];
+    double out = a.alpha * sum;
+    if (a.beta != 0.0) out += a.beta * a.y[row];
+    a.y[row] = out;
+    if (a.dot) {
+        acc[0] += out * a.w[row];
+        acc[1] += out * out;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_spmv_tiles(SpmvArgs a, const int *S, int ntiles, int tiles_per_block,
+                                                       double *heads, double *tails)
+{
+    __shared__ double prod[kTileNnz];
+    __shared__ TileItem items[kTileItems];
+    __shared__ int scan_w[kBlock / 64];
+    __shared__ int n_items;
+    __shared__ double lds[8];
+    if (a.loop.st) {
+        if (a.check == CHECK_HALF) {
+            if (check_half(a.loop, a.half, lds)) return;
+        } else if (a.loop.st->state != 0) {
+            return;
+        }
+    }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int cid = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+    const int kbase = a.rp[0], kend = a.rp[a.n];
+    double acc[2] = {0.0, 0.0};
+    for (int tt = 0; tt < tiles_per_block; tt++) {
+        const long long tl = (long long)cid * tiles_per_block + tt;
+        if (tl >= ntiles) break;
+        const int t = (int)tl;
+        const int k0 = kbase + t * kTileNnz;
+        const int k1 = kend - k0 < kTileNnz ? kend : k0 + kTileNnz;
+        const int cnt = k1 - k0;
+        const int s0 = S[t], s1 = S[t + 1];
+        for (int j = tid; j < cnt; j += kBlock)
+            prod[j] = __builtin_nontemporal_load(a.val + k0 + j) * a.x[__builtin_nontemporal_load(a.ci + k0 + j)];
+        if (tid == 0) {
+            int m = 0;
+            const int first_start = a.rp[s0];          // s0 == n: rp[n] = kend > k0
+            if (first_start > k0) {                    // entry k0 belongs to row s0 - 1, which began earlier
+                items[m].j0 = 0;
+                items[m].j1 = (first_start < k1 ? first_start : k1) - k0;
+                items[m].row = s0 - 1;
+                items[m].kind = 1;
+                m++;
+            }
+            n_items = m;
+        }
+        __syncthreads();
+        for (int r0 = s0; r0 < s1; r0 += kBlock) {
+            const int base_items = n_items;
+            const int r = r0 + tid;
+            const bool isrow = r < s1;
+            int rb = 0, re = 0;
+            if (isrow) {
+                rb = a.rp[r];
+                re = a.rp[r + 1];
+            }
+            const bool spans = isrow && re > k1;       // only the last row that starts here can
+            const int rend = re < k1 ? re : k1;
+            const bool coop = isrow && (spans || rend - rb > kTileShort);
+            if (isrow && !coop) {
+                double sum = 0.0;
+                for (int j = rb - k0; j < rend - k0; j++) sum += prod[j];
+                spmv_finish_row(a, r, sum, acc);
+            }
+            int total;
+            const int pos = block_scan_flag(coop ? 1 : 0, scan_w, &total);
+            if (coop) {
+                TileItem it;
+                it.j0 = rb - k0;
+                it.j1 = rend - k0;
+                it.row = r;
+                it.kind = spans ? 2 : 0;
+                items[base_items + pos] = it;
+            }
+            __syncthreads();
+            if (tid == 0) n_items = base_items + total;
+            __syncthreads();
+        }
+        const int m = n_items;
+        for (int i = wave; i < m; i += kBlock / 64) {
+            const TileItem it = items[i];
+            double sum = 0.0;
+            for (int j = it.j0 + lane; j < it.j1; j += 64) sum += prod[j];
+            sum = wave_sum(sum);
+            if (lane == 0) {
+                if (it.kind == 0) spmv_finish_row(a, it.row, sum, acc);
+                else if (it.kind == 1) heads[t] = sum;
+                else tails[t] = sum;
+            }
+        }
+        __syncthreads();       // prod and items are reused by the next tile
+    }
+    if (a.dot) {
+        block_sum<2>(acc, lds);
+        if (tid == 0) {
+            a.parts[2 * b] = acc[0];
+            a.parts[2 * b + 1] = acc[1];
+        }
+    }
+}
+
+// rows spanning several tiles: one wavefront per row adds tails[t] + heads[t+1 .. last] (fixed tree)
+__global__ __launch_bounds__(kBlock) void k_spmv_tiles_fix(SpmvArgs a, const int *S, const int *span, int nspan,
+                                                           const double *heads, const double *tails, int parts_off)
+{
+    __shared__ double lds[8];
+    if (a.loop.st && a.loop.st->state != 0) return;      // (a half-step test was evaluated by k_spmv_tiles)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kbase = a.rp[0];
+    double acc[2] = {0.0, 0.0};
+    for (int g = blockIdx.x * (kBlock / 64) + wave; g < nspan; g += gridDim.x * (kBlock / 64)) {
+        const int t = span[g];
+        const int row = S[t + 1] - 1;
+        const int last = (a.rp[row + 1] - 1 - kbase) / kTileNnz;      // tile holding the row's last entry
+        double sum = 0.0;
+        for (int q = t + 1 + lane; q <= last; q += 64) sum += heads[q];
+        sum = wave_sum(sum);
+        if (lane == 0) spmv_finish_row(a, row, tails[t] + sum, acc);
+    }
+    if (a.dot) {
+        block_sum<2>(acc, lds);
+        if (threadIdx.x == 0) {
+            a.parts[2 * (parts_off + blockIdx.x)] = acc[0];
+            a.parts[2 * (parts_off + blockIdx.x) + 1] = acc[1];
+        }
+    }
+}
+
+// S[t] = first row r with rp[r] >= first entry of tile t (rows are rp[0..n]); flag[t] = the last row that
+// starts in tile t continues beyond it
+__global__ __launch_bounds__(kBlock) void k_tiles_rows(int n, const int *rp, int ntiles, int *S)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t > ntiles) return;
+    if (t == ntiles) { S[t] = n; return; }
+    const long long key = (long long)rp[0] + (long long)t * kTileNnz;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (rp[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    S[t] = lo;
+}
+
+__global__ __launch_bounds__(kBlock) void k_tiles_span(int n, const int *rp, int ntiles, const int *S, int *flag)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= ntiles) return;
+    const long long k1 = (long long)rp[0] + (long long)(t + 1) * kTileNnz;
+    const int s0 = S[t], s1 = S[t + 1];
+    flag[t] = (s1 > s0 && rp[s1] > k1) ? 1 : 0;         // row s1 - 1 ends at rp[s1]
+}
+
+// lane-iterations the lanes-per-row kernel spends: sum over groups of 64/L consecutive rows (one wave
+// instruction stream) of max ceil(len / L), times 64 -- compared with nnz this is its imbalance
+__global__ __launch_bounds__(kBlock) void k_lane_cost(int n, const int *rp, int L, unsigned long long *out)
+{
+    const int G = 64 / L;
+    const long long g = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long r0 = g * G;
+    unsigned long long it = 0;
+    if (r0 < n) {
+        int m = 0;
+        for (int q = 0; q < G && r0 + q < n; q++) {
+            const int len = rp[r0 + q + 1] - rp[r0 + q];
+            const int c = (len + L - 1) / L;
+            m = c > m ? c : m;
+        }
+        it = (unsigned long long)m;
+    }
+    it = (unsigned long long)wave_sum((double)it);      // exact below 2^53
+    if ((threadIdx.x & 63) == 0 && it) atomicAdd(out, it);
+}
+
+void plan_spmv_free(SpmvPlan *plan)
+{
+    void *ptrs[] = {plan->tile_S, plan->tile_span, plan->tile_heads, plan->tile_tails};
+    for (void *q : ptrs)
+        if (q) hipFree(q);
+    plan->tile_S = plan->tile_span = nullptr;
+    plan->tile_heads = plan->tile_tails = nullptr;
+    plan->tiles = 0;
+}
+
+static int plan_spmv_tiles(hipStream_t s, int n_rows, int64_t nnz, const int *rp, SpmvPlan *plan)
+{
+    const int64_t nt64 = (nnz + kTileNnz - 1) / kTileNnz;
+    if (nt64 < 1 || nt64 > (1 << 24)) return CUDAMAT_OK;                 // keep the lanes-per-row plan
+    const int ntiles = (int)nt64;
+    int *flag = nullptr;
+    int rc = CUDAMAT_OK;
+    do {
+        if (hipMalloc((void **)&plan->tile_S, sizeof(int) * ((size_t)ntiles + 1)) != hipSuccess ||
+            hipMalloc((void **)&plan->tile_heads, sizeof(double) * (size_t)ntiles) != hipSuccess ||
+            hipMalloc((void **)&plan->tile_tails, sizeof(double) * (size_t)ntiles) != hipSuccess ||
+            hipMalloc((void **)&flag, sizeof(int) * (size_t)ntiles) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
+        hipMemsetAsync(plan->tile_heads, 0, sizeof(double) * (size_t)ntiles, s);
+        hipMemsetAsync(plan->tile_tails, 0, sizeof(double) * (size_t)ntiles, s);
+        hipLaunchKernelGGL(k_tiles_rows, dim3((unsigned)((ntiles + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp,
+                           ntiles, plan->tile_S);
+        hipLaunchKernelGGL(k_tiles_span, dim3((unsigned)((ntiles + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp,
+                           ntiles, plan->tile_S, flag);
+        std::vector<int> h((size_t)ntiles), span;
+        if (hipMemcpyAsync(h.data(), flag, sizeof(int) * (size_t)ntiles, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        for (int t = 0; t < ntiles; t++)
+            if (h[(size_t)t]) span.push_back(t);
+        plan->tile_nspan = (int)span.size();
+        if (!span.empty()) {
+            if (hipMalloc((void **)&plan->tile_span, sizeof(int) * span.size()) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
+            if (hipMemcpy(plan->tile_span, span.data(), sizeof(int) * span.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                rc = CUDAMAT_ERR_HIP; break;
+            }
+        }
+        const int fix_grid = span.empty() ? 0 : (int)std::min<size_t>(64, (span.size() + 3) / 4);
+        const int main_max = kSpmvGridMax - 64;
+        int grid = ntiles < main_max ? ntiles : main_max;
+        const int per = (ntiles + grid - 1) / grid;
+        grid = (ntiles + per - 1) / per;
+        plan->tiles = ntiles;
+        plan->rows_per_block = per;          // tiles per workgroup
+        plan->grid = grid;
+        plan->tile_fix_grid = fix_grid;
+    } while (0);
+    if (flag) hipFree(flag);
+    if (rc) {
+        plan_spmv_free(plan);
+        if (rc == CUDAMAT_ERR_NOMEM) return CUDAMAT_OK;                  // no room for the tables: lanes-per-row plan stays
+        return fail_hip(hipGetLastError(), "tile plan", __FILE__, __LINE__);
+    }
+    return CUDAMAT_OK;
+}
+
 // max over tiles of R rows of the number of entries in the tile, for R = 64, 128, 256
 __global__ __launch_bounds__(kBlock) void k_tile_nnz_max(int n, const int *rp, int *out)
 {
@@ -372,13 +655,41 @@ __global__ __launch_bounds__(kBlock) void k_tile_nnz_max(int n, const int *rp, i
     if ((t & 3) == 0) atomicMax(&out[2], at(r0 + 256) - b0);
 }
 
+// skewed row lengths: measure what the lanes-per-row plan would cost and switch to tiles when it is unbalanced
+static int plan_spmv_balance(hipStream_t s, int n_rows, int64_t nnz, const int *rp, SpmvPlan *plan)
+{
+    const char *form = getenv("CUDAMAT_SPMV_FORM");
+    if (form && !strcmp(form, "lanes")) return CUDAMAT_OK;
+    const bool force = form && !strcmp(form, "tiles");
+    if (nnz <= 0 || n_rows <= 0) return CUDAMAT_OK;
+    if (!force) {
+        if (nnz < 65536) return CUDAMAT_OK;
+        unsigned long long *d = nullptr, h = 0;
+        CM_HIP(hipMalloc((void **)&d, sizeof(h)));
+        hipMemsetAsync(d, 0, sizeof(h), s);
+        const long long groups = ((long long)n_rows + (64 / plan->lanes) - 1) / (64 / plan->lanes);
+        hipLaunchKernelGGL(k_lane_cost, dim3((unsigned)((groups + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp,
+                           plan->lanes, d);
+        hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s);
+        const hipError_t e = hipStreamSynchronize(s);
+        hipFree(d);
+        if (e != hipSuccess) return fail_hip(e, "lane cost", __FILE__, __LINE__);
+        plan->lane_cost = (double)h * 64.0 / (double)nnz;
+        // measured (scripts/skew_probe.py): at 2.0 (rows of 2 and 62 alternating) the lanes kernel is still memory-bound
+        // and 25 % faster than the tiles; at 3.7-5 (hub rows, Pareto lengths) the tiles win 1.4-9x
+        if (plan->lane_cost <= 2.5) return CUDAMAT_OK;
+    }
+    return plan_spmv_tiles(s, n_rows, nnz, rp, plan);
+}
+
 int plan_spmv_refine(hipStream_t s, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan)
 {
     (void)base;
     plan->stream_rows = 0;
     if (getenv("CUDAMAT_SPMV_LANES")) return CUDAMAT_OK;          // explicit lanes-per-row request
     const double mean = n_rows > 0 ? (double)nnz / n_rows : 0.0;
-    if (n_rows < 64 || mean > 12.0) return CUDAMAT_OK;
+    if (n_rows < 64) return CUDAMAT_OK;
+    if (mean > 12.0) return plan_spmv_balance(s, n_rows, nnz, rp, plan);
     int *d = nullptr, h[3] = {0, 0, 0};
     CM_HIP(hipMalloc((void **)&d, 3 * sizeof(int)));
     hipMemsetAsync(d, 0, 3 * sizeof(int), s);
@@ -392,7 +703,7 @@ int plan_spmv_refine(hipStream_t s, int n_rows, int64_t nnz, const int *rp, int 
     if (h[2] <= kStreamNnz) R = 256;
     else if (h[1] <= kStreamNnz) R = 128;
     else if (h[0] <= kStreamNnz) R = 64;
-    if (!R) return CUDAMAT_OK;
+    if (!R) return plan_spmv_balance(s, n_rows, nnz, rp, plan);
     const long long tiles_r = ((long long)n_rows + R - 1) / R;
     int grid = (int)(tiles_r < kSpmvGridMax ? tiles_r : kSpmvGridMax);
     const long long per = (tiles_r + grid - 1) / grid;
@@ -405,6 +716,15 @@ int plan_spmv_refine(hipStream_t s, int n_rows, int64_t nnz, const int *rp, int 
 int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a)
 {
     dim3 g(plan.grid), b(kBlock);
+    if (plan.tiles) {
+        hipLaunchKernelGGL(k_spmv_tiles, g, b, 0, s, a, plan.tile_S, plan.tiles, plan.rows_per_block, plan.tile_heads,
+                           plan.tile_tails);
+        if (plan.tile_fix_grid)
+            hipLaunchKernelGGL(k_spmv_tiles_fix, dim3(plan.tile_fix_grid), b, 0, s, a, plan.tile_S, plan.tile_span,
+                               plan.tile_nspan, plan.tile_heads, plan.tile_tails, plan.grid);
+        CM_HIP(hipGetLastError());
+        return CUDAMAT_OK;
+    }
     if (plan.stream_rows) {
         switch (plan.stream_rows) {
         case 64:  hipLaunchKernelGGL(k_spmv_stream<64>, g, b, 0, s, a, plan.rows_per_block); break;

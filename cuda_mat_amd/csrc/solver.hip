@@ -136,6 +136,7 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     ilu0_release(s);
     pb_free(&s->pb);
     free_work(s);
+    plan_spmv_free(&s->plan);
     void *ptrs[] = {s->rp, s->ci, s->val, s->parts_full, s->parts_rv, s->parts_half, s->parts_tt,
                     s->red, s->st, s->hist};
     for (void *p : ptrs)
@@ -223,7 +224,7 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
 }
 
 // number of per-workgroup partial sums an SpMV launch leaves in `parts`
-static int spmv_parts(const cudamat_solver *s) { return s->spmv_mode == 1 ? s->pb.NRB : s->plan.grid; }
+static int spmv_parts(const cudamat_solver *s) { return s->spmv_mode == 1 ? s->pb.NRB : plan_spmv_parts(s->plan); }
 
 // Choose the SpMV implementation for this matrix (once): the blocked two-phase kernels when the
 // columns are scattered over a vector far larger than L2 AND they measure faster than the

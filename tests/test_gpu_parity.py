@@ -716,3 +716,88 @@ def test_trsv_timeout_redoes_the_solve_with_level_kernels(cm, ctx, oracle, monke
     assert res["0"][2] and res["1"][2] and res["0"][1] == res["1"][1]
     np.testing.assert_array_equal(res["0"][0], res["1"][0])
     np.testing.assert_allclose(res["1"][0], xs, atol=1e-7)
+
+
+def _skewed_matrix(oracle, kind, rng):
+    """integer-valued CSR with a nasty row-length distribution"""
+    import scipy.sparse as sp
+    if kind == "pareto":
+        n = 150000
+        lens = np.minimum(1 + (rng.pareto(1.3, n) * 4).astype(np.int64), 60000)
+    elif kind == "hubs":                       # rows of 8 + a few rows spanning tens of 2048-entry tiles
+        n = 120000
+        lens = np.full(n, 8, np.int64)
+        lens[[0, 1, 777, 60000, n - 2, n - 1]] = [50000, 4097, 2048, 100000, 2049, 30000]
+    elif kind == "empties":                    # runs of empty rows, also first / last, around tile boundaries
+        n = 90000
+        lens = rng.integers(0, 3, n).astype(np.int64) * rng.integers(0, 2, n)
+        lens[:300] = 0
+        lens[-500:] = 0
+        lens[40000:41000] = 0
+        lens[5000] = 7000
+    else:                                      # "mixed": a 1500-entry row among one-entry rows inside one tile
+        n = 70000
+        lens = np.ones(n, np.int64)
+        lens[::997] = 1500
+        lens[::13] = 40
+    rp = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    nnz = int(rp[-1])
+    rows = np.repeat(np.arange(n), lens)
+    cols = rng.integers(0, n, nnz)
+    S = sp.csr_matrix((np.ones(nnz), (rows, cols)), shape=(n, n))
+    S.sum_duplicates()
+    S.sort_indices()
+    S.data[:] = rng.integers(1, 5, S.nnz)
+    return oracle.Csr(n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), n)
+
+
+@pytest.mark.parametrize("kind", ["pareto", "hubs", "empties", "mixed"])
+def test_spmv_nnz_balanced_tiles(cm, ctx, oracle, kind, monkeypatch):
+    """k_spmv_tiles / k_spmv_tiles_fix (tiles of 2048 ENTRIES; rows spanning tiles finished from head / tail
+    partials): exact on integer data for every row-length pathology -- standalone entry point with alpha, beta
+    and the diagonal term, solver entry point, base 0 and 1, auto-selected and forced"""
+    rng = np.random.default_rng({"pareto": 1, "hubs": 2, "empties": 3, "mixed": 4}[kind])
+    A = _skewed_matrix(oracle, kind, rng)
+    n = A.n
+    x = rng.integers(-3, 4, n).astype(np.float64)
+    y0 = rng.integers(-2, 3, n).astype(np.float64)
+    d = rng.integers(-2, 3, n).astype(np.float64)
+    want = oracle.spmv(A, x)
+    want_full = oracle.csrmv(A, 2.0, x, -1.0, y0.copy() * 1.0)          # y = 2 A x - y0
+    for form in (None, "tiles", "lanes"):
+        if form:
+            monkeypatch.setenv("CUDAMAT_SPMV_FORM", form)
+        for base in (0, 1):
+            rp, ci, v = ctx.array((A.rowptr + base).astype(np.int32)), ctx.array((A.colidx + base).astype(np.int32)), ctx.array(A.val)
+            dx, dy = ctx.array(x), ctx.array(y0)
+            ctx.spmv(n, rp, ci, v, base, dx, dy, alpha=2.0, beta=-1.0)
+            np.testing.assert_array_equal(dy.download(), want_full)
+            dy.zero()
+            ctx.spmv(n, rp, ci, v, base, dx, dy, d=ctx.array(d))
+            np.testing.assert_array_equal(dy.download(), want + d * x)
+        monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
+        monkeypatch.delenv("CUDAMAT_SPMV_MODE")
+    monkeypatch.delenv("CUDAMAT_SPMV_FORM")
+
+
+def test_solve_with_tile_spmv(cm, ctx, oracle, monkeypatch):
+    """the fused dot partials of the tile kernels (main launch + the launch that finishes spanning rows) inside
+    the BiCGSTAB loop: same iterates as the oracle"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    A = _skewed_matrix(oracle, "hubs", rng)
+    S = sp.csr_matrix((A.val, A.colidx, A.rowptr), shape=(A.n, A.n))
+    S = (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() + 1.0)).tocsr()
+    S.sort_indices()
+    A2 = oracle.Csr(A.n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), A.n)
+    xs = oracle.xstar(A.n, 5)
+    b = oracle.spmv(A2, xs)
+    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
+    monkeypatch.setenv("CUDAMAT_SPMV_FORM", "tiles")
+    xg, st, h = _solve_dev(cm, ctx, A2, b, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-10)
+    xo, so, ho = oracle.pbicgstab(A2, b, maxit=200, tol=1e-10, want_hist=True)
+    assert st.converged and so.converged and abs(st.iters - so.iters) <= max(3, 0.3 * so.iters)
+    np.testing.assert_allclose(h[:6], ho[:6], rtol=1e-7)
+    np.testing.assert_allclose(xg, xs, rtol=1e-6)
