@@ -776,6 +776,7 @@ static int select_precond_matrix(cudamat_solver *s)
 int ilu0_setup(cudamat_solver *s, bool block)
 {
     CM_ARG(block || !s->sharded, "ILU(0) of the whole matrix is single-GPU only (use the block variant)");
+    CM_ARG(s->cols_sorted, "ILU(0) needs every row's column indices strictly increasing (mmio_wrapper.h:123 delivers that)");
     CM_HIP(hipSetDevice(s->ctx->device));
     ilu0_release(s);
     if (int rc0 = select_precond_matrix(s)) {

@@ -34,6 +34,7 @@ struct cudamat_solver {
     const double *d = nullptr;
     cm::SpmvPlan plan{};
     int spmv_mode = -1;        // -1 undecided, 0 CSR wave-per-row kernel, 1 propagation-blocking kernels
+    bool cols_sorted = true;   // every row's columns strictly increasing (checked at creation)
     cm::PbPlan pb{};
     double ms_csr = 0.0, ms_pb = 0.0;   // auto-tune timings
 

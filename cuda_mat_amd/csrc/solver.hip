@@ -69,6 +69,62 @@ static int ensure_work(cudamat_solver *s)
 
 static int ensure_spmv_mode(cudamat_solver *s);
 
+// ---- input validation (once, at creation): a malformed CSR must become an error code, never a stray access
+// flags[0]: row pointers not 0 = rp[0] <= rp[1] <= ... <= rp[n] = nnz;  flags[1]: a column id outside [0, n_cols);
+// flags[2]: some row's columns are not strictly increasing
+__global__ __launch_bounds__(kBlock) void k_check_rowptr(int n, long long nnz, const int *rp, int *flags)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i > n) return;
+    bool bad = false;
+    if (i == 0 && rp[0] != 0) bad = true;
+    if (i == n && rp[n] != nnz) bad = true;
+    if (i < n && rp[i] > rp[i + 1]) bad = true;
+    if (rp[i] < 0 || rp[i] > nnz) bad = true;
+    if (bad) flags[0] = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_check_columns(int n, long long n_cols, const int *rp, const int *ci, int *flags)
+{
+    constexpr int L = 8;
+    const long long row = ((long long)blockIdx.x * kBlock + threadIdx.x) / L;
+    if (row >= n) return;
+    const int lane = threadIdx.x & (L - 1);
+    const int s = rp[row], e = rp[row + 1];
+    bool range = false, order = false;
+    for (int k = s + lane; k < e; k += L) {
+        const int c = ci[k];
+        if (c < 0 || c >= n_cols) range = true;
+        if (k > s && ci[k - 1] >= c) order = true;
+    }
+    if (range) flags[1] = 1;
+    if (order) flags[2] = 1;
+}
+
+static int validate_csr(cudamat_solver *s)
+{
+    hipStream_t st = s->ctx->stream;
+    int *d = nullptr, h[3] = {0, 0, 0};
+    CM_HIP(hipMalloc((void **)&d, sizeof(h)));
+    hipMemsetAsync(d, 0, sizeof(h), st);
+    hipLaunchKernelGGL(k_check_rowptr, dim3((unsigned)(((long long)s->n + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, s->n,
+                       (long long)s->nnz, s->rp, d);
+    hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess && !h[0] && s->n > 0 && s->nnz > 0) {
+        hipLaunchKernelGGL(k_check_columns, dim3((unsigned)(((long long)s->n * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           s->n, (long long)s->n_cols, s->rp, s->ci, d);
+        hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+        e = hipStreamSynchronize(st);
+    }
+    hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "CSR validation", __FILE__, __LINE__);
+    if (h[0]) { set_error("row pointers must start at the index base, never decrease and end at nnz"); return CUDAMAT_ERR_ARG; }
+    if (h[1]) { set_error("a column index lies outside [base, base + n_cols)"); return CUDAMAT_ERR_ARG; }
+    s->cols_sorted = h[2] == 0;
+    return CUDAMAT_OK;
+}
+
 extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz,
                                      const int *rowptr, const int *colidx, const double *val,
                                      int base, cudamat_solver **out)
@@ -118,6 +174,10 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
     if (rc) {
         cudamat_solver_destroy(s);
         return rc;
+    }
+    if (int rcv = validate_csr(s)) {
+        cudamat_solver_destroy(s);
+        return rcv;
     }
     s->plan = plan_spmv(n_local, nnz);
     if (int rc2 = plan_spmv_refine(st, n_local, nnz, s->rp, 0, &s->plan)) {
@@ -238,6 +298,10 @@ static int ensure_spmv_mode(cudamat_solver *s)
     const bool force_pb = env && !strcmp(env, "pb");
     s->spmv_mode = 0;
     if (force_csr || s->n == 0 || s->nnz == 0) return CUDAMAT_OK;
+    if (!s->cols_sorted) {        // the blocked builder ranks entries by runs of equal column block: needs sorted rows
+        if (force_pb) { set_error("the blocked SpMV needs rows with increasing column indices"); return CUDAMAT_ERR_ARG; }
+        return CUDAMAT_OK;
+    }
     if (!force_pb && !pb_candidate(st, s->n, s->n_cols, s->nnz, s->rp, s->ci)) return CUDAMAT_OK;
     int rc = pb_build(st, s->n, s->n_cols, s->nnz, s->rp, s->ci, s->val, &s->pb);
     if (rc != CUDAMAT_OK) {

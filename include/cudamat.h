@@ -158,7 +158,10 @@ int cudamat_scal(cudamat_ctx *ctx, int64_t n, double alpha, double *x);
  *   n_cols  : number of columns = global dimension
  *   rowptr/colidx/val : DEVICE pointers, base taken from `base`; they are copied
  *   (and rebased to 0) into the solver's own HBM arrays, so the caller may free them.
- * Work vectors and the reduction workspace are allocated here, once.                 */
+ * Work vectors and the reduction workspace are allocated here, once.
+ * The arrays are validated on the device: row pointers that are not monotone from base to base + nnz or a
+ * column outside [base, base + n_cols) => CUDAMAT_ERR_ARG.  Rows whose columns are not strictly increasing
+ * are accepted for the un-preconditioned loops (lanes-per-row / tile SpMV); ILU(0) refuses them.        */
 int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz,
                           const int *rowptr, const int *colidx, const double *val,
                           int base, cudamat_solver **out);

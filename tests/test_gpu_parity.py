@@ -801,3 +801,41 @@ def test_solve_with_tile_spmv(cm, ctx, oracle, monkeypatch):
     assert st.converged and so.converged and abs(st.iters - so.iters) <= max(3, 0.3 * so.iters)
     np.testing.assert_allclose(h[:6], ho[:6], rtol=1e-7)
     np.testing.assert_allclose(xg, xs, rtol=1e-6)
+
+
+def test_solver_validates_its_csr(cm, ctx, oracle, monkeypatch):
+    """malformed inputs become CUDAMAT_ERR_ARG at creation (never a stray device access); rows with unsorted
+    columns are accepted by the un-preconditioned path and refused by ILU(0) and by the blocked SpMV"""
+    A = oracle.rand_rows(5000, 12, 3)
+    n = A.n
+    bad_rp = A.rowptr.copy()
+    bad_rp[100] = bad_rp[101] + 5                       # decreasing
+    with pytest.raises(cm.CudamatError) as e:
+        cm.Solver.from_host_csr(ctx, bad_rp, A.colidx, A.val)
+    assert e.value.code == 2
+    for bad in (n, -1, 2 ** 30):
+        ci = A.colidx.copy()
+        ci[12345] = bad
+        with pytest.raises(cm.CudamatError) as e:
+            cm.Solver.from_host_csr(ctx, A.rowptr, ci, A.val)
+        assert e.value.code == 2
+    # unsorted row (swap two entries of row 7): SpMV still right, ILU(0) and the blocked form refuse
+    ci, v = A.colidx.copy(), A.val.copy()
+    k = A.rowptr[7]
+    ci[[k, k + 3]] = ci[[k + 3, k]]
+    v[[k, k + 3]] = v[[k + 3, k]]
+    x = np.arange(n, dtype=np.float64) % 7 - 3
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, ci, v)
+    dx, dy = ctx.array(x), ctx.empty(n)
+    s.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), oracle.spmv(A, x))
+    with pytest.raises(cm.CudamatError) as e:
+        s.ilu0()
+    assert e.value.code == 2
+    s.close()
+    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "pb")
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, ci, v)
+    with pytest.raises(cm.CudamatError) as e:
+        s.spmv(dx, dy)
+    assert e.value.code == 2
+    s.close()
