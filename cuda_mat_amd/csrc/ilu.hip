@@ -469,6 +469,82 @@ __global__ __launch_bounds__(kBlock) void k_trsv_syncfree(int r0, int r1, const 
     }
 }
 
+// ---- small systems (n <= 16384): the whole solve in ONE workgroup with the solution vector in LDS
+// The level-by-level chain is then LDS read -> multiply-add -> shuffle -> LDS write -> barrier (~0.15 us per level):
+// each team's row of the NEXT level (row pointers, first entries, right-hand side, 1/diagonal) is fetched from
+// global memory before the barrier, so nothing but LDS sits between two levels (mat10000: 199 levels per factor).
+// Same per-row summation as k_trsv_level (lane k takes entries k, k + LANES, ...; xor tree) => bit-identical.
+constexpr int kLdsTrsvRows = 16384;
+
+template <int LANES>
+__global__ __launch_bounds__(kBlock) void k_trsv_lds(int n, int nlev, const int *level_ptr, const int *frp, const int *fci,
+                                                     const double *fval, const int *row_of, const double *dinv,
+                                                     const double *rhs, double *out)
+{
+    extern __shared__ __attribute__((aligned(16))) double xs[];       // n doubles, original row numbering
+    constexpr int RPB = kBlock / LANES;
+    const int lane = threadIdx.x & (LANES - 1), team = threadIdx.x / LANES;
+    // prefetched state of this team's first row of the coming level
+    int pr = 0, s = 0, e = 0, r = 0, c = 0;
+    double a = 0.0, b = 0.0, di = 1.0;
+    bool mine = false;
+    auto fetch = [&](int l) {
+        mine = false;
+        if (l >= nlev) return;
+        pr = level_ptr[l] + team;
+        mine = pr < level_ptr[l + 1];
+        if (!mine) return;
+        s = frp[pr];
+        e = frp[pr + 1];
+        if (s + lane < e) {
+            c = fci[s + lane];
+            a = fval[s + lane];
+        }
+        if (lane == 0) {
+            r = row_of[pr];
+            b = rhs[r];
+            if (dinv) di = dinv[pr];
+        }
+    };
+    fetch(0);
+    for (int l = 0; l < nlev; l++) {
+        const int lend = level_ptr[l + 1];
+        const bool have = mine;
+        const int pr0 = pr, s0 = s, e0 = e, r0 = r;
+        const double b0 = b, di0 = di;
+        double sum = 0.0;
+        if (have) {
+            if (s0 + lane < e0) sum = a * xs[c];
+            for (int k = s0 + lane + LANES; k < e0; k += LANES) sum += fval[k] * xs[fci[k]];
+        }
+#pragma unroll
+        for (int o = LANES / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (have && lane == 0) {
+            double v = b0 - sum;
+            if (dinv) v *= di0;
+            xs[r0] = v;
+            out[r0] = v;
+        }
+        // further rows of a level wider than the workgroup's teams
+        for (int q = pr0 + RPB; have && q < lend; q += RPB) {
+            const int qs = frp[q], qe = frp[q + 1];
+            double t = 0.0;
+            for (int k = qs + lane; k < qe; k += LANES) t += fval[k] * xs[fci[k]];
+#pragma unroll
+            for (int o = LANES / 2; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane == 0) {
+                const int rr = row_of[q];
+                double v = rhs[rr] - t;
+                if (dinv) v *= dinv[q];
+                xs[rr] = v;
+                out[rr] = v;
+            }
+        }
+        fetch(l + 1);                      // global loads of the next level overlap the barrier
+        __syncthreads();
+    }
+}
+
 static int pick_lanes(double mean)
 {
     if (mean <= 3.0) return 2;
@@ -494,6 +570,7 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
     std::vector<int> lev_host;             // level of every original row (kept until the split)
     bool syncfree = false;                 // one dependency-driven launch per group instead of one launch per level
     int spin_limit = kSpinLimit;
+    bool lds = false;                      // n <= 16384, narrow levels: the whole solve in one workgroup, x in LDS
 };
 
 }  // namespace cm
@@ -991,6 +1068,10 @@ int ilu0_setup(cudamat_solver *s, bool block)
             const bool forced = sf && sf[0] == '1';
             pl->L.syncfree = on && s->L.nlevels > 1 && (forced || widest(s->L) > 512);
             pl->U.syncfree = on && s->U.nlevels > 1 && (forced || widest(s->U) > 512);
+            const char *le = getenv("CUDAMAT_TRSV_LDS");
+            const bool lds_on = !(le && le[0] == '0') && n > 0 && n <= kLdsTrsvRows;
+            pl->L.lds = lds_on && !pl->L.hybrid && widest(s->L) <= 512;
+            pl->U.lds = lds_on && !pl->U.hybrid && widest(s->U) <= 512;
             if (const char *lim = getenv("CUDAMAT_TRSV_SPIN_LIMIT")) pl->L.spin_limit = pl->U.spin_limit = atoi(lim);
         }
         s->has_ilu = true;
@@ -1106,6 +1187,30 @@ int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *
     const TriHost &H = upper ? pl->U : pl->L;
     hipStream_t st = s->ctx->stream;
     int rc;
+    if (H.lds && !H.syncfree) {
+        const size_t bytes = sizeof(double) * (size_t)s->n;
+#define CM_TRSV_LDS(LV)                                                                                             \
+    do {                                                                                                            \
+        static bool attr = false;                                                                                   \
+        if (!attr) {                                                                                                \
+            hipFuncSetAttribute((const void *)k_trsv_lds<LV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr = true;                                                                                            \
+        }                                                                                                           \
+        hipLaunchKernelGGL(k_trsv_lds<LV>, dim3(1), dim3(kBlock), bytes, st, s->n, F.nlevels, H.level_ptr_dev, F.rp, \
+                           F.ci, F.val, F.row_of, F.dinv, rhs, out);                                                \
+    } while (0)
+        switch (H.lanes) {
+        case 2:  CM_TRSV_LDS(2); break;
+        case 4:  CM_TRSV_LDS(4); break;
+        case 8:  CM_TRSV_LDS(8); break;
+        case 16: CM_TRSV_LDS(16); break;
+        case 32: CM_TRSV_LDS(32); break;
+        default: CM_TRSV_LDS(64); break;
+        }
+#undef CM_TRSV_LDS
+        CM_HIP(hipGetLastError());
+        return CUDAMAT_OK;
+    }
     if (H.syncfree) {
         if (rhs == out) { set_error("triangular solve: rhs and out must not alias"); return CUDAMAT_ERR_ARG; }
         switch (H.lanes) {

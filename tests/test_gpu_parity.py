@@ -860,3 +860,38 @@ def test_ilu0_prefetching_kernel_equals_simple_kernel(cm, ctx, oracle, golden_di
         s.close()
     np.testing.assert_array_equal(got[0], got[1])
     np.testing.assert_allclose(got[0], oracle.ilu0(A), rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["mat900", "mat10000", "chain3000", "longrows", "rand9000x30"])
+def test_lds_resident_trsv_equals_level_kernels(cm, ctx, oracle, golden_dir, name, monkeypatch):
+    """k_trsv_lds (n <= 16384: one workgroup, solution vector in LDS, next level's operands prefetched across the
+    barrier) against the level kernels with the vector in global memory: bit-identical L^-1 U^-1, and both within
+    1e-10 of the oracle's substitutions"""
+    if name == "chain3000":
+        A = _chain_matrix(oracle, 3000, 2, 3)
+    elif name == "longrows":
+        A = _real_sparse(oracle, 400, 0.6, 5)
+    elif name == "rand9000x30":
+        A = oracle.rand_rows(9000, 30, 77)          # levels of ~100-300 rows: several rows per team and level
+    else:
+        A = _load(oracle, golden_dir, name)
+    monkeypatch.setenv("CUDAMAT_TRSV_SYNCFREE", "0")
+    rng = np.random.default_rng(8)
+    rhs = [rng.standard_normal(A.n) for _ in range(2)]
+    got = {}
+    for lds in ("0", "1"):
+        monkeypatch.setenv("CUDAMAT_TRSV_LDS", lds)
+        s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+        s.ilu0()
+        outs = []
+        for b in rhs:
+            dr, do = ctx.array(b), ctx.empty(A.n)
+            s.precond_apply(dr, do)
+            outs.append(do.download())
+        got[lds] = outs
+        s.close()
+    for a, b in zip(got["0"], got["1"]):
+        np.testing.assert_array_equal(a, b)
+    want = oracle.ilu0(A)
+    ref = oracle.trsv_upper(A, want, oracle.trsv_lower_unit(A, want, rhs[0]))
+    np.testing.assert_allclose(got["1"][0], ref, rtol=1e-10, atol=1e-12)
