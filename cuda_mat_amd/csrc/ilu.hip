@@ -108,10 +108,10 @@ __global__ __launch_bounds__(kBlock) void k_level_sweep(int n, const int *rp, co
 // (lev preset to -1; 4-byte write-through stores, polled with sc1 loads) and publishes its own.  Workgroups
 // are dispatched in index order, so the first unfinished row never waits for a row that has not started;
 // spins are bounded and a timeout (err) sends the caller back to the relaxation sweeps.
+template <int L>
 __global__ __launch_bounds__(kBlock) void k_levels_dep(int n, const int *rp, const int *ci, const int *diag_pos,
                                                        int upper, int *lev, int *err)
 {
-    constexpr int L = 8;
     const int lane = threadIdx.x & (L - 1);
     const int team_shift = (threadIdx.x & 63) & ~(L - 1);
     const long long t = ((long long)blockIdx.x * kBlock + threadIdx.x) / L;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_levels_dep(int n, const int *rp, con
             }
         }
         const unsigned long long pending = __ballot(have);
-        if (!done && ((pending >> team_shift) & 0xFFull) == 0) {
+        if (!done && ((pending >> team_shift) & ((1ull << L) - 1ull)) == 0) {
             int mm = m;
 #pragma unroll
             for (int o = L / 2; o > 0; o >>= 1) {
@@ -395,7 +395,8 @@ template <int LANES>
 __global__ __launch_bounds__(kBlock) void k_trsv_syncfree(int r0, int r1, const int *frp, const int *fci,
                                                           const double *fval, const int *row_of,
                                                           const double *dinv, const double *far,
-                                                          const double *rhs, double *out, int *err, int spin_limit)
+                                                          const double *rhs, double *out, int *err, int spin_limit,
+                                                          int nap)
 {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     constexpr int RPB = kBlock / LANES;
@@ -465,7 +466,13 @@ __global__ __launch_bounds__(kBlock) void k_trsv_syncfree(int r0, int r1, const 
             done = true;
         }
         if (__ballot(!done) == 0) break;
-        if (pending) __builtin_amdgcn_s_sleep(2);
+        if (pending) {
+            if (nap == 1) __builtin_amdgcn_s_sleep(1);
+            else if (nap == 2) __builtin_amdgcn_s_sleep(2);
+            else if (nap >= 4) {
+                for (int q = 0; q < nap; q += 4) __builtin_amdgcn_s_sleep(8);      // nap/4 x 512 cycles
+            }
+        }
     }
 }
 
@@ -570,6 +577,8 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
     std::vector<int> lev_host;             // level of every original row (kept until the split)
     bool syncfree = false;                 // one dependency-driven launch per group instead of one launch per level
     int spin_limit = kSpinLimit;
+    int nap = 2;                           // s_sleep between polls (CUDAMAT_TRSV_NAP = 0, 1, 2, 4)
+    int occ = 8;                           // workgroups per CU the dependency-driven launch may keep resident
     bool lds = false;                      // n <= 16384, narrow levels: the whole solve in one workgroup, x in LDS
 };
 
@@ -645,8 +654,18 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
     const char *force_sweep = getenv("CUDAMAT_LEVELS_SWEEP");
     if (n > 0 && err_host && !(force_sweep && force_sweep[0] == '1')) {
         CM_HIP(hipMemsetAsync(d_lev, 0xFF, sizeof(int) * (size_t)n, st));
-        hipLaunchKernelGGL(k_levels_dep, dim3(grid), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0,
-                           d_lev, err_dev);
+        // lanes per row from the mean number of dependencies: with 2 per row (stencils) one lane per row keeps 8x
+        // more rows in flight, and rows in flight are what a chain-like dependency graph needs (unlike the
+        // triangular solves, fewer resident workgroups only slow this pass down: Poisson 0.9 / 2.2 / 4.1 s at 8 / 2 / 1)
+        const double mean_dep = (double)(s->pm_nnz - n) / 2.0 / n;
+        const int L = mean_dep <= 3.0 ? 1 : mean_dep <= 6.0 ? 2 : 8;
+        const unsigned gridL = (unsigned)(((long long)n * L + kBlock - 1) / kBlock);
+        if (L == 1)
+            hipLaunchKernelGGL(k_levels_dep<1>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev);
+        else if (L == 2)
+            hipLaunchKernelGGL(k_levels_dep<2>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev);
+        else
+            hipLaunchKernelGGL(k_levels_dep<8>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev);
         CM_HIP(hipGetLastError());
         CM_HIP(hipStreamSynchronize(st));
         have_levels = *err_host == 0;
@@ -1073,6 +1092,19 @@ int ilu0_setup(cudamat_solver *s, bool block)
             pl->L.lds = lds_on && !pl->L.hybrid && widest(s->L) <= 512;
             pl->U.lds = lds_on && !pl->U.hybrid && widest(s->U) <= 512;
             if (const char *lim = getenv("CUDAMAT_TRSV_SPIN_LIMIT")) pl->L.spin_limit = pl->U.spin_limit = atoi(lim);
+            if (const char *np = getenv("CUDAMAT_TRSV_NAP")) pl->L.nap = pl->U.nap = atoi(np);
+            // Resident workgroups per CU of the dependency-driven launch.  Every waiting row polls memory, and pollers
+            // slow the very hand-offs they wait for: with little work per level the chain of hand-offs is the whole
+            // cost and FEWER resident workgroups are faster (Poisson 4000x2500, 5 K entries per level: 27.6 ms per
+            // application at 8 per CU, 15.0 ms at 1); with much work per level the gathers need the occupancy
+            // (1e6 x 50 random, 190 K entries per level: 1.75 ms at 1, 0.82 ms at 4, 0.89 ms at 8).
+            auto pick_occ = [](const TriFactor &F) {
+                const double per_level = F.nlevels > 0 ? (double)F.nnz / F.nlevels : 0.0;
+                return per_level < 16384.0 ? 1 : per_level < 131072.0 ? 2 : 4;
+            };
+            pl->L.occ = pick_occ(s->L);
+            pl->U.occ = pick_occ(s->U);
+            if (const char *oc = getenv("CUDAMAT_TRSV_OCC")) pl->L.occ = pl->U.occ = atoi(oc);
         }
         s->has_ilu = true;
     } while (0);
@@ -1152,8 +1184,15 @@ static int launch_trsv_syncfree(hipStream_t st, const TriFactor &F, const TriHos
             far = H.far_buf;
         }
         const unsigned grid = (unsigned)(((long long)(r1 - r0) + RPB - 1) / RPB);
-        hipLaunchKernelGGL(k_trsv_syncfree<LANES>, dim3(grid), dim3(kBlock), 0, st, r0, r1, F.rp, F.ci, F.val, F.row_of,
-                           F.dinv, far, rhs, out, err, H.spin_limit);
+        // residency is throttled with an (unused) dynamic LDS request: fewer waiting workgroups, fewer pollers
+        const size_t lds_pad = H.occ >= 8 ? 0 : (size_t)(152 * 1024) / (size_t)(H.occ > 0 ? H.occ : 1);
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute((const void *)k_trsv_syncfree<LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(k_trsv_syncfree<LANES>, dim3(grid), dim3(kBlock), lds_pad, st, r0, r1, F.rp, F.ci, F.val, F.row_of,
+                           F.dinv, far, rhs, out, err, H.spin_limit, H.nap);
     }
     return CUDAMAT_OK;
 }
