@@ -324,11 +324,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a, int tiles_pe
     }
     const int tid = threadIdx.x;
     const int nb = gridDim.x, b = blockIdx.x;
-    const int cid = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+    // Tiles are dealt CYCLICALLY inside an XCD's contiguous share: at any moment the workgroups of one XCD sit on
+    // neighbouring tiles, so the three uses of an x entry by a stencil row (rows i - nx, i, i + nx) fall into the
+    // same few microseconds and hit the XCD's L2 instead of being re-fetched after 20 MB of streamed entries.
+    const bool xcd_split = (nb & 7) == 0;
+    const int wg_per_set = xcd_split ? nb >> 3 : nb;
+    const int set = xcd_split ? (b & 7) : 0;
+    const int w = xcd_split ? (b >> 3) : b;
+    const long long set_tile0 = (long long)set * wg_per_set * tiles_per_block;
     double acc[2] = {0.0, 0.0};
     for (int t = 0; t < tiles_per_block; t++) {
-        const long long r0l = ((long long)cid * tiles_per_block + t) * R;
-        if (r0l >= a.n) break;
+        const long long r0l = (set_tile0 + (long long)t * wg_per_set + w) * R;
+        if (r0l >= a.n) continue;
         const int r0 = (int)r0l;
         const int nr = a.n - r0 < R ? a.n - r0 : R;
         for (int i = tid; i <= nr; i += kBlock) srp[i] = a.rp[r0 + i];
