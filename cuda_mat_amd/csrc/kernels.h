@@ -29,6 +29,11 @@ struct SpmvPlan {
     int *tile_S = nullptr, *tile_span = nullptr;
     double *tile_heads = nullptr, *tile_tails = nullptr;
     double lane_cost = 0.0;   // lane-iterations of the lanes-per-row kernel / nnz (1 = perfectly balanced)
+    // stream kernel with compressed indices (banded matrices): 16-bit column offsets from the tile's first row,
+    // 8-bit row lengths, one entry offset per tile; owned by the plan
+    short *c_off16 = nullptr;
+    unsigned char *c_len8 = nullptr;
+    int *c_tile_base = nullptr;
 };
 SpmvPlan plan_spmv(int n_rows, int64_t nnz);
 void plan_spmv_free(SpmvPlan *plan);
@@ -62,6 +67,8 @@ struct SpmvArgs {
     ScalarSrc half;
 };
 int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a);
+// stream plans only: build the compressed index copy when every offset fits (no-op otherwise); rp/ci 0-based
+int plan_spmv_compress(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const int *ci, SpmvPlan *plan);
 
 int vec_grid(int64_t n);
 

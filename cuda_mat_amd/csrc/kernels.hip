@@ -370,6 +370,156 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(SpmvArgs a, int tiles_pe
     }
 }
 
+// ---- the same with compressed indices (banded matrices): per entry a 16-bit column offset from the tile's first
+// row instead of a 32-bit column id, per row an 8-bit length instead of a 32-bit row pointer (+ one entry offset per
+// tile).  The stream kernel sits at the mixed-traffic HBM ceiling, so bytes are the only lever: C3 moves 0.81 GB
+// instead of 0.94 GB.  Built once per system by plan_spmv_compress when every offset fits; same arithmetic, same
+// summation order => bit-identical to k_spmv_stream.
+__device__ __forceinline__ int block_scan_int(int v, int *lds_waves, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();                       // lds_waves may still be read from the previous round
+    if (lane == 63) lds_waves[wave] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) {
+        const int t = lds_waves[w];
+        if (w < wave) before += t;
+        all += t;
+    }
+    *total = all;
+    return before + inc - v;
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_spmv_stream_c(SpmvArgs a, int tiles_per_block, const int *tile_base,
+                                                          const short *off16, const unsigned char *len8)
+{
+    __shared__ double prod[kStreamNnz];
+    __shared__ int srp[R + 1];
+    __shared__ int scan_w[kBlock / 64];
+    __shared__ double lds[8];
+    if (a.loop.st) {
+        if (a.check == CHECK_HALF) {
+            if (check_half(a.loop, a.half, lds)) return;
+        } else if (a.loop.st->state != 0) {
+            return;
+        }
+    }
+    const int tid = threadIdx.x;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const bool xcd_split = (nb & 7) == 0;
+    const int wg_per_set = xcd_split ? nb >> 3 : nb;
+    const int set = xcd_split ? (b & 7) : 0;
+    const int w = xcd_split ? (b >> 3) : b;
+    const long long set_tile0 = (long long)set * wg_per_set * tiles_per_block;
+    double acc[2] = {0.0, 0.0};
+    for (int t = 0; t < tiles_per_block; t++) {
+        const long long tile = set_tile0 + (long long)t * wg_per_set + w;
+        const long long r0l = tile * R;
+        if (r0l >= a.n) continue;
+        const int r0 = (int)r0l;
+        const int nr = a.n - r0 < R ? a.n - r0 : R;
+        const int base = tile_base[tile], cnt = tile_base[tile + 1] - base;
+        const int len = tid < nr ? (int)len8[r0 + tid] : 0;
+        int total;
+        const int start = block_scan_int(len, scan_w, &total);
+        if (tid < nr) srp[tid] = start;
+        if (tid == 0) srp[nr] = total;
+        for (int k = tid; k < cnt; k += kBlock)
+            prod[k] = __builtin_nontemporal_load(a.val + base + k) * a.x[r0 + (int)__builtin_nontemporal_load(off16 + base + k)];
+        __syncthreads();
+        if (tid < nr) {
+            const int row = r0 + tid;
+            const int s = srp[tid], e = srp[tid + 1];
+            double sum = 0.0;
+            for (int j = s; j < e; j++) sum += prod[j];
+            if (a.d) sum += a.d[row] * a.xd[row];
+            double out = a.alpha * sum;
+            if (a.beta != 0.0) out += a.beta * a.y[row];
+            a.y[row] = out;
+            if (a.dot) {
+                acc[0] += out * a.w[row];
+                acc[1] += out * out;
+            }
+        }
+        __syncthreads();
+    }
+    if (a.dot) {
+        block_sum<2>(acc, lds);
+        if (tid == 0) {
+            a.parts[2 * b] = acc[0];
+            a.parts[2 * b + 1] = acc[1];
+        }
+    }
+}
+
+// one 8-lane team per row: 8-bit length, 16-bit offsets from the first row of the row's tile; flags[0] = does not fit
+__global__ __launch_bounds__(kBlock) void k_stream_compress(int n, int R, const int *rp, const int *ci, short *off16,
+                                                            unsigned char *len8, int *tile_base, int *flags)
+{
+    constexpr int L = 8;
+    const long long row = ((long long)blockIdx.x * kBlock + threadIdx.x) / L;
+    if (row > n) return;
+    const int lane = threadIdx.x & (L - 1);
+    if (row == n) {                                   // closing entry of the tile table
+        if (lane == 0) tile_base[(n + R - 1) / R] = rp[n] - rp[0];
+        return;
+    }
+    const int s = rp[row], e = rp[row + 1];
+    const int r0 = (int)(row / R) * R;
+    if (lane == 0) {
+        if (e - s > 255) flags[0] = 1;
+        len8[row] = (unsigned char)(e - s);
+        if (row == r0) tile_base[row / R] = s - rp[0];
+    }
+    for (int k = s + lane; k < e; k += L) {
+        const int off = ci[k] - r0;
+        if (off < -32768 || off > 32767) flags[0] = 1;
+        off16[k - rp[0]] = (short)off;
+    }
+}
+
+int plan_spmv_compress(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const int *ci, SpmvPlan *plan)
+{
+    const char *env = getenv("CUDAMAT_SPMV_COMPRESS");
+    if (!plan->stream_rows || nnz <= 0 || (env && env[0] == '0')) return CUDAMAT_OK;
+    const int R = plan->stream_rows;
+    const size_t ntiles = ((size_t)n_rows + R - 1) / R;
+    int *flags = nullptr, h = 0;
+    int rc = CUDAMAT_OK;
+    do {
+        if (hipMalloc((void **)&plan->c_off16, sizeof(short) * (size_t)nnz) != hipSuccess ||
+            hipMalloc((void **)&plan->c_len8, (size_t)n_rows) != hipSuccess ||
+            hipMalloc((void **)&plan->c_tile_base, sizeof(int) * (ntiles + 1)) != hipSuccess ||
+            hipMalloc((void **)&flags, sizeof(int)) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
+        hipMemsetAsync(flags, 0, sizeof(int), s);
+        const long long threads = ((long long)n_rows + 1) * 8;
+        hipLaunchKernelGGL(k_stream_compress, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, R,
+                           rp, ci, plan->c_off16, plan->c_len8, plan->c_tile_base, flags);
+        if (hipMemcpyAsync(&h, flags, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+    } while (0);
+    if (flags) hipFree(flags);
+    if (rc || h) {                                    // does not fit (or no memory): the plain stream kernel stays
+        void *ptrs[] = {plan->c_off16, plan->c_len8, plan->c_tile_base};
+        for (void *q : ptrs)
+            if (q) hipFree(q);
+        plan->c_off16 = nullptr;
+        plan->c_len8 = nullptr;
+        plan->c_tile_base = nullptr;
+        if (rc == CUDAMAT_ERR_HIP) return fail_hip(hipGetLastError(), "index compression", __FILE__, __LINE__);
+    }
+    return CUDAMAT_OK;
+}
+
 // ------------------------------------------------------------ SpMV, skewed row lengths
 // Tiles of kTileNnz consecutive ENTRIES (not rows): every workgroup streams the same number of entries
 // whatever the row-length distribution (a few rows of 1e5 entries among rows of 8 leave the
@@ -592,9 +742,13 @@ __global__ __launch_bounds__(kBlock) void k_lane_cost(int n, const int *rp, int 
 
 void plan_spmv_free(SpmvPlan *plan)
 {
-    void *ptrs[] = {plan->tile_S, plan->tile_span, plan->tile_heads, plan->tile_tails};
+    void *ptrs[] = {plan->tile_S, plan->tile_span, plan->tile_heads, plan->tile_tails, plan->c_off16, plan->c_len8,
+                    plan->c_tile_base};
     for (void *q : ptrs)
         if (q) hipFree(q);
+    plan->c_off16 = nullptr;
+    plan->c_len8 = nullptr;
+    plan->c_tile_base = nullptr;
     plan->tile_S = plan->tile_span = nullptr;
     plan->tile_heads = plan->tile_tails = nullptr;
     plan->tiles = 0;
@@ -729,6 +883,15 @@ int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a)
         if (plan.tile_fix_grid)
             hipLaunchKernelGGL(k_spmv_tiles_fix, dim3(plan.tile_fix_grid), b, 0, s, a, plan.tile_S, plan.tile_span,
                                plan.tile_nspan, plan.tile_heads, plan.tile_tails, plan.grid);
+        CM_HIP(hipGetLastError());
+        return CUDAMAT_OK;
+    }
+    if (plan.stream_rows && plan.c_off16) {
+        switch (plan.stream_rows) {
+        case 64:  hipLaunchKernelGGL(k_spmv_stream_c<64>, g, b, 0, s, a, plan.rows_per_block, plan.c_tile_base, plan.c_off16, plan.c_len8); break;
+        case 128: hipLaunchKernelGGL(k_spmv_stream_c<128>, g, b, 0, s, a, plan.rows_per_block, plan.c_tile_base, plan.c_off16, plan.c_len8); break;
+        default:  hipLaunchKernelGGL(k_spmv_stream_c<256>, g, b, 0, s, a, plan.rows_per_block, plan.c_tile_base, plan.c_off16, plan.c_len8); break;
+        }
         CM_HIP(hipGetLastError());
         return CUDAMAT_OK;
     }

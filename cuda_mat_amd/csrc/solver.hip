@@ -184,6 +184,10 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
         cudamat_solver_destroy(s);
         return rc2;
     }
+    if (int rc3 = plan_spmv_compress(st, n_local, nnz, s->rp, s->ci, &s->plan)) {
+        cudamat_solver_destroy(s);
+        return rc3;
+    }
     *out = s;
     return CUDAMAT_OK;
 }

@@ -895,3 +895,60 @@ def test_lds_resident_trsv_equals_level_kernels(cm, ctx, oracle, golden_dir, nam
     want = oracle.ilu0(A)
     ref = oracle.trsv_upper(A, want, oracle.trsv_lower_unit(A, want, rhs[0]))
     np.testing.assert_allclose(got["1"][0], ref, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["poisson300x210", "banded_ragged", "too_wide", "long_row_255", "base1"])
+def test_stream_spmv_with_compressed_indices(cm, ctx, oracle, case, monkeypatch):
+    """k_spmv_stream_c (16-bit column offsets from the tile's first row, 8-bit row lengths) = k_spmv_stream bit for
+    bit, and exact against the oracle on integer data; matrices whose offsets do not fit keep the plain kernel"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(31)
+    base = 0
+    if case == "poisson300x210":
+        A = oracle.poisson5(300, 210)
+    else:
+        n = 40000
+        if case == "banded_ragged":          # 0..9 entries per row (empty rows too) within +-3000 of the diagonal
+            lens = rng.integers(0, 10, n)
+            width = 3000
+        elif case == "too_wide":             # short rows, columns anywhere: offsets do not fit 16 bits
+            lens = rng.integers(1, 8, n)
+            width = n
+        elif case == "long_row_255":         # one row of exactly 255 entries among rows of 3
+            lens = np.full(n, 3)
+            lens[777] = 255
+            width = 2000
+        else:
+            lens = rng.integers(1, 6, n)
+            width = 500
+            base = 1
+        rows = np.repeat(np.arange(n), lens)
+        cols = np.clip(rows + rng.integers(-width, width + 1, rows.size), 0, n - 1)
+        S = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(n, n))
+        S.sum_duplicates()
+        S.sort_indices()
+        S.data[:] = rng.integers(-3, 4, S.nnz)
+        A = oracle.Csr(n, (S.indptr + base).astype(np.int32), (S.indices + base).astype(np.int32),
+                       S.data.astype(np.float64), n)
+    x = rng.integers(-4, 5, A.n).astype(np.float64)
+    d = rng.integers(-2, 3, A.n).astype(np.float64)
+    want = oracle.spmv(A, x)
+    got = {}
+    for comp in ("0", "1"):
+        monkeypatch.setenv("CUDAMAT_SPMV_COMPRESS", comp)
+        monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
+        got[comp] = (_spmv_via_solver(cm, ctx, A, x), _spmv_via_solver(cm, ctx, A, x, d=d))
+    for comp in got:
+        np.testing.assert_array_equal(got[comp][0], want)
+        np.testing.assert_array_equal(got[comp][1], want + d * x)
+    # inside a solve (fused dots): identical histories with and without the compressed copy
+    if case == "poisson300x210":
+        b = oracle.spmv(A, 1.0 + np.sin(np.arange(A.n)))
+        hist = []
+        for comp in ("0", "1"):
+            monkeypatch.setenv("CUDAMAT_SPMV_COMPRESS", comp)
+            xg, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=400, tol=1e-8)
+            assert st.converged
+            hist.append((xg, h))
+        np.testing.assert_array_equal(hist[0][0], hist[1][0])
+        np.testing.assert_array_equal(hist[0][1], hist[1][1])
