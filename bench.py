@@ -54,7 +54,6 @@ def cpu_baseline(args):
     oracle, faithful threading (SpMV + dot parallel, vector loops serial), timed on this
     host on a bounded sample of the same workload: the first --cpu-rows rows' worth of the
     same generator at the same nnz/row.  BiCG, like BiCGSTAB, costs 2 SpMV per iteration."""
-    import numpy as np
     from oracle import oracle as O
     n = args.cpu_rows
     if args.workload == "poisson5":

@@ -1,5 +1,5 @@
 """ad-hoc: time the SpMV kernels on shard-shaped blocks (n/G rows x n columns) of the 1e7 x 50 matrix on ONE GPU"""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import cuda_mat_amd as cm

@@ -1,5 +1,5 @@
 """ad-hoc: SpMV on skewed row-length distributions: power-law rows, a few huge rows, banded + hubs"""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import cuda_mat_amd as cm

@@ -1,7 +1,6 @@
 """BASELINE.json's full sizes (1e7 rows) through size-independent properties -- the oracle cannot run
 these in seconds, so the checks are: two independent HIP implementations agree bit for bit, linearity
 holds exactly on integer data, and the solve returns the known x* it was built from."""
-import os
 
 import numpy as np
 import pytest
