@@ -1,4 +1,5 @@
-"""soak test (not part of the suite): many random systems through every path, against the oracle"""
+"""soak test (run by hand: python tests/soak.py <seed> <cases>; not collected by pytest): many random systems through
+every path, against the oracle -- lives under tests/ because only test code may use the oracle"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp
