@@ -321,6 +321,12 @@ def run_bench(args):
                            "allgathers": comm.n_allgather, "allreduces": comm.n_allreduce, "backend": backend}
         if precond:
             out["trsv_ms_per_apply"] = ms_trsv / max(n_trsv / 2, 1)
+            if ms_trsv > 0:
+                # one application = L^-1 then U^-1: SURVEY 8d's 12*nnz + 8(n+1) + 32*n algorithmic bytes (nnz of this rank)
+                b_trsv = 12.0 * nnz + 8.0 * (nloc + 1) + 32.0 * nloc
+                gbs = b_trsv / (out["trsv_ms_per_apply"] * 1e-3) / 1e9
+                out["trsv_roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_application": b_trsv}
             out["levels"] = [st.n_levels_l, st.n_levels_u]
             # one-off setup (outside the timed region): level analysis of L and U; ILU(0) + factor layout + far/near split
             out["setup_s"] = {"analysis": st.t_analysis, "factor": st.t_factor}
