@@ -952,3 +952,33 @@ def test_stream_spmv_with_compressed_indices(cm, ctx, oracle, case, monkeypatch)
             hist.append((xg, h))
         np.testing.assert_array_equal(hist[0][0], hist[1][0])
         np.testing.assert_array_equal(hist[0][1], hist[1][1])
+
+
+@pytest.mark.parametrize("n,longest", [(3000, 1300), (3000, 2500)])
+def test_ilu0_very_long_rows(cm, ctx, oracle, n, longest):
+    """a maximum row length above 1024 entries selects k_ilu0_level<4> (LDS slice per wave), above 2048 the
+    one-wave-per-workgroup launch; factors and L^-1 U^-1 against the oracle.  (A few dense rows among sparse
+    ones keep the oracle's O(sum len^2) factorisation cheap.)"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(17)
+    S = sp.random(n, n, 0.003, random_state=5, format="lil")
+    for r in (n - 1, n - 7, n // 2):
+        cols = rng.choice(n, size=longest, replace=False)
+        S[r, cols] = rng.uniform(-1, 1, longest)
+    S = S.tocsr()
+    S.setdiag(0)
+    S.eliminate_zeros()
+    S = (S + sp.diags(1.0 + np.asarray(abs(S).sum(axis=1)).ravel())).tocsr()
+    S.sort_indices()
+    A = oracle.Csr(n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy(), n)
+    assert np.diff(A.rowptr).max() > (1024 if longest < 2048 else 2048)
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+    s.ilu0()
+    want = oracle.ilu0(A)
+    np.testing.assert_allclose(s.ilu0_values(), want, rtol=1e-11, atol=1e-13)
+    rhs = rng.standard_normal(n)
+    dr, do = ctx.array(rhs), ctx.empty(n)
+    s.precond_apply(dr, do)
+    ref = oracle.trsv_upper(A, want, oracle.trsv_lower_unit(A, want, rhs))
+    np.testing.assert_allclose(do.download(), ref, rtol=1e-9, atol=1e-11)
+    s.close()
