@@ -7,11 +7,19 @@
 //                                            shares A's pattern (:316,:357-358), no pivoting
 //   cusparseDcsrsv_solve x4 / iteration    -> t = L^-1 y (unit diagonal), U^-1 t (:92-98,:121-127)
 //
-// MI355X design: rows are grouped by dependency level; L and U are re-stored in LEVEL-MAJOR
-// order (rows of one level contiguous, own rowptr/colidx/values, 1/diag precomputed for U), so a
-// triangular solve is a sequence of SpMV-shaped launches that stream contiguous HBM: one launch
-// per large level, and ONE single-workgroup launch for every run of consecutive small levels
-// (workgroup barrier between levels) so that banded matrices do not pay a launch per level.
+// MI355X design: rows are grouped by dependency level (one dependency-driven pass, k_levels_dep); L and U are
+// re-stored in LEVEL-MAJOR order (rows of one level contiguous, own rowptr/colidx/values, 1/diag precomputed for
+// U).  A triangular solve then takes the form that fits the factor:
+//   * k_trsv_syncfree   one launch per GROUP of levels; rows wait inside the launch for the values they depend on
+//                       (bounded polls of a "not ready" bit pattern) -- default when a level is wider than 512 rows;
+//                       residency is throttled when the work per level is small (pollers slow the hand-offs);
+//   * hybrid split      big factors with scattered columns: entries whose column lies in an EARLIER group go
+//                       through one blocked two-phase SpMV per group (streams), only the rest is gathered;
+//   * k_trsv_lds        n <= 16384 with narrow levels: one workgroup, solution vector in LDS, barrier per level;
+//   * k_trsv_level / k_trsv_small_levels   one launch per level / one single-workgroup launch per run of small
+//                       levels -- the reference form the others are bit-identical to, and the fallback when a
+//                       dependency-driven solve times out (another spinning kernel on the same GPU).
+// Block-Jacobi (row-sharded runs): the same machinery on the rank's diagonal block (select_precond_matrix).
 // Algorithmic bytes per preconditioner application: 12 nnz + 8 (n+1) + 32 n.
 #include <algorithm>
 #include <chrono>
