@@ -69,7 +69,14 @@ def cpu_baseline(args):
     dt = time.perf_counter() - t0
     it = max(it, 1)
     scale = args.rows / float(n)
+    # like for like: the oracle's restatement of the GPU loop (BiCGSTAB, pbicgstab.cu:581-754) on the same
+    # sample; tol = 0 never triggers, so exactly cpu_iters iterations run
+    t1 = time.perf_counter()
+    _, _, st2 = O.pbicgstab2(A, b, maxit=args.cpu_iters, tol=0.0)
+    dt2 = time.perf_counter() - t1
     return {
+        "bicgstab_port": {"value": max(st2.iters, 1) / dt2 / scale, "unit": "iter/s",
+                          "sample": "oracle BiCGSTAB restatement, %d iterations on the same sample" % max(st2.iters, 1)},
         "value": it / dt / scale, "unit": "iter/s", "cores": O.num_threads(), "kind": "port",
         "sample": "oracle BiCG restatement of bicstab_omp (2 SpMV/iter; SpMV+dot OpenMP, vector loops "
                   "serial as in the reference), %d iterations (incl. its A^T build) on a %d-row x %d nnz/row "
