@@ -67,6 +67,21 @@ struct SpmvArgs {
     ScalarSrc half;
 };
 int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a);
+
+// fused loop of small systems: the SpMV computes its input vector on the fly (kernels.hip, "fused loop")
+struct FuseArgs {
+    int mode;                              // 1: p' = r + beta (p - omega v);  2: s = r - alpha v
+    const double *r;
+    const double *p_old, *v_old;           // mode 1 inputs
+    double *p_out;                         // mode 1: p' stored by the row owners
+    const double *v;                       // mode 2 input (the v just computed)
+    double *s_out, *xsol;                  // mode 2: s stored by the row owners, x += alpha p'
+    const double *p;
+    ScalarSrc src;                         // mode 1: (rw.r, ||r||^2) partials;  mode 2: rw.v partials
+    double *parts_half;                    // mode 2: ||s||^2 partial of every workgroup
+};
+bool fused_spmv_supported(const SpmvPlan &plan);
+int launch_fused_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, const FuseArgs &f);
 // stream plans only: build the compressed index copy when every offset fits (no-op otherwise); rp/ci 0-based
 int plan_spmv_compress(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const int *ci, SpmvPlan *plan);
 
@@ -84,8 +99,10 @@ int launch_update_p(hipStream_t s, LoopArgs la, ScalarSrc full, int64_t n, const
 int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, const double *v,
                 double *x, const double *pw, double *parts, int *nparts);
 // omega = (t.r)/(t.t); x += omega s; r -= omega t; parts = (rw.r, r.r); it++
+// half.ptr != NULL: evaluate the half-step stopping test from `half` first (fused small-system loop)
 int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, const double *sv,
-                double *r, const double *t, const double *rw, double *parts, int *nparts);
+                double *r, const double *t, const double *rw, double *parts, int *nparts,
+                ScalarSrc half = ScalarSrc{nullptr, 0, 1});
 // standalone stopping tests (one workgroup)
 int launch_check(hipStream_t s, LoopArgs la, ScalarSrc src, int which);
 // out[k] = sum of partials, k < K (one workgroup)

@@ -1106,12 +1106,16 @@ int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, 
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_full(LoopArgs la, ScalarSrc tt, int64_t n, double *x,
                                                  const double *sv, double *r, const double *t,
-                                                 const double *rw, double *parts)
+                                                 const double *rw, double *parts, ScalarSrc half)
 {
     __shared__ double lds[8];
     LoopState *st = la.st;
     if (st->state != 0) {             // frozen: still tell the host this iteration's launches have drained
         publish_progress(la, st->state);
+        return;
+    }
+    if (half.ptr && check_half(la, half, lds)) {   // fused small-system loop: the half-step test is evaluated here
+        publish_progress(la, 1);
         return;
     }
     double sc[2];
@@ -1153,14 +1157,201 @@ __global__ __launch_bounds__(kBlock) void k_full(LoopArgs la, ScalarSrc tt, int6
 }
 
 int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, const double *sv,
-                double *r, const double *t, const double *rw, double *parts, int *nparts)
+                double *r, const double *t, const double *rw, double *parts, int *nparts, ScalarSrc half)
 {
     const int g = vec_grid(n);
     *nparts = g;
     if (aligned16(x) && aligned16(sv) && aligned16(r) && aligned16(t) && aligned16(rw))
-        hipLaunchKernelGGL(k_full<1>, dim3(g), dim3(kBlock), 0, s, la, tt, n, x, sv, r, t, rw, parts);
+        hipLaunchKernelGGL(k_full<1>, dim3(g), dim3(kBlock), 0, s, la, tt, n, x, sv, r, t, rw, parts, half);
     else
-        hipLaunchKernelGGL(k_full<0>, dim3(g), dim3(kBlock), 0, s, la, tt, n, x, sv, r, t, rw, parts);
+        hipLaunchKernelGGL(k_full<0>, dim3(g), dim3(kBlock), 0, s, la, tt, n, x, sv, r, t, rw, parts, half);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// ---------------------------------------------------------------- fused loop for small (L2-resident) systems
+// Below ~1e5 rows an iteration is five launches of 3-5 us each: launch boundaries, not bytes.  Here the vector
+// update in front of each SpMV is folded INTO the SpMV: the kernel computes the input vector on the fly at the
+// columns it gathers (three / two cheap L2 gathers instead of one) and the owner of a row also stores it, so one
+// iteration is three launches:
+//   k_fspmv<.., FUSE_P>     rho, beta, full-step test; p' = r + beta (p - omega v) on the fly; v' = A p';  rw.v'
+//   k_fspmv<.., FUSE_HALF>  alpha; s = r - alpha v' on the fly; x += alpha p'; t = A s;  (t.s, t.t), ||s||^2
+//   k_full                  half-step test, omega, x += omega s, r = s - omega t, (rw.r, ||r||^2)
+// p, v and r are double-buffered (a workgroup may still gather the old vector while another stores the new one).
+// Every value is produced by the same expression as in k_update_p / k_half, so iterates agree with the five-launch
+// loop up to the summation order of ||s||^2 (per SpMV workgroup here, per vector chunk there).
+enum { FUSE_P = 1, FUSE_HALF = 2 };
+
+template <int MODE>
+struct FusedX {
+    const double *r, *b1, *b2;     // FUSE_P: b1 = p, b2 = v;  FUSE_HALF: b1 = v
+    double c1, c2;                 // FUSE_P: beta, -omega;    FUSE_HALF: -alpha
+    bool first;                    // FUSE_P at iteration 0: p = r already (k_init)
+    __device__ __forceinline__ double operator()(int c) const
+    {
+        if (MODE == FUSE_P) {
+            if (first) return b1[c];
+            double pp = fma(c2, b2[c], b1[c]);                 // pbicgstab.cu:86
+            pp = c1 * pp;                                      // :87
+            return r[c] + pp;                                  // :88
+        }
+        return fma(c1, b1[c], r[c]);                           // :109
+    }
+};
+
+// common prologue: the scalars of the folded vector kernel; false = this launch is frozen / the loop has stopped
+template <int MODE>
+__device__ __forceinline__ bool fused_prologue(const LoopArgs &la, const FuseArgs &f, double *lds, FusedX<MODE> &X,
+                                               double &alpha_out)
+{
+    LoopState *st = la.st;
+    if (st->state != 0) return false;
+    const int it = st->it;
+    X.r = f.r;
+    if (MODE == FUSE_P) {
+        double sc[2];
+        load_scalars<2>(f.src, sc, lds);
+        if (check_full(la, sc)) return false;
+        const double rho = sc[0];
+        const double rhop = st->rho[(it + 1) & 1];
+        const double alpha = st->alpha, omega = st->omega;
+        if (leader()) st->rho[it & 1] = rho;
+        X.first = it == 0;
+        X.b1 = f.p_old;
+        X.b2 = f.v_old;
+        X.c1 = (rho / rhop) * (alpha / omega);                 // :84 (unused at it == 0)
+        X.c2 = -omega;
+        alpha_out = 0.0;
+    } else {
+        double sc[1];
+        load_scalars<1>(f.src, sc, lds);
+        const double alpha = st->rho[it & 1] / sc[0];          // :107
+        if (leader()) st->alpha = alpha;
+        X.first = false;
+        X.b1 = f.v;
+        X.b2 = nullptr;
+        X.c1 = -alpha;
+        X.c2 = 0.0;
+        alpha_out = alpha;
+    }
+    return true;
+}
+
+// what the owner of `row` does once its sum is known
+template <int MODE>
+__device__ __forceinline__ void fused_finish_row(const SpmvArgs &a, const FuseArgs &f, const FusedX<MODE> &X, double alpha,
+                                                 int row, double sum, double (&acc)[3])
+{
+    const double xr = X(row);
+    if (a.d) sum += a.d[row] * xr;
+    a.y[row] = sum;                                            // alpha = 1, beta = 0 inside the loop
+    if (MODE == FUSE_P) {
+        f.p_out[row] = xr;
+        acc[0] += sum * a.w[row];                              // rw . v
+    } else {
+        f.s_out[row] = xr;
+        f.xsol[row] = fma(alpha, f.p[row], f.xsol[row]);       // :110
+        acc[0] += sum * xr;                                    // t . s
+        acc[1] += sum * sum;                                   // t . t
+        acc[2] += xr * xr;                                     // ||s||^2 (:111)
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void fused_store_parts(const SpmvArgs &a, const FuseArgs &f, double (&acc)[3], double *lds)
+{
+    block_sum<3>(acc, lds);
+    if (threadIdx.x == 0) {
+        a.parts[2 * blockIdx.x] = acc[0];
+        a.parts[2 * blockIdx.x + 1] = acc[1];
+        if (MODE == FUSE_HALF) f.parts_half[blockIdx.x] = acc[2];
+    }
+}
+
+template <int L, int MODE>
+__global__ __launch_bounds__(kBlock) void k_fspmv_lanes(SpmvArgs a, int rows_per_block, FuseArgs f)
+{
+    __shared__ double lds[12];
+    FusedX<MODE> X;
+    double alpha;
+    if (!fused_prologue<MODE>(a.loop, f, lds, X, alpha)) return;
+    constexpr int RPB = kBlock / L;
+    const int lane = threadIdx.x & (L - 1);
+    const int group = threadIdx.x / L;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const int row_begin = (int)(r0 < a.n ? r0 : a.n);
+    const int row_end = (int)(r0 + rows_per_block < a.n ? r0 + rows_per_block : a.n);
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int row = row_begin + group; row < row_end; row += RPB) {
+        const int s = a.rp[row], e = a.rp[row + 1];
+        double sum = 0.0;
+        for (int k = s + lane; k < e; k += L) sum += a.val[k] * X(a.ci[k]);
+        sum = group_sum<L>(sum);
+        if (lane == 0) fused_finish_row<MODE>(a, f, X, alpha, row, sum, acc);
+    }
+    fused_store_parts<MODE>(a, f, acc, lds);
+}
+
+template <int R, int MODE>
+__global__ __launch_bounds__(kBlock) void k_fspmv_stream(SpmvArgs a, int tiles_per_block, FuseArgs f)
+{
+    __shared__ double prod[kStreamNnz];
+    __shared__ int srp[R + 1];
+    __shared__ double lds[12];
+    FusedX<MODE> X;
+    double alpha;
+    if (!fused_prologue<MODE>(a.loop, f, lds, X, alpha)) return;
+    const int tid = threadIdx.x;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int t = 0; t < tiles_per_block; t++) {
+        const long long r0l = ((long long)blockIdx.x * tiles_per_block + t) * R;
+        if (r0l >= a.n) break;
+        const int r0 = (int)r0l;
+        const int nr = a.n - r0 < R ? a.n - r0 : R;
+        for (int i = tid; i <= nr; i += kBlock) srp[i] = a.rp[r0 + i];
+        __syncthreads();
+        const int base = srp[0];
+        const int cnt = srp[nr] - base;
+        for (int k = tid; k < cnt; k += kBlock) prod[k] = a.val[base + k] * X(a.ci[base + k]);
+        __syncthreads();
+        if (tid < nr) {
+            const int s = srp[tid] - base, e = srp[tid + 1] - base;
+            double sum = 0.0;
+            for (int j = s; j < e; j++) sum += prod[j];
+            fused_finish_row<MODE>(a, f, X, alpha, r0 + tid, sum, acc);
+        }
+        __syncthreads();
+    }
+    fused_store_parts<MODE>(a, f, acc, lds);
+}
+
+bool fused_spmv_supported(const SpmvPlan &plan) { return plan.tiles == 0; }
+
+int launch_fused_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, const FuseArgs &f)
+{
+    dim3 g(plan.grid), b(kBlock);
+#define CM_FS(KERNEL, PARAM)                                                                          \
+    do {                                                                                              \
+        if (f.mode == FUSE_P) hipLaunchKernelGGL((KERNEL<PARAM, FUSE_P>), g, b, 0, s, a, plan.rows_per_block, f);      \
+        else hipLaunchKernelGGL((KERNEL<PARAM, FUSE_HALF>), g, b, 0, s, a, plan.rows_per_block, f);                    \
+    } while (0)
+    if (plan.stream_rows) {
+        switch (plan.stream_rows) {
+        case 64:  CM_FS(k_fspmv_stream, 64); break;
+        case 128: CM_FS(k_fspmv_stream, 128); break;
+        default:  CM_FS(k_fspmv_stream, 256); break;
+        }
+    } else {
+        switch (plan.lanes) {
+        case 2:  CM_FS(k_fspmv_lanes, 2); break;
+        case 4:  CM_FS(k_fspmv_lanes, 4); break;
+        case 8:  CM_FS(k_fspmv_lanes, 8); break;
+        case 16: CM_FS(k_fspmv_lanes, 16); break;
+        case 32: CM_FS(k_fspmv_lanes, 32); break;
+        default: CM_FS(k_fspmv_lanes, 64); break;
+        }
+    }
+#undef CM_FS
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }

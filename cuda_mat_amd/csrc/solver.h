@@ -43,6 +43,7 @@ struct cudamat_solver {
            *v = nullptr;
     double *gather = nullptr;  // world * n_pad doubles (sharded runs)
     double *x0_save = nullptr; // the caller's x0, kept while a dependency-driven preconditioner may have to be redone
+    double *v2 = nullptr;      // second v buffer of the fused small-system loop (p and r double-buffer in pw and s)
 
     // reduction workspace: four stages of per-workgroup partials + reduced scalars
     double *parts_full = nullptr, *parts_rv = nullptr, *parts_half = nullptr, *parts_tt = nullptr;

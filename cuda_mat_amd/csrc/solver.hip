@@ -17,6 +17,7 @@
 //   * row-sharded operation: the same loop, with the SpMV input gathered and the
 //     scalar partials all-reduced through caller-supplied collectives (RCCL).
 #include <chrono>
+#include <utility>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,7 +44,7 @@ static int dev_alloc(void **p, size_t bytes)
 
 static void free_work(cudamat_solver *s)
 {
-    double **vs[] = {&s->r, &s->rw, &s->p, &s->pw, &s->s, &s->t, &s->v, &s->gather, &s->x0_save};
+    double **vs[] = {&s->r, &s->rw, &s->p, &s->pw, &s->s, &s->t, &s->v, &s->gather, &s->x0_save, &s->v2};
     for (double **q : vs) {
         if (*q) hipFree(*q);
         *q = nullptr;
@@ -459,6 +460,27 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     }
     CM_TRY(launch_init_finish(st, s->st, full_src, tol));
 
+    // Small systems (vectors resident in L2): three launches per iteration instead of five -- the vector updates
+    // in front of the two SpMVs are folded into them (kernels.hip, "fused loop"); p, v and r are double-buffered.
+    bool fused = false;
+    {
+        // Measured (bench.py, one MI355X): 5-point stencil rows 38.5 -> 46.3 k it/s at 1e4 rows, 37.7 -> 43.8 k at 4e4,
+        // 30.4 -> 32.1 k at 1.6e5, even at 4.9e5, slower beyond; with 50 entries per row the three gathers per entry
+        // cost more than the two launches save (29.9 -> 24.1 k it/s at 2e4 rows).  So: short rows (the stream-tile
+        // plan) up to 3e5 rows.  CUDAMAT_FUSED=0 disables, CUDAMAT_FUSED=N forces it for every supported plan up to N rows.
+        const char *fe = getenv("CUDAMAT_FUSED");
+        const bool forced = fe && fe[0] != '\0';
+        const long long max_rows = forced ? atoll(fe) : 300000;
+        fused = !sharded && !precond && s->spmv_mode == 0 && fused_spmv_supported(s->plan) && n > 0 && n <= max_rows &&
+                (forced || s->plan.stream_rows > 0);
+        if (fused && !s->v2) {
+            const size_t nb = sizeof(double) * (size_t)(s->n_pad > 0 ? s->n_pad : 1);
+            CM_TRY(dev_alloc((void **)&s->v2, nb));
+            CM_HIP(hipMemsetAsync(s->v2, 0, nb, st));
+        }
+    }
+    double *p_a = s->p, *p_b = s->pw, *v_a = s->v, *v_b = s->v2;
+
     int k = 0;
     for (; k < maxit; k++) {
         if (k >= kLag) {   // lagged, deterministic look at the device state: the progress word of
@@ -478,6 +500,35 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             if ((unsigned)(w & 0xffffffffULL) != 0u) break;
         }
         la.k = k;
+        if (fused) {
+            SpmvArgs a{};
+            a.n = n; a.rp = s->rp; a.ci = s->ci; a.val = s->val; a.x = nullptr; a.d = s->d; a.xd = nullptr;
+            a.alpha = 1.0; a.beta = 0.0; a.loop = la; a.check = CHECK_NONE; a.half = nosrc;
+            const int np = plan_spmv_parts(s->plan);
+            // rho, beta, full-step test, p' = r + beta (p - omega v), v' = A p', rw.v'            :80-89, :104-106
+            FuseArgs f1{};
+            f1.mode = 1; f1.r = s->r; f1.p_old = p_a; f1.v_old = v_a; f1.p_out = p_b; f1.src = full_src;
+            a.y = v_b; a.dot = 1; a.w = s->rw; a.parts = s->parts_rv;
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            CM_TRY(launch_fused_spmv(st, s->plan, a, f1));
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            // alpha, s = r - alpha v', x += alpha p', t = A s, (t.s, t.t), ||s||^2                :107-111, :132-136
+            FuseArgs f2{};
+            f2.mode = 2; f2.r = s->r; f2.v = v_b; f2.s_out = s->s; f2.xsol = x; f2.p = p_b;
+            f2.src = ScalarSrc{s->parts_rv, np, 2}; f2.parts_half = s->parts_half;
+            a.y = s->t; a.dot = 2; a.w = nullptr; a.parts = s->parts_tt;
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            CM_TRY(launch_fused_spmv(st, s->plan, a, f2));
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            // half-step test, omega, x += omega s, r = s - omega t, (rw.r, ||r||^2), i++          :116, :137-151
+            CM_TRY(launch_full(st, la, ScalarSrc{s->parts_tt, np, 2}, n, x, s->s, s->s, s->t, s->rw, s->parts_full, &np_full,
+                               ScalarSrc{s->parts_half, np, 1}));
+            full_src = ScalarSrc{s->parts_full, np_full, 2};
+            std::swap(p_a, p_b);
+            std::swap(v_a, v_b);
+            std::swap(s->r, s->s);        // the new residual was written over s
+            continue;
+        }
         // rho, beta, p = r + beta (p - omega v)                     :80-89
         CM_TRY(launch_update_p(st, la, full_src, n, s->r, s->p, s->v));
         const double *pw = s->p;
