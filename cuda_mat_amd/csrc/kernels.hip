@@ -1298,21 +1298,54 @@ __global__ __launch_bounds__(kBlock) void k_fspmv_stream(SpmvArgs a, int tiles_p
     __shared__ double prod[kStreamNnz];
     __shared__ int srp[R + 1];
     __shared__ double lds[12];
+    constexpr int E = kStreamNnz / kBlock;
+    const int tid = threadIdx.x;
+    // The first tile's row pointers and entries do not depend on the loop scalars: fetch them BEFORE the prologue
+    // (partial sums -> rho, beta / alpha), so the two dependent round trips overlap instead of adding up.
+    const long long first_row = (long long)blockIdx.x * tiles_per_block * R;
+    double v0[E];
+    int c0[E];
+    int nr0 = 0, base0 = 0, cnt0 = 0;
+    if (first_row < a.n) {
+        const int r0 = (int)first_row;
+        nr0 = a.n - r0 < R ? a.n - r0 : R;
+        for (int i = tid; i <= nr0; i += kBlock) srp[i] = a.rp[r0 + i];
+        __syncthreads();
+        base0 = srp[0];
+        cnt0 = srp[nr0] - base0;
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int k = tid + j * kBlock;
+            if (k < cnt0) {
+                v0[j] = a.val[base0 + k];
+                c0[j] = a.ci[base0 + k];
+            }
+        }
+    }
     FusedX<MODE> X;
     double alpha;
     if (!fused_prologue<MODE>(a.loop, f, lds, X, alpha)) return;
-    const int tid = threadIdx.x;
     double acc[3] = {0.0, 0.0, 0.0};
     for (int t = 0; t < tiles_per_block; t++) {
-        const long long r0l = ((long long)blockIdx.x * tiles_per_block + t) * R;
+        const long long r0l = first_row + (long long)t * R;
         if (r0l >= a.n) break;
         const int r0 = (int)r0l;
-        const int nr = a.n - r0 < R ? a.n - r0 : R;
-        for (int i = tid; i <= nr; i += kBlock) srp[i] = a.rp[r0 + i];
-        __syncthreads();
-        const int base = srp[0];
-        const int cnt = srp[nr] - base;
-        for (int k = tid; k < cnt; k += kBlock) prod[k] = a.val[base + k] * X(a.ci[base + k]);
+        int nr, base, cnt;
+        if (t == 0) {
+            nr = nr0; base = base0; cnt = cnt0;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int k = tid + j * kBlock;
+                if (k < cnt) prod[k] = v0[j] * X(c0[j]);
+            }
+        } else {
+            nr = a.n - r0 < R ? a.n - r0 : R;
+            for (int i = tid; i <= nr; i += kBlock) srp[i] = a.rp[r0 + i];
+            __syncthreads();
+            base = srp[0];
+            cnt = srp[nr] - base;
+            for (int k = tid; k < cnt; k += kBlock) prod[k] = a.val[base + k] * X(a.ci[base + k]);
+        }
         __syncthreads();
         if (tid < nr) {
             const int s = srp[tid] - base, e = srp[tid + 1] - base;
