@@ -1238,19 +1238,39 @@ __device__ __forceinline__ bool fused_prologue(const LoopArgs &la, const FuseArg
 }
 
 // what the owner of `row` does once its sum is known
+// operands of the row owner's last step that do not depend on the loop scalars (fetched early where possible)
+struct FusedRowOps {
+    double w, p, x, d;
+};
+
+template <int MODE>
+__device__ __forceinline__ FusedRowOps fused_row_ops(const SpmvArgs &a, const FuseArgs &f, int row)
+{
+    FusedRowOps o;
+    o.w = 0.0; o.p = 0.0; o.x = 0.0;
+    o.d = a.d ? a.d[row] : 0.0;
+    if (MODE == FUSE_P) {
+        o.w = a.w[row];
+    } else {
+        o.p = f.p[row];
+        o.x = f.xsol[row];
+    }
+    return o;
+}
+
 template <int MODE>
 __device__ __forceinline__ void fused_finish_row(const SpmvArgs &a, const FuseArgs &f, const FusedX<MODE> &X, double alpha,
-                                                 int row, double sum, double (&acc)[3])
+                                                 int row, double sum, const FusedRowOps &o, double (&acc)[3])
 {
     const double xr = X(row);
-    if (a.d) sum += a.d[row] * xr;
+    if (a.d) sum += o.d * xr;
     a.y[row] = sum;                                            // alpha = 1, beta = 0 inside the loop
     if (MODE == FUSE_P) {
         f.p_out[row] = xr;
-        acc[0] += sum * a.w[row];                              // rw . v
+        acc[0] += sum * o.w;                                   // rw . v
     } else {
         f.s_out[row] = xr;
-        f.xsol[row] = fma(alpha, f.p[row], f.xsol[row]);       // :110
+        f.xsol[row] = fma(alpha, o.p, o.x);                    // :110
         acc[0] += sum * xr;                                    // t . s
         acc[1] += sum * sum;                                   // t . t
         acc[2] += xr * xr;                                     // ||s||^2 (:111)
@@ -1287,7 +1307,7 @@ __global__ __launch_bounds__(kBlock) void k_fspmv_lanes(SpmvArgs a, int rows_per
         double sum = 0.0;
         for (int k = s + lane; k < e; k += L) sum += a.val[k] * X(a.ci[k]);
         sum = group_sum<L>(sum);
-        if (lane == 0) fused_finish_row<MODE>(a, f, X, alpha, row, sum, acc);
+        if (lane == 0) fused_finish_row<MODE>(a, f, X, alpha, row, sum, fused_row_ops<MODE>(a, f, row), acc);
     }
     fused_store_parts<MODE>(a, f, acc, lds);
 }
@@ -1322,6 +1342,9 @@ __global__ __launch_bounds__(kBlock) void k_fspmv_stream(SpmvArgs a, int tiles_p
             }
         }
     }
+    FusedRowOps ops0;
+    ops0.w = ops0.p = ops0.x = ops0.d = 0.0;
+    if (tid < nr0) ops0 = fused_row_ops<MODE>(a, f, (int)first_row + tid);
     FusedX<MODE> X;
     double alpha;
     if (!fused_prologue<MODE>(a.loop, f, lds, X, alpha)) return;
@@ -1351,7 +1374,7 @@ __global__ __launch_bounds__(kBlock) void k_fspmv_stream(SpmvArgs a, int tiles_p
             const int s = srp[tid] - base, e = srp[tid + 1] - base;
             double sum = 0.0;
             for (int j = s; j < e; j++) sum += prod[j];
-            fused_finish_row<MODE>(a, f, X, alpha, r0 + tid, sum, acc);
+            fused_finish_row<MODE>(a, f, X, alpha, r0 + tid, sum, t == 0 ? ops0 : fused_row_ops<MODE>(a, f, r0 + tid), acc);
         }
         __syncthreads();
     }
