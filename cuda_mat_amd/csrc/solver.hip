@@ -428,7 +428,10 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     if (precond && (!s->has_ilu || (s->sharded && !s->ilu_block)))
         CM_TRY(ilu0_setup(s, precond == CUDAMAT_PRECOND_BLOCK_ILU0));
 
-    const int need_hist = (loop == CUDAMAT_LOOP_PBICGSTAB ? 2 : 1) * (maxit > 0 ? maxit : 1);
+    // residual history: two entries per iteration (half / full step) or one; capped at 2^20 entries (8 MB) -- a solve
+    // with a larger maxit keeps the first 2^20 (the kernels check the capacity)
+    const long long want_hist = (long long)(loop == CUDAMAT_LOOP_PBICGSTAB ? 2 : 1) * (maxit > 0 ? maxit : 1);
+    const int need_hist = (int)(want_hist < (1LL << 20) ? want_hist : (1LL << 20));
     if (need_hist > s->hist_cap) {
         if (s->hist) { CM_HIP(hipStreamSynchronize(st)); hipFree(s->hist); s->hist = nullptr; }
         CM_TRY(dev_alloc((void **)&s->hist, sizeof(double) * (size_t)need_hist));

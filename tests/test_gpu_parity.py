@@ -1022,3 +1022,13 @@ def test_fused_small_system_loop_equals_five_launch_loop(cm, ctx, oracle, golden
     else:
         assert abs(st0.iters - st1.iters) <= max(2, st0.iters // 10)
     np.testing.assert_allclose(x1, xs, rtol=1e-6)
+
+
+def test_huge_maxit_does_not_allocate_a_huge_history(cm, ctx, oracle, golden_dir):
+    """maxit = 2^30 (a caller's 'no limit'): the residual history is capped at 2^20 entries instead of 16 GB"""
+    A = _load(oracle, golden_dir, "mat900")
+    b = oracle.spmv(A, 1.0 + np.sin(np.arange(A.n)))
+    x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=2 ** 30, tol=1e-8)
+    assert st.converged and st.iters < 100 and len(h) <= 2 * st.iters + 1
+    xo, so = oracle.pbicgstab(A, b, maxit=2000, tol=1e-8)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5
