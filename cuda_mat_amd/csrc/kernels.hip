@@ -984,7 +984,9 @@ __global__ __launch_bounds__(kBlock) void k_init_finish(LoopState *st, ScalarSrc
     load_scalars<2>(init, sc, lds);
     if (threadIdx.x == 0) {
         const double nrm0 = sqrt(sc[1]);           // pbicgstab.cu:74 / :655
-        st->state = 0;
+        // x0 already solves the system exactly (r0 = 0): the reference's loop would divide 0 by 0 and hand back NaNs;
+        // here the loop starts frozen in the 'converged' state and x0 is returned untouched
+        st->state = nrm0 == 0.0 ? 2 : 0;
         st->it = 0;
         st->rho[0] = 1.0;                          // pbicgstab.cu:617 (rho = 1)
         st->rho[1] = 1.0;

@@ -1032,3 +1032,17 @@ def test_huge_maxit_does_not_allocate_a_huge_history(cm, ctx, oracle, golden_dir
     assert st.converged and st.iters < 100 and len(h) <= 2 * st.iters + 1
     xo, so = oracle.pbicgstab(A, b, maxit=2000, tol=1e-8)
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5
+
+
+@pytest.mark.parametrize("precond", [0, 1])
+def test_exact_initial_guess_returns_at_once(cm, ctx, oracle, precond):
+    """r0 = 0 (x0 already solves the system): converged, 0 iterations, x0 untouched -- where the reference's loop
+    (and the oracle's restatement of it) divides 0 by 0 and returns NaNs; a deliberate difference"""
+    A = oracle.rand_rows(500, 10, 3)
+    b = oracle.spmv(A, np.ones(A.n))
+    for loop in (cm.LOOP_PBICGSTAB, cm.LOOP_PBICGSTAB2):
+        if precond and loop == cm.LOOP_PBICGSTAB2:
+            continue
+        x, st, h = _solve_dev(cm, ctx, A, b, precond=precond, loop=loop, maxit=50, tol=1e-8)
+        assert st.converged and st.iters == 0 and not st.breakdown and st.nrm0 == 0.0
+        np.testing.assert_array_equal(x, np.ones(A.n))
