@@ -496,14 +496,17 @@ def test_degenerate_systems(cm, ctx, oracle):
     assert ok and np.allclose(x, b / dg, rtol=1e-10)
     ok, x, dt, st = cm.bicgstab_lu_precond(n, n, dg, rp, ci, b, 50, 1e-12)
     assert st.converged and st.iters <= 1 and np.allclose(x, b / dg, rtol=1e-12)
-    # x0 already solves the system: r0 = 0, tol*||r0|| = 0, rho = 0 -> the reference's loop divides
-    # 0/0 and runs to maxit (pbicgstab.cu:81,107 have no guard); it must terminate and report failure
+    # x0 already solves the system: r0 = 0, tol*||r0|| = 0, rho = 0 -> the reference's loop divides 0/0 and runs to
+    # maxit with NaNs (pbicgstab.cu:81,107 have no guard; the oracle restates that).  Deliberate difference
+    # (DESIGN.md section 1): here the loop starts frozen, x0 comes back untouched and the solve reports convergence
     A = oracle.poisson5(20, 20)
     b1 = oracle.spmv(A, np.ones(A.n))
-    x, st, h = _solve_dev(cm, ctx, A, b1, loop=cm.LOOP_PBICGSTAB, maxit=7, tol=1e-8)
-    assert st.iters == 7 and not st.converged and st.nrm0 == 0.0
-    x, st, h = _solve_dev(cm, ctx, A, b1, loop=cm.LOOP_PBICGSTAB2, maxit=7, tol=1e-8)
-    assert not st.converged and st.breakdown and st.iters == 1          # NaN omega trips the guard (:735)
+    xo, so = oracle.pbicgstab(A, b1, maxit=7, tol=1e-8)
+    assert not so.converged and not np.isfinite(xo).all()              # what upstream does
+    for lp in (cm.LOOP_PBICGSTAB, cm.LOOP_PBICGSTAB2):
+        x, st, h = _solve_dev(cm, ctx, A, b1, loop=lp, maxit=7, tol=1e-8)
+        assert st.iters == 0 and st.converged and not st.breakdown and st.nrm0 == 0.0
+        np.testing.assert_array_equal(x, np.ones(A.n))
     # rows without entries (singular, but SpMV and the loop must not misbehave)
     E = oracle.Csr(4, np.array([0, 1, 1, 2, 2], np.int32), np.array([0, 2], np.int32), np.array([2.0, 3.0]), 4)
     s = cm.Solver.from_host_csr(ctx, E.rowptr, E.colidx, E.val)
