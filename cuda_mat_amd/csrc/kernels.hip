@@ -71,6 +71,21 @@ __device__ __forceinline__ void load_scalars(const ScalarSrc &s, double (&out)[K
 
 __device__ __forceinline__ bool leader() { return blockIdx.x == 0 && threadIdx.x == 0; }
 
+// The loop state as ONE thread of the workgroup reads it, handed to the others through LDS.  A stopping
+// test's leader may publish state != 0 while this very launch is still starting waves; waves of one
+// workgroup must not disagree about it (those that carried on would reduce over LDS slots the others never
+// wrote).  Different workgroups may still read different values: each then evaluates the same test on the
+// same partial sums and reaches the same decision.  Used by every kernel that contains a stopping test.
+__device__ __forceinline__ int uniform_state(const LoopState *st)
+{
+    __shared__ int s_state;
+    if (threadIdx.x == 0) s_state = st->state;
+    __syncthreads();
+    const int v = s_state;
+    __syncthreads();
+    return v;
+}
+
 __device__ __forceinline__ void publish_progress(const LoopArgs &la, int state)
 {
     if (la.snap && leader())
@@ -84,7 +99,7 @@ __device__ __forceinline__ void publish_progress(const LoopArgs &la, int state)
 __device__ __forceinline__ bool check_half(const LoopArgs &la, const ScalarSrc &half, double *lds)
 {
     LoopState *st = la.st;
-    if (st->state != 0) return true;
+    if (uniform_state(st) != 0) return true;
     double sc[1];
     load_scalars<1>(half, sc, lds);
     const double nrm = sqrt(sc[0]);
@@ -132,7 +147,7 @@ __device__ __forceinline__ bool check_full(const LoopArgs &la, const double (&sc
 __global__ __launch_bounds__(kBlock) void k_check(LoopArgs la, ScalarSrc src, int which)
 {
     __shared__ double lds[8];
-    if (la.st->state != 0) return;
+    if (which != CHECK_HALF && uniform_state(la.st) != 0) return;   // (check_half reads the state itself)
     if (which == CHECK_HALF) {
         check_half(la, src, lds);
     } else {
@@ -1012,7 +1027,7 @@ __global__ __launch_bounds__(kBlock) void k_update_p(LoopArgs la, ScalarSrc full
 {
     __shared__ double lds[8];
     LoopState *st = la.st;
-    if (st->state != 0) return;
+    if (uniform_state(st) != 0) return;
     const int it = st->it;
     double sc[2];
     load_scalars<2>(full, sc, lds);
@@ -1112,8 +1127,11 @@ __global__ __launch_bounds__(kBlock) void k_full(LoopArgs la, ScalarSrc tt, int6
 {
     __shared__ double lds[8];
     LoopState *st = la.st;
-    if (st->state != 0) {             // frozen: still tell the host this iteration's launches have drained
-        publish_progress(la, st->state);
+    // With a half-step test inside this launch (fused loop) the state is read once per workgroup, so a
+    // workgroup can never split into waves that saw the leader's exit and waves that go on to update x and r.
+    const int frozen = half.ptr ? uniform_state(st) : st->state;
+    if (frozen != 0) {                // frozen: still tell the host this iteration's launches have drained
+        publish_progress(la, frozen);
         return;
     }
     if (half.ptr && check_half(la, half, lds)) {   // fused small-system loop: the half-step test is evaluated here
@@ -1207,7 +1225,7 @@ __device__ __forceinline__ bool fused_prologue(const LoopArgs &la, const FuseArg
                                                double &alpha_out)
 {
     LoopState *st = la.st;
-    if (st->state != 0) return false;
+    if (uniform_state(st) != 0) return false;
     const int it = st->it;
     X.r = f.r;
     if (MODE == FUSE_P) {
