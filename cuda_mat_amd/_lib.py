@@ -30,7 +30,7 @@ class Stats(C.Structure):
                 ("t_analysis", C.c_double), ("t_factor", C.c_double), ("t_solve", C.c_double),
                 ("t_total", C.c_double), ("ms_spmv", C.c_double), ("n_spmv", C.c_int),
                 ("ms_trsv", C.c_double), ("n_trsv", C.c_int), ("n_levels_l", C.c_int),
-                ("n_levels_u", C.c_int)]
+                ("n_levels_u", C.c_int), ("trsv_form", C.c_int), ("trsv_fallbacks", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

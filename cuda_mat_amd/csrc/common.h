@@ -13,6 +13,9 @@ namespace cm {
 
 void set_error(const char *fmt, ...);
 int fail_hip(hipError_t e, const char *what, const char *file, int line);
+// raise hipFuncAttributeMaxDynamicSharedMemorySize of kernel `fn` to 160 KB on the CURRENT device; remembered per
+// (device, kernel), so a second device driven by the same process gets its own call; the return code is checked
+int set_max_lds(const void *fn);
 
 #define CM_HIP(expr)                                                        \
     do {                                                                    \

@@ -4,6 +4,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "kernels.h"
 
 namespace cm {
@@ -22,6 +26,21 @@ int fail_hip(hipError_t e, const char *what, const char *file, int line)
 {
     set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
     return CUDAMAT_ERR_HIP;
+}
+
+int set_max_lds(const void *fn)
+{
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    CM_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, fn})) return CUDAMAT_OK;
+    hipFuncAttributes fa;
+    CM_HIP(hipFuncGetAttributes(&fa, fn));                 // static LDS counts against the CU's 160 KB too
+    CM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes));
+    done.insert({dev, fn});
+    return CUDAMAT_OK;
 }
 
 }  // namespace cm

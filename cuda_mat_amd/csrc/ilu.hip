@@ -114,15 +114,26 @@ __global__ __launch_bounds__(kBlock) void k_level_sweep(int n, const int *rp, co
 // The same fixed point in ONE pass: rows are visited in dependency order (ascending for the lower part,
 // descending for the upper part), a row waits until the levels of its dependencies have been published
 // (lev preset to -1; 4-byte write-through stores, polled with sc1 loads) and publishes its own.  Workgroups
-// are dispatched in index order, so the first unfinished row never waits for a row that has not started;
-// spins are bounded and a timeout (err) sends the caller back to the relaxation sweeps.
+// claim chunks of consecutive positions from an atomic ticket (see k_trsv_syncfree), so a waiting row only
+// waits for rows of resident workgroups whatever the dispatcher does; spins are bounded all the same and a
+// timeout (err) sends the caller back to the relaxation sweeps.
 template <int L>
 __global__ __launch_bounds__(kBlock) void k_levels_dep(int n, const int *rp, const int *ci, const int *diag_pos,
-                                                       int upper, int *lev, int *err)
+                                                       int upper, int *lev, int *err, unsigned *ticket, int steps)
 {
     const int lane = threadIdx.x & (L - 1);
     const int team_shift = (threadIdx.x & 63) & ~(L - 1);
-    const long long t = ((long long)blockIdx.x * kBlock + threadIdx.x) / L;
+    __shared__ unsigned s_ticket[2];
+    const long long nsub = ((long long)n * L + kBlock - 1) / kBlock;
+    if (threadIdx.x == 0) s_ticket[0] = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int turn = 0;; turn ^= 1) {
+    __syncthreads();
+    const long long first = (long long)s_ticket[turn] * steps;
+    if (first >= nsub) return;
+    unsigned next_ticket = 0;
+    if (threadIdx.x == 0) next_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   for (int step = 0; step < steps && first + step < nsub; step++) {
+    const long long t = ((first + step) * kBlock + threadIdx.x) / L;
     const bool valid = t < n;
     const int i = valid ? (upper ? n - 1 - (int)t : (int)t) : 0;
     int k = 0, e = 0;
@@ -163,6 +174,9 @@ __global__ __launch_bounds__(kBlock) void k_levels_dep(int n, const int *rp, con
         if (__ballot(!done) == 0) break;
         if (pending) __builtin_amdgcn_s_sleep(2);
     }
+   }
+    if (threadIdx.x == 0) s_ticket[turn ^ 1] = next_ticket;
+  }
 }
 
 // copy one triangular part of the combined LU values into level-major storage
@@ -381,15 +395,21 @@ __global__ __launch_bounds__(kBlock) void k_trsv_small_levels(int l0, int l1, co
 }
 
 // ---- dependency-driven ("sync-free") solve of a whole group of levels in ONE launch
-// Rows are stored level-major, so every dependency of permuted row pr sits at a smaller pr: workgroups are
-// dispatched in index order and a waiting row only ever waits for rows of earlier (already dispatched)
-// workgroups or of its own wave, so the lowest unfinished row can always finish.  Readiness travels with
+// Rows are stored level-major, so every dependency of permuted row pr sits at a smaller pr.  Workgroups CLAIM
+// chunks of consecutive rows from an atomic ticket, so chunk t is only ever held by a workgroup that is already
+// running, and it is claimed after every chunk < t: a waiting row waits for rows of its own wave or of chunks
+// held by resident workgroups, and the lowest unfinished chunk never waits for anything unclaimed -- forward
+// progress does not depend on the order or the number of workgroups the dispatcher starts (the grid may be
+// smaller or larger than what fits; other kernels may hold part of the GPU).  A workgroup fetches its next
+// ticket while it works on the current one (the atomic's round trip is off the chain); holding a ticket early is
+// harmless: its owner is resident and working on a lower chunk.  Readiness travels with
 // the data: `out` is pre-filled with a SIGNALLING-NaN bit pattern that no arithmetic result can have (every
 // operation quiets a signalling NaN), a producer publishes its value with one 8-byte write-through (sc1)
 // store and consumers poll the value itself with 8-byte sc1 loads -- no flags, no fences (one naturally
 // aligned 8-byte granule written by one store).  Each row is still summed by its own LANES lanes in the
 // level kernel's order, so the result is bit-identical to the level-by-level solve.
-// Every spin is bounded: a lane that gives up sets *err (pinned host word) and proceeds with what it read.
+// Every spin is still bounded (defence in depth): a lane that gives up sets *err (pinned host word) and proceeds
+// with what it read; cudamat_solver_solve then redoes the solve level by level and counts it (trsv_fallbacks).
 constexpr unsigned long long kNotReady = 0x7FF4C0DEC0DEC0DEull;
 constexpr int kSpinLimit = 1 << 21;      // polls of one dependency before a row gives up (CUDAMAT_TRSV_SPIN_LIMIT)
 
@@ -399,19 +419,29 @@ __global__ __launch_bounds__(kBlock) void k_fill_not_ready(long long n, unsigned
         out[i] = kNotReady;
 }
 
-template <int LANES>
-__global__ __launch_bounds__(kBlock) void k_trsv_syncfree(int r0, int r1, const int *frp, const int *fci,
+template <int LANES, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_trsv_syncfree(int r0, int r1, const int *frp, const int *fci,
                                                           const double *fval, const int *row_of,
                                                           const double *dinv, const double *far,
                                                           const double *rhs, double *out, int *err, int spin_limit,
-                                                          int nap)
+                                                          int nap, unsigned *ticket, int steps)
 {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
-    constexpr int RPB = kBlock / LANES;
+    constexpr int RPB = BLOCK / LANES;
     const int lane = threadIdx.x & (LANES - 1);
     const int team_shift = (threadIdx.x & 63) & ~(LANES - 1);
     constexpr unsigned long long team_bits = LANES == 64 ? ~0ull : ((1ull << LANES) - 1ull);
-    const long long prl = (long long)r0 + (long long)blockIdx.x * RPB + threadIdx.x / LANES;
+    __shared__ unsigned s_ticket[2];
+    const long long nsub = ((long long)(r1 - r0) + RPB - 1) / RPB;       // sub-chunks of RPB rows
+    if (threadIdx.x == 0) s_ticket[0] = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int turn = 0;; turn ^= 1) {
+    __syncthreads();                                   // this turn's ticket is in LDS (the slots alternate)
+    const long long first = (long long)s_ticket[turn] * steps;
+    if (first >= nsub) return;
+    unsigned next_ticket = 0;                          // in flight while this chunk is solved, stored at its end
+    if (threadIdx.x == 0) next_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   for (int step = 0; step < steps && first + step < nsub; step++) {
+    const long long prl = (long long)r0 + (first + step) * RPB + threadIdx.x / LANES;
     const bool valid = prl < r1;
     const int pr = valid ? (int)prl : r0;
     int k = 0, e = 0;
@@ -482,6 +512,9 @@ __global__ __launch_bounds__(kBlock) void k_trsv_syncfree(int r0, int r1, const 
             }
         }
     }
+   }   // steps of one ticket
+    if (threadIdx.x == 0) s_ticket[turn ^ 1] = next_ticket;
+  }    // tickets
 }
 
 // ---- small systems (n <= 16384): the whole solve in ONE workgroup with the solution vector in LDS
@@ -588,6 +621,7 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
     int nap = 2;                           // s_sleep between polls (CUDAMAT_TRSV_NAP = 0, 1, 2, 4)
     int occ = 8;                           // workgroups per CU the dependency-driven launch may keep resident
     bool lds = false;                      // n <= 16384, narrow levels: the whole solve in one workgroup, x in LDS
+    unsigned *tickets = nullptr;           // device: one chunk-ticket counter per dependency-driven launch (group)
 };
 
 }  // namespace cm
@@ -639,6 +673,7 @@ int ilu0_release(cudamat_solver *s)
         for (TriHost *h : {&pl->L, &pl->U}) {
             for (PbPlan &fp : h->far) pb_free(&fp);
             if (h->far_buf) hipFree(h->far_buf);
+            if (h->tickets) hipFree(h->tickets);
         }
         if (pl->err_host) hipHostFree(pl->err_host);
         delete pl;
@@ -667,13 +702,19 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
         // triangular solves, fewer resident workgroups only slow this pass down: Poisson 0.9 / 2.2 / 4.1 s at 8 / 2 / 1)
         const double mean_dep = (double)(s->pm_nnz - n) / 2.0 / n;
         const int L = mean_dep <= 3.0 ? 1 : mean_dep <= 6.0 ? 2 : 8;
-        const unsigned gridL = (unsigned)(((long long)n * L + kBlock - 1) / kBlock);
+        const long long nsub = ((long long)n * L + kBlock - 1) / kBlock;
+        int steps = 4;                                           // a ticket = 4 x 256 threads' worth of rows
+        while (steps > 1 && nsub / steps < 1024) steps >>= 1;
+        const long long ntick = (nsub + steps - 1) / steps;
+        const unsigned gridL = (unsigned)(ntick < 2048 ? ntick : 2048);       // 8 resident workgroups per CU
+        unsigned *d_ticket = (unsigned *)(d_flags + 2);
+        CM_HIP(hipMemsetAsync(d_ticket, 0, sizeof(unsigned), st));
         if (L == 1)
-            hipLaunchKernelGGL(k_levels_dep<1>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev);
+            hipLaunchKernelGGL(k_levels_dep<1>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev, d_ticket, steps);
         else if (L == 2)
-            hipLaunchKernelGGL(k_levels_dep<2>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev);
+            hipLaunchKernelGGL(k_levels_dep<2>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev, d_ticket, steps);
         else
-            hipLaunchKernelGGL(k_levels_dep<8>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev);
+            hipLaunchKernelGGL(k_levels_dep<8>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev, d_ticket, steps);
         CM_HIP(hipGetLastError());
         CM_HIP(hipStreamSynchronize(st));
         have_levels = *err_host == 0;
@@ -993,7 +1034,7 @@ int ilu0_setup(cudamat_solver *s, bool block)
     const double t0 = now_s();
     double t_stamp = t0;
     do {
-        if ((rc = dalloc(&d_flags, 2))) break;
+        if ((rc = dalloc(&d_flags, 4))) break;     // [0..1] flags, [2] ticket counter of k_levels_dep
         if ((rc = dalloc(&d_lev, (size_t)n))) break;
         if (hipHostMalloc((void **)&pl->err_host, sizeof(int), hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void **)&pl->err_dev, pl->err_host, 0) != hipSuccess) {
@@ -1046,9 +1087,9 @@ int ilu0_setup(cudamat_solver *s, bool block)
             break;
         }
         if (hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
-        hipFuncSetAttribute((const void *)k_ilu0_level<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void *)k_ilu0_level<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void *)k_ilu0_level_fast<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if ((rc = set_max_lds((const void *)k_ilu0_level<1>))) break;
+        if ((rc = set_max_lds((const void *)k_ilu0_level<4>))) break;
+        if ((rc = set_max_lds((const void *)k_ilu0_level_fast<4>))) break;
         for (int l = 0; l < s->L.nlevels; l++) {
             const int r0 = s->L.level_ptr[(size_t)l], r1 = s->L.level_ptr[(size_t)l + 1];
             const int rows = r1 - r0;
@@ -1113,6 +1154,11 @@ int ilu0_setup(cudamat_solver *s, bool block)
             pl->L.occ = pick_occ(s->L);
             pl->U.occ = pick_occ(s->U);
             if (const char *oc = getenv("CUDAMAT_TRSV_OCC")) pl->L.occ = pl->U.occ = atoi(oc);
+            for (TriHost *h : {&pl->L, &pl->U}) {
+                const size_t k = h->grp_level.size() > 1 ? h->grp_level.size() - 1 : 1;
+                if (!h->tickets && (rc = dalloc(&h->tickets, k))) break;
+            }
+            if (rc) break;
         }
         s->has_ilu = true;
     } while (0);
@@ -1173,16 +1219,17 @@ static int launch_trsv_segments(hipStream_t st, const TriFactor &F, const TriHos
     return CUDAMAT_OK;
 }
 
-template <int LANES>
-static int launch_trsv_syncfree(hipStream_t st, const TriFactor &F, const TriHost &H, int n, const double *rhs,
-                                double *out, int *err)
+template <int LANES, int BLOCK>
+static int launch_trsv_syncfree_b(hipStream_t st, const TriFactor &F, const TriHost &H, int n, const double *rhs,
+                                  double *out, int *err, int per_cu)
 {
-    constexpr int RPB = kBlock / LANES;
+    constexpr int RPB = BLOCK / LANES;
     int fill_grid = (int)(((long long)n + kBlock - 1) / kBlock);
     if (fill_grid > kVecGridMax) fill_grid = kVecGridMax;
     hipLaunchKernelGGL(k_fill_not_ready, dim3(fill_grid ? fill_grid : 1), dim3(kBlock), 0, st, (long long)n,
                        (unsigned long long *)out);
     const int K = (int)H.grp_level.size() - 1;
+    CM_HIP(hipMemsetAsync(H.tickets, 0, sizeof(unsigned) * (size_t)(K > 0 ? K : 1), st));     // one ticket counter per launch
     for (int g = 0; g < K; g++) {
         const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)g]], r1 = F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]];
         if (r1 <= r0) continue;
@@ -1191,24 +1238,51 @@ static int launch_trsv_syncfree(hipStream_t st, const TriFactor &F, const TriHos
             CM_TRY(launch_far(st, F, H, g, out));
             far = H.far_buf;
         }
-        const unsigned grid = (unsigned)(((long long)(r1 - r0) + RPB - 1) / RPB);
-        // residency is throttled with an (unused) dynamic LDS request: fewer waiting workgroups, fewer pollers
-        const size_t lds_pad = H.occ >= 8 ? 0 : (size_t)(152 * 1024) / (size_t)(H.occ > 0 ? H.occ : 1);
-        static bool attr = false;
-        if (!attr) {
-            hipFuncSetAttribute((const void *)k_trsv_syncfree<LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
-        hipLaunchKernelGGL(k_trsv_syncfree<LANES>, dim3(grid), dim3(kBlock), lds_pad, st, r0, r1, F.rp, F.ci, F.val, F.row_of,
-                           F.dinv, far, rhs, out, err, H.spin_limit, H.nap);
+        // A ticket = `steps` consecutive sub-chunks of RPB rows: at least 256 rows, so that the one counter sees an
+        // atomic per 256 rows at most (far below what one address sustains).  The rows in flight are
+        // (resident workgroups) x (rows per ticket): kept as narrow as a level or two, because a row far ahead of the
+        // lowest unfinished one would mostly wait -- hence big workgroups (BLOCK = 256 x occ threads, one per CU)
+        // rather than many small ones.
+        const long long nsub = ((long long)(r1 - r0) + RPB - 1) / RPB;
+        int steps = 256 / RPB > 0 ? 256 / RPB : 1;
+        while (steps > 1 && nsub / steps < 1024) steps >>= 1;
+        const long long ntick = (nsub + steps - 1) / steps;
+        // no more workgroups than can be resident; more would only queue behind the persistent ones
+        const long long cap = (long long)per_cu * 256;
+        const unsigned grid = (unsigned)(ntick < cap ? ntick : cap);
+        // residency is pinned with an (unused) dynamic LDS request: fewer waiting workgroups, fewer pollers
+        const size_t lds_pad = (size_t)(152 * 1024) / (size_t)per_cu;
+        CM_TRY(set_max_lds((const void *)k_trsv_syncfree<LANES, BLOCK>));
+        hipLaunchKernelGGL((k_trsv_syncfree<LANES, BLOCK>), dim3(grid), dim3(BLOCK), lds_pad, st, r0, r1, F.rp, F.ci, F.val,
+                           F.row_of, F.dinv, far, rhs, out, err, H.spin_limit, H.nap, H.tickets + g, steps);
     }
     return CUDAMAT_OK;
+}
+
+// occ = resident waves per CU / 4 (1, 2, 4, 8): one workgroup of 256 x occ threads per CU (two of 1024 at occ = 8)
+template <int LANES>
+static int launch_trsv_syncfree(hipStream_t st, const TriFactor &F, const TriHost &H, int n, const double *rhs,
+                                double *out, int *err)
+{
+    const int occ = H.occ >= 8 ? 8 : H.occ >= 4 ? 4 : H.occ >= 2 ? 2 : 1;
+    if (occ == 1) return launch_trsv_syncfree_b<LANES, 256>(st, F, H, n, rhs, out, err, 1);
+    if (occ == 2) return launch_trsv_syncfree_b<LANES, 512>(st, F, H, n, rhs, out, err, 1);
+    return launch_trsv_syncfree_b<LANES, 1024>(st, F, H, n, rhs, out, err, occ == 8 ? 2 : 1);
 }
 
 bool trsv_syncfree_active(cudamat_solver *s)
 {
     IluPlans *pl = plans_of(s, false);
     return pl && s->has_ilu && (pl->L.syncfree || pl->U.syncfree);
+}
+
+int trsv_form_code(cudamat_solver *s)
+{
+    IluPlans *pl = plans_of(s, false);
+    if (!pl || !s->has_ilu) return 0;
+    if (pl->L.syncfree || pl->U.syncfree) return 1;
+    if (pl->L.lds || pl->U.lds) return 2;
+    return 0;
 }
 
 void trsv_disable_syncfree(cudamat_solver *s)
@@ -1238,11 +1312,7 @@ int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *
         const size_t bytes = sizeof(double) * (size_t)s->n;
 #define CM_TRSV_LDS(LV)                                                                                             \
     do {                                                                                                            \
-        static bool attr = false;                                                                                   \
-        if (!attr) {                                                                                                \
-            hipFuncSetAttribute((const void *)k_trsv_lds<LV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr = true;                                                                                            \
-        }                                                                                                           \
+        CM_TRY(set_max_lds((const void *)k_trsv_lds<LV>));                                                          \
         hipLaunchKernelGGL(k_trsv_lds<LV>, dim3(1), dim3(kBlock), bytes, st, s->n, F.nlevels, H.level_ptr_dev, F.rp, \
                            F.ci, F.val, F.row_of, F.dinv, rhs, out);                                                \
     } while (0)

@@ -79,6 +79,7 @@ struct cudamat_solver {
     cm::TriFactor L, U;
     void *ilu_plans = nullptr;  // launch plans owned by ilu.hip
     double t_analysis = 0.0, t_factor = 0.0, t_analysis_l = 0.0, t_analysis_u = 0.0;
+    int trsv_fallbacks = 0;     // solves redone level by level after a dependency-driven wait timed out
 };
 
 namespace cm {
@@ -87,5 +88,6 @@ int ilu0_release(cudamat_solver *s);
 int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *rhs, double *out);
 int trsv_status(cudamat_solver *s);   // after a stream sync: did a dependency-driven solve give up waiting?
 bool trsv_syncfree_active(cudamat_solver *s);
+int trsv_form_code(cudamat_solver *s);           // 0 level launches, 1 dependency-driven, 2 single workgroup in LDS
 void trsv_disable_syncfree(cudamat_solver *s);   // sticky: level-by-level kernels from now on
 }  // namespace cm

@@ -641,6 +641,8 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     stt.t_solve = t_loop1 - t_loop0;
     stt.n_levels_l = s->L.nlevels;
     stt.n_levels_u = s->U.nlevels;
+    stt.trsv_form = precond ? trsv_form_code(s) : 0;
+    stt.trsv_fallbacks = s->trsv_fallbacks;
     if (profile) {
         // events come in (start, stop) pairs; trsv pairs and spmv pairs alternate as recorded
         size_t i = 0;
@@ -698,6 +700,7 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
         return CUDAMAT_ERR_HIP;
     }
     trsv_disable_syncfree(s);
+    s->trsv_fallbacks++;          // reported in cudamat_stats: a redo must not pass for a slow solve
     if (getenv("CUDAMAT_VERBOSE"))
         fprintf(stderr, "cudamat: a dependency-driven triangular solve timed out (GPU shared with another spin-waiting "
                         "kernel?); redoing the solve with one launch per level\n");

@@ -268,8 +268,8 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
         if ((rc = dalloc(&p.slen, nbins))) break;
         const unsigned grid = (unsigned)((p.NSUB + kPbBuildWaves - 1) / kPbBuildWaves);
         const size_t lds = sizeof(int) * (size_t)kPbBuildWaves * p.NCB;
-        hipFuncSetAttribute((const void *)k_pb_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void *)k_pb_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if ((rc = set_max_lds((const void *)k_pb_rows<false>))) break;
+        if ((rc = set_max_lds((const void *)k_pb_rows<true>))) break;
         hipLaunchKernelGGL(k_pb_rows<false>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, p.CB,
                            p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr);
         if (hipGetLastError() != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb count launch failed"); break; }
@@ -480,11 +480,7 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
 int launch_spmv_pb(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
 {
     if (a.loop.st && a.check == CHECK_HALF) CM_TRY(launch_check(st, a.loop, a.half, CHECK_HALF));
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void *)k_pb_phase1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    CM_TRY(set_max_lds((const void *)k_pb_phase1));
     hipLaunchKernelGGL(k_pb_phase1, dim3(p.NCB), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x,
                        (long long)p.n_cols, p.CB, p.cstart, p.pv, p.pc, p.P, a.loop.st);
     Pb2Args b;
@@ -498,11 +494,7 @@ int launch_spmv_pb(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
     const size_t lds = sizeof(double) * ((size_t)p.NW * p.SR + 2 * (size_t)p.NW);
 #define CM_P2(NWV, LPSV)                                                                                  \
     do {                                                                                                  \
-        static bool attr = false;                                                                         \
-        if (!attr) {                                                                                      \
-            hipFuncSetAttribute((const void *)k_pb_phase2<NWV, LPSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr = true;                                                                                  \
-        }                                                                                                 \
+        CM_TRY(set_max_lds((const void *)k_pb_phase2<NWV, LPSV>));                                       \
         hipLaunchKernelGGL((k_pb_phase2<NWV, LPSV>), dim3(p.NRB), dim3(64 * NWV), lds, st, b);           \
     } while (0)
 #define CM_P2_LPS(NWV)                                           \

@@ -94,6 +94,12 @@ typedef struct cudamat_stats {
     double ms_spmv;     int n_spmv;
     double ms_trsv;     int n_trsv;
     int n_levels_l;     int n_levels_u;
+    /* triangular-solve form this solve ended with: 0 one launch per level, 1 dependency-driven
+     * launches (rows wait inside the launch), 2 one workgroup with the vector in LDS          */
+    int trsv_form;
+    /* solves of this solver that were discarded and redone level by level because a wait of a
+     * dependency-driven launch ran into its bound (0 in a healthy run; the result is the same) */
+    int trsv_fallbacks;
 } cudamat_stats;
 
 /* Collectives for a row-sharded solve, supplied by the host program (e.g. RCCL

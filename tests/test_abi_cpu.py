@@ -33,10 +33,27 @@ def test_every_declared_symbol_is_exported(cm):
 
 def test_struct_layouts_match_header(cm):
     import ctypes as C
-    # cudamat_stats: 4 ints | 6 doubles | double,int(+pad) | double | 3 ints (+pad to 8)
-    assert C.sizeof(cm.Stats) == 16 + 48 + 16 + 8 + 16
-    assert cm.Stats.ms_spmv.offset == 64 and cm.Stats.n_levels_u.offset == 96
-    assert C.sizeof(cm.Comm) == 8 + 8 + 8 + 8
+    # every field of both structs against what the C compiler makes of include/cudamat.h
+    import subprocess, tempfile
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    fields = {"cudamat_stats": cm.Stats, "cudamat_comm": cm.Comm}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cudamat.h"', 'int main(void){']
+    for cname, cls in fields.items():
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    src.append('return 0;}')
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "l.c"), "w") as fh:
+            fh.write("\n".join(src))
+        subprocess.run(["gcc", "-I", inc, "-o", os.path.join(d, "l"), os.path.join(d, "l.c")], check=True)
+        out = subprocess.run([os.path.join(d, "l")], check=True, capture_output=True, text=True).stdout
+    got = dict(line.split() for line in out.splitlines())
+    for cname, cls in fields.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, f)]) == getattr(cls, f).offset, (cname, f)
+    assert cm.Stats.ms_spmv.offset == 64 and cm.Stats.n_levels_u.offset == 96     # round-1 layout kept
 
 
 @pytest.mark.parametrize("name", FIXTURES)

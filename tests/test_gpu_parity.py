@@ -712,10 +712,13 @@ def test_trsv_timeout_redoes_the_solve_with_level_kernels(cm, ctx, oracle, monke
         assert s.trsv_form() == int(form)
         db, dx = ctx.array(b), ctx.array(x0)
         st = s.solve(db, dx, precond=cm.PRECOND_ILU0, maxit=100, tol=1e-10)       # caller's x0 (no X0_ONES flag)
-        res[form] = (dx.download(), st.iters, st.converged, s.trsv_form())
+        res[form] = (dx.download(), st.iters, st.converged, s.trsv_form(), st.trsv_fallbacks, st.trsv_form)
         s.close()
     monkeypatch.delenv("CUDAMAT_TRSV_SPIN_LIMIT")
     assert res["1"][3] == 0, "the timeout should have switched the solver to the level kernels"
+    # the redo is reported, not hidden: one fallback, and the stats name the form the solve ended with
+    assert res["0"][4] == 0 and res["1"][4] == 1
+    assert res["0"][5] == res["1"][5] and res["1"][5] in (0, 2)      # (2: single-workgroup LDS form, n <= 16384)
     assert res["0"][2] and res["1"][2] and res["0"][1] == res["1"][1]
     np.testing.assert_array_equal(res["0"][0], res["1"][0])
     np.testing.assert_allclose(res["1"][0], xs, atol=1e-7)
