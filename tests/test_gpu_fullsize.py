@@ -86,3 +86,127 @@ def test_full_size_solve_returns_xstar(cm):
     assert np.linalg.norm(r) <= 2e-8 * st.nrm0
     s.close()
     ctx.close()
+
+
+def test_full_size_poisson_solve_200_iterations(cm):
+    """BASELINE configs[2] as a SOLVE (4000 x 2500 five-point Laplacian, no preconditioner): a fixed window of 200
+    iterations (tol = 0 never fires); the residual the loop carries by recurrence (pbicgstab.cu:139-142) must still
+    be the true residual b - A x of the iterate it returns, and the iterate must have made progress."""
+    ctx = cm.Context(0)
+    nnz, rp, ci, va = _system(cm, ctx, "poisson5")
+    s = cm.Solver(ctx, N, N, nnz, rp, ci, va, 0)
+    for t in (rp, ci, va):
+        t.free()
+    xs, b, x, ax = ctx.empty(N), ctx.empty(N), ctx.empty(N), ctx.empty(N)
+    ctx.gen_xstar(0, N, 0x5EEE, xs)
+    s.spmv(xs, b)
+    st = s.solve(b, x, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=0.0, flags=cm.FLAG_X0_ONES)
+    assert st.iters == 200 and not st.converged
+    hist = s.history()
+    assert len(hist) == 400 and np.all(np.isfinite(hist))
+    s.spmv(x, ax)
+    r_true = np.linalg.norm(b.download() - ax.download())
+    # the recurrence drifts from the true residual by rounding only: O(eps * iterations * ||A|| ||x||) ~ 1e-9 ||r0|| here
+    assert abs(r_true - st.nrm) <= 1e-7 * st.nrm0, (r_true, st.nrm, st.nrm0)
+    assert st.nrm == hist[-1]
+    assert r_true < 0.2 * st.nrm0
+    s.close()
+    ctx.close()
+
+
+def _host_row(h_rp, h_ci, vals, i):
+    a, e = int(h_rp[i]), int(h_rp[i + 1])
+    return h_ci[a:e], vals[a:e]
+
+
+def test_full_size_ilu0_c5(cm, monkeypatch):
+    """BASELINE configs[4]: the 1e7 x 50 matrix with ILU(0) on one GPU (pbicgstab.cu:336-374).  The oracle cannot
+    factor 5e8 entries in seconds, so: (1) sampled rows of the factor are re-eliminated on the host from A's row and
+    the GPU's final pivot rows (the IKJ definition of csrilu0, row by row); (2) the dependency-driven and the
+    level-by-level triangular solves agree bit for bit; (3) L (U out) reproduces the right-hand side on sampled rows;
+    (4) the preconditioned solve returns x*, with the true residual under the stopping tolerance, without any
+    fallback."""
+    rng = np.random.default_rng(5)
+    ctx = cm.Context(0)
+    nnz, rp, ci, va = _system(cm, ctx, "rand50")
+    h_rp, h_ci, h_va = rp.download().astype(np.int64), ci.download(), va.download()
+    s = cm.Solver(ctx, N, N, nnz, rp, ci, va, 0)
+    for t in (rp, ci, va):
+        t.free()
+    s.ilu0()
+    assert s.trsv_form() == 1
+    lu = s.ilu0_values()
+    assert lu.shape == (nnz,)
+
+    def upper_of(k):                       # (columns, values) of row k from its diagonal on
+        c, v = _host_row(h_rp, h_ci, lu, k)
+        d = int(np.searchsorted(c, k))
+        assert c[d] == k
+        return c[d:], v[d:]
+
+    # (1) IKJ re-elimination of sampled rows
+    rows = np.unique(np.concatenate([rng.integers(0, N, 1500), [0, 1, N - 2, N - 1]]))
+    worst = 0.0
+    for i in rows:
+        c, w = _host_row(h_rp, h_ci, h_va, i)
+        w = w.copy()
+        for pos in range(int(np.searchsorted(c, i))):          # pivots k < i in increasing order
+            k = int(c[pos])
+            uc, uv = upper_of(k)
+            w[pos] = w[pos] / uv[0]
+            hit = np.searchsorted(c, uc[1:])
+            ok = (hit < len(c)) & (c[np.minimum(hit, len(c) - 1)] == uc[1:])
+            w[hit[ok]] -= w[pos] * uv[1:][ok]
+        got = _host_row(h_rp, h_ci, lu, i)[1]
+        worst = max(worst, float(np.max(np.abs(got - w) / np.maximum(np.abs(w), 1e-300))))
+    assert worst <= 1e-12, worst
+
+    # (2) + (3) triangular solves
+    rhs, out1, out0 = ctx.empty(N), ctx.empty(N), ctx.empty(N)
+    ctx.gen_xstar(0, N, 11, rhs)
+    s.precond_apply(rhs, out1)
+    h_out, h_rhs = out1.download(), rhs.download()
+    worst = 0.0
+    for i in rows[::4]:
+        c, v = _host_row(h_rp, h_ci, lu, i)
+        d = int(np.searchsorted(c, i))
+        acc = 0.0
+        for pos in range(d + 1):                                # (L w)_i with w = U out, unit diagonal
+            k = int(c[pos])
+            uc, uv = upper_of(k)
+            wk = float(np.dot(uv, h_out[uc]))
+            acc += wk if pos == d else v[pos] * wk
+        worst = max(worst, abs(acc - h_rhs[i]) / abs(h_rhs[i]))
+    assert worst <= 1e-10, worst
+    monkeypatch.setenv("CUDAMAT_TRSV_SYNCFREE", "0")
+    s.close()
+    del lu
+    # the level-by-level form needs its own plans: a second solver over the same system
+    rp, ci, va = ctx.array(h_rp.astype(np.int32)), ctx.array(h_ci), ctx.array(h_va)
+    s0 = cm.Solver(ctx, N, N, nnz, rp, ci, va, 0)
+    for t in (rp, ci, va):
+        t.free()
+    s0.ilu0()
+    assert s0.trsv_form() == 0
+    s0.precond_apply(rhs, out0)
+    np.testing.assert_array_equal(out0.download(), h_out)
+    s0.close()
+    monkeypatch.delenv("CUDAMAT_TRSV_SYNCFREE")
+
+    # (4) the preconditioned solve (default forms)
+    rp, ci, va = ctx.array(h_rp.astype(np.int32)), ctx.array(h_ci), ctx.array(h_va)
+    del h_ci, h_va
+    s = cm.Solver(ctx, N, N, nnz, rp, ci, va, 0)
+    for t in (rp, ci, va):
+        t.free()
+    xs, b, x, ax = ctx.empty(N), ctx.empty(N), ctx.empty(N), ctx.empty(N)
+    ctx.gen_xstar(0, N, 0x5EEE, xs)
+    s.spmv(xs, b)
+    st = s.solve(b, x, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PBICGSTAB, maxit=100, tol=1e-8, flags=cm.FLAG_X0_ONES)
+    assert st.converged and st.iters <= 5
+    assert st.trsv_form == 1 and st.trsv_fallbacks == 0 and s.trsv_form() == 1
+    np.testing.assert_allclose(x.download(), xs.download(), rtol=1e-6)
+    s.spmv(x, ax)
+    assert np.linalg.norm(b.download() - ax.download()) <= 1e-7 * st.nrm0
+    s.close()
+    ctx.close()
