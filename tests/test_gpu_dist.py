@@ -278,7 +278,8 @@ def test_block_jacobi_ilu0_sharded_vs_oracle(cm, oracle, golden_dir, world, name
     for o in out:
         assert (o[3]["iters"], o[3]["half_exit"], o[3]["converged"]) == (st0["iters"], st0["half_exit"], st0["converged"])
     assert st0["converged"] and abs(st0["iters"] - so.iters) <= max(1, so.iters // 10)
-    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5            # 1e-5 relative at tol 1e-8
+    # 1e-6: both sides are deterministic (fixed-order HIP reductions, single-threaded oracle, see the fixture above)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
     np.testing.assert_allclose(x, xs, rtol=0, atol=1e-4)       # tol 1e-8 on the residual; x* = 1 + sin(i)
     k = min(len(out[0][4]), 4)
     np.testing.assert_allclose(out[0][4][:k], ho[:k], rtol=1e-8)

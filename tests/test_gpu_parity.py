@@ -313,6 +313,25 @@ def test_drop_in_entry_points(cm, oracle, golden_dir):
     np.testing.assert_allclose(x, [7 / 6, 17 / 3, -23 / 6], rtol=1e-7)
 
 
+@pytest.mark.parametrize("rhs", ["sin", "urand"])
+def test_mat900_solution_matches_reference_program(cm, ctx, oracle, golden_dir, rhs):
+    """BASELINE configs[0] (mat900 through the reference's CPU program) against the HIP path: the UNMODIFIED
+    bicstab_omp binary's printed solution (6 digits, its eps 1e-6; tests/golden/bicg_mat900_*.npz) and the
+    oracle's BiCG restatement run to the 1e-8 BASELINE states, both vs the HIP BiCGSTAB solution at tol 1e-8."""
+    g = np.load(os.path.join(golden_dir, "bicg_mat900_%s.npz" % rhs))
+    A = _load(oracle, golden_dir, "mat900")
+    b = g["b"]
+    x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=2000, tol=1e-8)
+    assert st.converged
+    assert np.linalg.norm(x - g["x"]) / np.linalg.norm(g["x"]) <= 2e-5          # 6-digit print + eps 1e-6
+    xc, itc = oracle.bicg(A, b, maxit=2000, eps=1e-8)                            # C1 at the stated tolerance
+    assert 0 < itc < 2000
+    assert np.linalg.norm(x - xc) / np.linalg.norm(xc) <= 1e-5                   # SURVEY 8c (kappa(mat900) ~ 195)
+    r0 = np.linalg.norm(b - oracle.spmv(A, np.ones(A.n)))
+    assert np.linalg.norm(b - oracle.spmv(A, x)) <= 1e-7 * r0                    # true residual, SURVEY 8c
+    assert np.linalg.norm(b - oracle.spmv(A, xc)) <= 1e-7 * np.linalg.norm(b)    # the CPU path stops on ||r|| / ||b||
+
+
 def test_rand_matrix_solution_matches_reference_program(cm, ctx, oracle, golden_dir):
     """the synthetic random matrix (integer entries) at 20000 x 50: GPU BiCGSTAB solution vs the
     UNMODIFIED reference CPU program's printed solution (tests/golden/bicg_rand20000x50.npz)."""
