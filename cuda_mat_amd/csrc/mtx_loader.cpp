@@ -19,7 +19,9 @@
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -38,6 +40,12 @@ std::string lower(std::string s)
     return s;
 }
 
+void close_file(std::FILE *&f)
+{
+    if (f) std::fclose(f);
+    f = nullptr;
+}
+
 int fail(const char *msg, const char *file)
 {
     std::fprintf(stderr, "!!!! %s: '%s'\n", msg, file);
@@ -46,17 +54,35 @@ int fail(const char *msg, const char *file)
 
 }  // namespace
 
+static int load_mtx(std::FILE *&f, const char *filename, int csr_format, int *m, int *n, int *nnz,
+                    double **val, int **row, int **col);
+
 extern "C" int cudamat_load_mtx(const char *filename, int csr_format, int *m, int *n, int *nnz,
                                 double **val, int **row, int **col)
 {
     if (!filename || !m || !n || !nnz || !val || !row || !col) return CUDAMAT_ERR_ARG;
-    std::FILE *f = std::fopen(filename, "r");
+    std::FILE *f = nullptr;
+    int rc;
+    try {                                   // nothing may unwind through the C boundary
+        rc = load_mtx(f, filename, csr_format, m, n, nnz, val, row, col);
+    } catch (const std::bad_alloc &) {
+        std::fprintf(stderr, "!!!! out of memory while reading '%s'\n", filename);
+        rc = CUDAMAT_ERR_NOMEM;
+    }
+    if (f) std::fclose(f);                  // (every path inside sets f to NULL after closing it)
+    return rc;
+}
+
+static int load_mtx(std::FILE *&f, const char *filename, int csr_format, int *m, int *n, int *nnz,
+                    double **val, int **row, int **col)
+{
+    f = std::fopen(filename, "r");
     if (!f) return fail("can not open file", filename);                 // mmio_wrapper.h:156
     char line[1100];
     char t0[80], t1[80], t2[80], t3[80], t4[80];
     if (!std::fgets(line, 1025, f) ||
         std::sscanf(line, "%64s %64s %64s %64s %64s", t0, t1, t2, t3, t4) != 5) {
-        std::fclose(f);
+        close_file(f);
         return fail("can not open file", filename);
     }
     const std::string object = lower(t1), format = lower(t2), field = lower(t3), symm = lower(t4);
@@ -64,49 +90,57 @@ extern "C" int cudamat_load_mtx(const char *filename, int csr_format, int *m, in
     const bool symm_ok = symm == "general" || symm == "symmetric" || symm == "hermitian" || symm == "skew-symmetric";
     if (std::strncmp(t0, "%%MatrixMarket", 14) != 0 || object != "matrix" || !field_ok || !symm_ok ||
         (format != "coordinate" && format != "array")) {
-        std::fclose(f);
+        close_file(f);
         return fail("can not open file", filename);
     }
     if (format != "coordinate" || (field == "real" && symm == "hermitian")) {   // mmio.c:92-101,352
-        std::fclose(f);
+        close_file(f);
         return fail("can not open file", filename);
     }
     if (field == "complex") {
-        std::fclose(f);
+        close_file(f);
         std::fprintf(stderr, "!!!! complex matrix requires type 'z' or 'c'\n");          // :162
         return CUDAMAT_ERR_IO;
     }
     if (field == "pattern") {
-        std::fclose(f);
+        close_file(f);
         std::fprintf(stderr, "!!!! dense, array, pattern and integer matrices are not supported\n");  // :167
         return CUDAMAT_ERR_IO;
     }
     int M = 0, N = 0, nz = 0;
     do {
-        if (!std::fgets(line, 1025, f)) { std::fclose(f); return fail("can not open file", filename); }
+        if (!std::fgets(line, 1025, f)) { close_file(f); return fail("can not open file", filename); }
     } while (line[0] == '%');
     if (std::sscanf(line, "%d %d %d", &M, &N, &nz) != 3) {
         int got;
         do {
             got = std::fscanf(f, "%d %d %d", &M, &N, &nz);
-            if (got == EOF) { std::fclose(f); return fail("can not open file", filename); }
+            if (got == EOF) { close_file(f); return fail("can not open file", filename); }
         } while (got != 3);
     }
-    if (M < 0 || N < 0 || nz < 0) { std::fclose(f); return fail("can not open file", filename); }
+    if (M < 0 || N < 0 || nz < 0) { close_file(f); return fail("can not open file", filename); }
     const bool mirror = symm != "general";
+    // the interface counts entries in an int (mmio_wrapper.h:139): a header whose (mirrored) entry count
+    // cannot be represented is refused before anything is allocated for it
+    if ((long long)nz * (mirror ? 2 : 1) > (long long)INT_MAX) {
+        close_file(f);
+        std::fprintf(stderr, "!!!! '%s': %d stored entries%s do not fit the int interface\n", filename, nz,
+                     mirror ? " (mirrored)" : "");
+        return CUDAMAT_ERR_IO;
+    }
     const bool skew = symm == "skew-symmetric";
     std::vector<Entry> e;
-    e.reserve((size_t)nz * (mirror ? 2 : 1));
+    e.reserve(std::min<size_t>((size_t)nz * (mirror ? 2 : 1), (size_t)1 << 26));   // a lying header must not reserve GBs
     for (int k = 0; k < nz; k++) {
         Entry t;
         if (std::fscanf(f, "%d %d %lg", &t.i, &t.j, &t.v) != 3) {
-            std::fclose(f);
+            close_file(f);
             return fail("can not open file", filename);
         }
         e.push_back(t);
         if (mirror && t.i != t.j) e.push_back(Entry{t.j, t.i, skew ? -t.v : t.v});
     }
-    std::fclose(f);
+    close_file(f);
 
     if (csr_format)
         std::stable_sort(e.begin(), e.end(), [](const Entry &a, const Entry &b) {
@@ -131,9 +165,10 @@ extern "C" int cudamat_load_mtx(const char *filename, int csr_format, int *m, in
     const int dim = csr_format ? M : N;
     // every major index must fall inside [base, base+dim): the reference would write
     // out of bounds here (mmio_wrapper.h:40); this loader reports it instead.
+    const int odim = csr_format ? N : M;
     for (const Entry &t : e) {
-        const int major = csr_format ? t.i : t.j;
-        if (major < base || major >= base + dim) {
+        const int major = csr_format ? t.i : t.j, minor = csr_format ? t.j : t.i;
+        if (major < base || major >= base + dim || minor >= base + odim) {
             std::fprintf(stderr, "!!!! verify_pattern failed\n");
             return CUDAMAT_ERR_IO;
         }

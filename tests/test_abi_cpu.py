@@ -130,6 +130,20 @@ def test_loader_rejects_what_the_reference_rejects(cm, oracle, tmp_path, capfd):
     capfd.readouterr()
 
 
+def test_loader_survives_hostile_headers(cm, tmp_path, capfd):
+    """sizes the int interface cannot hold, a header that promises 2^31 - 1 entries, and a column index beyond
+    the matrix are reported as errors (no exception through the C boundary, no out-of-range CSR handed out)"""
+    bad = {
+        "huge.mtx": "%%MatrixMarket matrix coordinate real general\n3 3 2147483647\n1 1 1\n",
+        "hugesym.mtx": "%%MatrixMarket matrix coordinate real symmetric\n3 3 1500000000\n1 1 1\n",
+        "widecol.mtx": "%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1\n2 7 2\n",
+        "negdim.mtx": "%%MatrixMarket matrix coordinate real general\n-3 3 1\n1 1 1\n",
+    }
+    for name, text in bad.items():
+        assert cm.loadMMSparseMatrix(_write(tmp_path, name, text))[0] == 1, name
+    capfd.readouterr()
+
+
 def test_compute_fails_loudly_without_gpu(cm):
     """no silent CPU fallback: without a HIP device every compute entry point raises"""
     if cm.device_count() > 0:
