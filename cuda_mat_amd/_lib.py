@@ -40,10 +40,14 @@ ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int6
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
 
 
+GATHER_PART_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64)
+
+
 class Comm(C.Structure):
     """struct cudamat_comm"""
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("user", C.c_void_p),
-                ("allgather", ALLGATHER_FN), ("allreduce", ALLREDUCE_FN)]
+                ("allgather", ALLGATHER_FN), ("allreduce", ALLREDUCE_FN),
+                ("gather_part", GATHER_PART_FN), ("comm_stream", C.c_void_p)]
 
 
 def build(force=False):

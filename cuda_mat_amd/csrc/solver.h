@@ -64,6 +64,12 @@ struct cudamat_solver {
     // row sharding
     bool sharded = false;
     cudamat_comm comm{};
+    // overlapped gather (blocked SpMV + a communicator with gather_part): phase 1 runs on the pieces of the
+    // gathered vector that have arrived while the next ones are in flight on the communicator's stream
+    bool overlap = false;
+    bool agreed = false;       // the ranks have compared their setup outcomes since the last set_comm
+    int overlap_chunks = 4;
+    hipEvent_t ev_x = nullptr, ev_part[cm::kPbMaxChunks] = {};
 
     // ILU(0)
     bool has_ilu = false;

@@ -160,7 +160,7 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
         if ((rc = dev_alloc((void **)&s->parts_rv, sizeof(double) * 2 * kMaxParts))) break;
         if ((rc = dev_alloc((void **)&s->parts_half, sizeof(double) * 2 * kMaxParts))) break;
         if ((rc = dev_alloc((void **)&s->parts_tt, sizeof(double) * 2 * kMaxParts))) break;
-        if ((rc = dev_alloc((void **)&s->red, sizeof(double) * 8))) break;
+        if ((rc = dev_alloc((void **)&s->red, sizeof(double) * 16))) break;
         if ((rc = dev_alloc((void **)&s->st, sizeof(LoopState)))) break;
         if (hipHostMalloc((void **)&s->st_ring, sizeof(LoopState) * kRing, hipHostMallocDefault) != hipSuccess) {
             rc = CUDAMAT_ERR_HIP; set_error("hipHostMalloc failed"); break;
@@ -211,6 +211,9 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     for (int i = 0; i < kRing; i++)
         if (s->ev[i]) hipEventDestroy(s->ev[i]);
     for (hipEvent_t e : s->prof_ev) hipEventDestroy(e);
+    if (s->ev_x) hipEventDestroy(s->ev_x);
+    for (hipEvent_t e : s->ev_part)
+        if (e) hipEventDestroy(e);
     delete s;
     return CUDAMAT_OK;
 }
@@ -230,6 +233,8 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     pb_free(&s->pb);
     ilu0_release(s);           // factors belong to the old partition
     s->spmv_mode = -1;
+    s->overlap = false;
+    s->agreed = false;
     const char *force = getenv("CUDAMAT_FORCE_SHARDED");
     const bool forced = comm && comm->world == 1 && force && force[0] == '1';
     if (!comm || (comm->world <= 1 && !forced)) {
@@ -251,6 +256,14 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     s->comm = *comm;
     s->sharded = true;
     s->n_pad = (int)per;
+    if (comm->gather_part && comm->comm_stream && !s->ev_x) {
+        CM_HIP(hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming));
+        for (int c = 0; c < kPbMaxChunks; c++) CM_HIP(hipEventCreateWithFlags(&s->ev_part[c], hipEventDisableTiming));
+    }
+    if (const char *ch = getenv("CUDAMAT_OVERLAP_CHUNKS")) {
+        const int v = atoi(ch);
+        if (v >= 1 && v <= kPbMaxChunks) s->overlap_chunks = v;
+    }
     return CUDAMAT_OK;
 }
 
@@ -260,13 +273,14 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
                       double *parts, LoopArgs la, int check, ScalarSrc half)
 {
     const double *xfull = x_local;
-    if (s->sharded) {
+    const bool overlapped = s->sharded && s->overlap && s->spmv_mode == 1;
+    if (s->sharded && !overlapped) {
         if (s->comm.allgather(s->comm.user, x_local, s->gather, (int64_t)s->n_pad) != 0) {
             set_error("allgather callback failed");
             return CUDAMAT_ERR_COMM;
         }
-        xfull = s->gather;
     }
+    if (s->sharded) xfull = s->gather;
     SpmvArgs a{};
     a.n = s->n;
     a.rp = s->rp;
@@ -284,6 +298,38 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
     a.loop = la;
     a.check = check;
     a.half = half;
+    if (overlapped) {
+        // The gather in pieces on the communicator's stream, phase 1 piece by piece behind it on ours:
+        //   comm stream:  [wait x ready] piece 0 | piece 1 | ...
+        //   our stream :  own slice -> gather buffer, test, phase 1 (local blocks) | wait 0, phase 1 (piece 0) | ... | phase 2
+        // The products do not depend on the order of the phase-1 launches and phase 2 adds them in column order as
+        // always, so the result is bit-identical to the plain gather + SpMV.  Hazards: the next SpMV's pieces wait
+        // for its `ev_x`, recorded on our stream behind this SpMV's phase 1 (the gather buffer is free by then); our
+        // stream has waited for every piece (= all of this rank's sends) before anything may overwrite x_local.
+        hipStream_t st = s->ctx->stream, cst = (hipStream_t)s->comm.comm_stream;
+        const PbPlan &p = s->pb;
+        CM_HIP(hipEventRecord(s->ev_x, st));
+        CM_HIP(hipStreamWaitEvent(cst, s->ev_x, 0));
+        for (int c = 0; c < p.chunks; c++) {
+            const int64_t off = (int64_t)c * p.chunk_len;
+            int64_t cnt = (int64_t)s->n_pad - off;
+            if (cnt > p.chunk_len) cnt = p.chunk_len;
+            if (cnt > 0 && s->comm.gather_part(s->comm.user, x_local, s->gather, (int64_t)s->n_pad, off, cnt) != 0) {
+                set_error("gather_part callback failed");
+                return CUDAMAT_ERR_COMM;
+            }
+            CM_HIP(hipEventRecord(s->ev_part[c], cst));
+        }
+        CM_HIP(hipMemcpyAsync(s->gather + (size_t)s->comm.rank * (size_t)s->n_pad, x_local, sizeof(double) * (size_t)s->n_pad,
+                              hipMemcpyDeviceToDevice, st));
+        CM_TRY(launch_pb_check(st, a));
+        CM_TRY(launch_pb_phase1(st, p, a, 0));
+        for (int c = 0; c < p.chunks; c++) {
+            CM_HIP(hipStreamWaitEvent(st, s->ev_part[c], 0));
+            CM_TRY(launch_pb_phase1(st, p, a, 1 + c));
+        }
+        return launch_pb_phase2(st, p, a);
+    }
     if (s->spmv_mode == 1) return launch_spmv_pb(s->ctx->stream, s->pb, a);
     return launch_spmv(s->ctx->stream, s->plan, a);
 }
@@ -308,7 +354,16 @@ static int ensure_spmv_mode(cudamat_solver *s)
         return CUDAMAT_OK;
     }
     if (!force_pb && !pb_candidate(st, s->n, s->n_cols, s->nnz, s->rp, s->ci)) return CUDAMAT_OK;
-    int rc = pb_build(st, s->n, s->n_cols, s->nnz, s->rp, s->ci, s->val, &s->pb);
+    // a sharded solver cuts the column blocks at the slices (and, for an overlapped gather, the pieces) of the
+    // gathered vector; the gather buffer's index IS the column id (uniform slices of n_pad)
+    PbCols cols;
+    const bool can_overlap = s->sharded && s->comm.world > 1 && s->comm.gather_part && s->comm.comm_stream;
+    if (s->sharded && s->comm.world > 1) {
+        cols.per = s->n_pad;
+        cols.rank = s->comm.rank;
+        cols.chunks = can_overlap ? s->overlap_chunks : 1;
+    }
+    int rc = pb_build(st, s->n, s->n_cols, s->nnz, s->rp, s->ci, s->val, &s->pb, &cols);
     if (rc != CUDAMAT_OK) {
         if (force_pb) return rc;
         return CUDAMAT_OK;            // e.g. out of memory for the blocked copy: keep CSR
@@ -357,6 +412,34 @@ static int allreduce(cudamat_solver *s, double *buf, int count)
     return CUDAMAT_OK;
 }
 
+// Sharded runs: the ranks agree on the outcome of the rank-local setup steps BEFORE the first collective of the
+// data path -- a rank whose blocked copy, ILU(0) or allocation failed makes every rank return an error (instead of
+// leaving its peers inside a collective for ever), and the gather is overlapped only if every rank runs the
+// blocked SpMV (the pieces are exchanged by a different call sequence than the plain all-gather).
+static int setup_agree(cudamat_solver *s, int rc_local)
+{
+    if (!s->sharded) return rc_local;
+    char saved[512];
+    snprintf(saved, sizeof(saved), "%s", cudamat_last_error());
+    hipStream_t st = s->ctx->stream;
+    double h[2] = {rc_local != CUDAMAT_OK ? 1.0 : 0.0, s->spmv_mode == 1 ? 1.0 : 0.0};
+    CM_HIP(hipMemcpyAsync(s->red + 10, h, sizeof(h), hipMemcpyHostToDevice, st));
+    CM_HIP(hipStreamSynchronize(st));                       // (h is a stack buffer)
+    CM_TRY(allreduce(s, s->red + 10, 2));
+    CM_HIP(hipMemcpyAsync(h, s->red + 10, sizeof(h), hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    const char *ov = getenv("CUDAMAT_OVERLAP");
+    s->overlap = s->comm.world > 1 && s->comm.gather_part && s->comm.comm_stream && s->ev_x && s->pb.chunks >= 1 &&
+                 h[1] == (double)s->comm.world && !(ov && ov[0] == '0');
+    s->agreed = true;
+    if (h[0] != 0.0) {
+        if (rc_local != CUDAMAT_OK) { set_error("%s", saved); return rc_local; }
+        set_error("%d rank(s) of the sharded solver failed during setup", (int)h[0]);
+        return CUDAMAT_ERR_COMM;
+    }
+    return CUDAMAT_OK;
+}
+
 extern "C" int cudamat_solver_spmv_mode(cudamat_solver *s, int *mode)
 {
     CM_ARG(s && mode, "null pointer");
@@ -371,8 +454,12 @@ extern "C" int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, dou
 {
     CM_ARG(s && x_local && y_local, "null pointer");
     CM_HIP(hipSetDevice(s->ctx->device));
-    CM_TRY(ensure_work(s));
-    CM_TRY(ensure_spmv_mode(s));
+    {
+        int rc_setup = ensure_work(s);
+        if (rc_setup == CUDAMAT_OK) rc_setup = ensure_spmv_mode(s);
+        if (s->sharded && !s->agreed) rc_setup = setup_agree(s, rc_setup);
+        CM_TRY(rc_setup);
+    }
     const double *xin = x_local;
     if (s->sharded) {   // the gather needs n_pad entries with a zero pad
         CM_HIP(hipMemcpyAsync(s->pw, x_local, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice,
@@ -423,10 +510,13 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     CM_HIP(hipSetDevice(s->ctx->device));
     const double t_begin = now_s();
     hipStream_t st = s->ctx->stream;
-    CM_TRY(ensure_work(s));
-    CM_TRY(ensure_spmv_mode(s));
-    if (precond && (!s->has_ilu || (s->sharded && !s->ilu_block)))
-        CM_TRY(ilu0_setup(s, precond == CUDAMAT_PRECOND_BLOCK_ILU0));
+    {
+        int rc_setup = ensure_work(s);
+        if (rc_setup == CUDAMAT_OK) rc_setup = ensure_spmv_mode(s);
+        if (rc_setup == CUDAMAT_OK && precond && (!s->has_ilu || (s->sharded && !s->ilu_block)))
+            rc_setup = ilu0_setup(s, precond == CUDAMAT_PRECOND_BLOCK_ILU0);
+        CM_TRY(setup_agree(s, rc_setup));        // sharded: every rank learns of a failure on any rank
+    }
 
     // residual history: two entries per iteration (half / full step) or one; capped at 2^20 entries (8 MB) -- a solve
     // with a larger maxit keeps the first 2^20 (the kernels check the capacity)
@@ -495,7 +585,12 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
                 while ((unsigned)((w = *slot) >> 32) != (unsigned)(j + 1)) {
                     __builtin_ia32_pause();
                     if (now_s() - t_wait > 30.0) {
-                        set_error("iteration %d did not report progress within 30 s", j);
+                        // give queued work a bounded chance to drain (a query, not a wait: the device may be wedged),
+                        // then fail the solve; in a sharded run the caller must exit so that its peers are torn down
+                        const double t_drain = now_s();
+                        while (hipStreamQuery(st) == hipErrorNotReady && now_s() - t_drain < 5.0) __builtin_ia32_pause();
+                        set_error("iteration %d did not report progress within 30 s%s", j,
+                                  sharded ? " (sharded run: this rank must exit, its peers are waiting in a collective)" : "");
                         return CUDAMAT_ERR_HIP;
                     }
                 }

@@ -5,11 +5,27 @@
 
 namespace cm {
 
+constexpr int kPbMaxChunks = 16;
+
+// How the column range is cut before it is tiled into column blocks (x tiles).  A row-sharded solver gathers
+// its SpMV input from `world` ranks, slice by slice and -- when the gather is overlapped with phase 1 --
+// piece by piece: column blocks never straddle a slice or a piece, so phase 1 of the blocks of a piece
+// can start as soon as that piece has arrived.
+struct PbCols {
+    int64_t per = 0;     // columns per slice (a rank's share of the gathered vector); 0: one slice = all columns
+    int chunks = 1;      // pieces per slice
+    int rank = 0;        // the local slice (needs no exchange)
+};
+
 struct PbPlan {
     int n = 0;            // local rows
     int64_t n_cols = 0;
     int64_t nnz = 0;
-    int CB = 0, NCB = 0;  // columns per block (x tile in LDS), number of column blocks
+    int CB = 0, NCB = 0;  // columns per block (x tile in LDS, upper bound), number of column blocks
+    int64_t per = 0;      // columns per slice, pieces per slice, columns per piece, blocks per piece
+    int chunks = 1;
+    int64_t chunk_len = 0;
+    int bpc = 0;
     int RB = 0, NRB = 0;  // rows per block, number of row blocks (= workgroups of phase 2)
     int NW = 0;           // waves per phase-2 workgroup = sub-blocks per row block
     int SR = 0;           // rows per sub-block (one wave owns them)
@@ -17,12 +33,16 @@ struct PbPlan {
     int NSUB = 0;         // NRB * NW
     // entries in (column block, row block, row, column) order
     double *pv = nullptr;          // values
-    unsigned short *pc = nullptr;  // column - cb*CB
+    unsigned short *pc = nullptr;  // column - first column of its block
     unsigned short *pr = nullptr;  // row - sub*SR
     double *P = nullptr;           // products val * x[col], same order (phase 1 -> phase 2)
     int *cstart = nullptr;         // NCB+1: first entry of every column block
+    int *col0 = nullptr;           // NCB+1: first column of every column block (blocks tile [0, n_cols) in order)
     int *sstart = nullptr;         // [NSUB][NCB]: first entry of (sub, cb)
     int *slen = nullptr;           // [NSUB][NCB]: entries of (sub, cb)
+    // phase-1 launch parts: part 0 = the blocks of the local slice, part 1 + c = piece c of every other slice
+    int *order = nullptr;          // NCB block ids, part after part
+    int part_off[kPbMaxChunks + 2] = {0};
     double build_seconds = 0.0;
 };
 
@@ -30,10 +50,15 @@ struct PbPlan {
 bool pb_candidate(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci);
 // build the blocked copy from 0-based CSR on the device
 int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
-             const double *val, PbPlan *out);
+             const double *val, PbPlan *out, const PbCols *cols = nullptr);
 void pb_free(PbPlan *p);
 // y = alpha*(A x + d.*xd) + beta*y with the same fused dot / prologue options as launch_spmv;
 // args.rp/ci/val are ignored (the plan holds the matrix)
 int launch_spmv_pb(hipStream_t st, const PbPlan &plan, const SpmvArgs &a);
+// the same in pieces (overlapped gather): the stopping test, phase 1 of launch part `part`
+// (0 .. plan.chunks; see PbPlan::order), phase 2
+int launch_pb_check(hipStream_t st, const SpmvArgs &a);
+int launch_pb_phase1(hipStream_t st, const PbPlan &plan, const SpmvArgs &a, int part);
+int launch_pb_phase2(hipStream_t st, const PbPlan &plan, const SpmvArgs &a);
 
 }  // namespace cm

@@ -51,7 +51,7 @@ static int dalloc(T **p, size_t count)
 
 void pb_free(PbPlan *p)
 {
-    void *ptrs[] = {p->pv, p->pc, p->pr, p->P, p->cstart, p->sstart, p->slen};
+    void *ptrs[] = {p->pv, p->pc, p->pr, p->P, p->cstart, p->col0, p->sstart, p->slen, p->order};
     for (void *q : ptrs)
         if (q) hipFree(q);
     *p = PbPlan();
@@ -76,10 +76,20 @@ bool pb_candidate(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int 
 // FILL: place every entry at cursor[cb]++ (cursor in LDS, seeded with the global start of the
 // (cb, sub) segment) -- deterministic, no global atomics.  Equal-cb lanes of one load are adjacent
 // (columns are sorted), so a lane's rank inside its run is lane - (first lane of the run).
+struct PbCut {          // device copy of the column cut: slice -> piece -> block
+    int per, chunks, chunk_len, bpc, CB;
+};
+__device__ __forceinline__ int col_to_cb(const PbCut &c, int col)
+{
+    const int q = col / c.per, w = col - q * c.per;
+    const int ch = w / c.chunk_len, off = w - ch * c.chunk_len;
+    return (q * c.chunks + ch) * c.bpc + off / c.CB;
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_rows(int n, const int *rp, const int *ci,
-                                                               const double *val, int CB, int NCB, int SR,
-                                                               int NSUB, int *bins, double *pv, u16 *pc, u16 *pr)
+                                                               const double *val, PbCut cut, const int *col0, int NCB,
+                                                               int SR, int NSUB, int *bins, double *pv, u16 *pc, u16 *pr)
 {
     extern __shared__ int lds_i[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_rows(int n, const int
             const int k = k0 + lane;
             const bool active = k < re;
             const int col = active ? ci[k] : -1;
-            const int cb = active ? col / CB : -1;
+            const int cb = active ? col_to_cb(cut, col) : -1;
             const int prev = __shfl_up(cb, 1, 64);
             const bool head = lane == 0 || cb != prev;
             int hs = head ? lane : 0;
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_rows(int n, const int
                 if (FILL) {
                     const int dest = base + rank;
                     pv[dest] = val[k];
-                    pc[dest] = (u16)(col - cb * CB);
+                    pc[dest] = (u16)(col - col0[cb]);
                     pr[dest] = (u16)(row - (int)row0);
                 }
                 if (tail) cur[cb] = base + rank + 1;
@@ -217,16 +227,33 @@ static int round_blocks(int64_t n, int tile_max)
 }
 
 int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
-             const double *val, PbPlan *out)
+             const double *val, PbPlan *out, const PbCols *cols)
 {
     const double t0 = now_s();
     PbPlan p;
     p.n = n;
     p.n_cols = n_cols;
     p.nnz = nnz;
-    p.NCB = round_blocks(n_cols, kTileMax);
-    p.CB = (int)((n_cols + p.NCB - 1) / p.NCB);
-    p.NCB = (int)((n_cols + p.CB - 1) / p.CB);
+    // the column cut: slices of `per` columns, `chunks` pieces per slice, `bpc` blocks of <= kTileMax columns per piece
+    int local_slice = 0;
+    if (cols && cols->per > 0 && cols->per < n_cols) {
+        p.per = cols->per;
+        p.chunks = cols->chunks < 1 ? 1 : cols->chunks > kPbMaxChunks ? kPbMaxChunks : cols->chunks;
+        p.chunk_len = (p.per + p.chunks - 1) / p.chunks;
+        p.bpc = (int)((p.chunk_len + kTileMax - 1) / kTileMax);
+        p.CB = (int)((p.chunk_len + p.bpc - 1) / p.bpc);
+        const int64_t slices = (n_cols + p.per - 1) / p.per;
+        p.NCB = (int)(slices * p.chunks * p.bpc);
+        local_slice = cols->rank;
+    } else {
+        p.per = n_cols;
+        p.chunks = 1;
+        p.chunk_len = n_cols;
+        p.NCB = round_blocks(n_cols, kTileMax);
+        p.CB = (int)((n_cols + p.NCB - 1) / p.NCB);
+        p.NCB = (int)((n_cols + p.CB - 1) / p.CB);
+        p.bpc = p.NCB;
+    }
     // Sub-blocks (one wave each): ~48 entries per (sub-block, column block) segment keeps a wave's
     // lanes busy, but never fewer than 4096 waves (16 per CU) -- a shard of a row-partitioned matrix
     // has few entries per column block and would otherwise be latency-bound.
@@ -264,13 +291,52 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
         if ((rc = dalloc(&p.pr, (size_t)nnz + 8))) break;
         if ((rc = dalloc(&p.P, (size_t)nnz + 8))) break;
         if ((rc = dalloc(&p.cstart, (size_t)p.NCB + 1))) break;
+        if ((rc = dalloc(&p.col0, (size_t)p.NCB + 1))) break;
+        if ((rc = dalloc(&p.order, (size_t)p.NCB))) break;
+        {
+            // first column of every block (blocks tile [0, n_cols) in order; blocks past the end are empty) and the
+            // phase-1 launch parts: the local slice first, then piece after piece of the other slices
+            std::vector<int> h0((size_t)p.NCB + 1), ord;
+            const int per_slice = p.chunks * p.bpc;
+            for (int cb = 0; cb <= p.NCB; cb++) {
+                const int64_t q = cb / per_slice, ch = (cb % per_slice) / p.bpc, k = cb % p.bpc;
+                int64_t in_piece = k * (int64_t)p.CB;
+                if (in_piece > p.chunk_len) in_piece = p.chunk_len;
+                int64_t in_slice = ch * p.chunk_len + in_piece;
+                if (in_slice > p.per) in_slice = p.per;
+                int64_t c0 = q * p.per + in_slice;
+                if (c0 > n_cols) c0 = n_cols;
+                h0[(size_t)cb] = (int)c0;
+            }
+            ord.reserve((size_t)p.NCB);
+            const int slices = p.NCB / per_slice;
+            if (slices > 1) {
+                for (int k = 0; k < per_slice; k++) ord.push_back(local_slice * per_slice + k);
+                p.part_off[0] = 0;
+                p.part_off[1] = (int)ord.size();
+                for (int ch = 0; ch < p.chunks; ch++) {
+                    for (int q = 0; q < slices; q++)
+                        if (q != local_slice)
+                            for (int k = 0; k < p.bpc; k++) ord.push_back((q * p.chunks + ch) * p.bpc + k);
+                    p.part_off[ch + 2] = (int)ord.size();
+                }
+            } else {
+                for (int cb = 0; cb < p.NCB; cb++) ord.push_back(cb);
+                p.part_off[0] = 0;
+                for (int ch = 0; ch <= p.chunks; ch++) p.part_off[ch + 1] = p.NCB;     // everything is "local"
+            }
+            if (hipMemcpyAsync(p.col0, h0.data(), sizeof(int) * h0.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(p.order, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb column cut upload failed"); break; }
+        }
+        const PbCut cut{(int)p.per, p.chunks, (int)p.chunk_len, p.bpc, p.CB};
         if ((rc = dalloc(&p.sstart, nbins))) break;
         if ((rc = dalloc(&p.slen, nbins))) break;
         const unsigned grid = (unsigned)((p.NSUB + kPbBuildWaves - 1) / kPbBuildWaves);
         const size_t lds = sizeof(int) * (size_t)kPbBuildWaves * p.NCB;
         if ((rc = set_max_lds((const void *)k_pb_rows<false>))) break;
         if ((rc = set_max_lds((const void *)k_pb_rows<true>))) break;
-        hipLaunchKernelGGL(k_pb_rows<false>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, p.CB,
+        hipLaunchKernelGGL(k_pb_rows<false>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, cut, p.col0,
                            p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr);
         if (hipGetLastError() != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb count launch failed"); break; }
         hipLaunchKernelGGL(k_pb_colsum, dim3(p.NCB), dim3(kBlock), 0, st, p.NSUB, bins, p.cstart);   // cstart doubles as scratch
@@ -281,7 +347,7 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
             hipMemcpyAsync(&counted, p.cstart + p.NCB, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb scan failed"); break; }
         if ((int64_t)counted != nnz) { rc = CUDAMAT_ERR_ARG; set_error("pb_build: counted %d entries, expected %lld", counted, (long long)nnz); break; }
-        hipLaunchKernelGGL(k_pb_rows<true>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, p.CB,
+        hipLaunchKernelGGL(k_pb_rows<true>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, cut, p.col0,
                            p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = CUDAMAT_ERR_HIP; set_error("pb fill failed"); break;
@@ -298,18 +364,18 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
 }
 
 // ------------------------------------------------------------------ phase 1
-__global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, long long n_cols, int CB,
+__global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const int *col0, const int *list,
                                                           const int *cstart, const double *pv, const u16 *pc,
                                                           double *P, const LoopState *st)
 {
     extern __shared__ __attribute__((aligned(16))) double xs[];
     if (st && st->state != 0) return;
-    const int cb = blockIdx.x;
-    const long long c0 = (long long)cb * CB;
-    const int cn = (int)(n_cols - c0 < CB ? n_cols - c0 : CB);
+    const int cb = list ? list[blockIdx.x] : (int)blockIdx.x;
+    const int s = cstart[cb], e = cstart[cb + 1];
+    if (s == e) return;                                    // (block-uniform) nothing stored in this block
+    const int c0 = col0[cb], cn = col0[cb + 1] - c0;
     for (int i = threadIdx.x; i < cn; i += kP1Threads) xs[i] = x[c0 + i];
     __syncthreads();
-    const int s = cstart[cb], e = cstart[cb + 1];
     // two entries per lane per step (16-byte value loads), four steps in flight
     const int k0 = (s & ~1) + 2 * (int)threadIdx.x;
     constexpr int STEP = 2 * kP1Threads;
@@ -477,12 +543,33 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
     }
 }
 
-int launch_spmv_pb(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
+int launch_pb_check(hipStream_t st, const SpmvArgs &a)
 {
     if (a.loop.st && a.check == CHECK_HALF) CM_TRY(launch_check(st, a.loop, a.half, CHECK_HALF));
+    return CUDAMAT_OK;
+}
+
+int launch_pb_phase1(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int part)
+{
     CM_TRY(set_max_lds((const void *)k_pb_phase1));
-    hipLaunchKernelGGL(k_pb_phase1, dim3(p.NCB), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x,
-                       (long long)p.n_cols, p.CB, p.cstart, p.pv, p.pc, p.P, a.loop.st);
+    // part < 0: every block in index order; otherwise the blocks of one launch part (PbPlan::order)
+    const int first = part < 0 ? 0 : p.part_off[part], last = part < 0 ? p.NCB : p.part_off[part + 1];
+    if (last <= first) return CUDAMAT_OK;
+    hipLaunchKernelGGL(k_pb_phase1, dim3(last - first), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x, p.col0,
+                       part < 0 ? (const int *)nullptr : p.order + first, p.cstart, p.pv, p.pc, p.P, a.loop.st);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+int launch_spmv_pb(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
+{
+    CM_TRY(launch_pb_check(st, a));
+    CM_TRY(launch_pb_phase1(st, p, a, -1));
+    return launch_pb_phase2(st, p, a);
+}
+
+int launch_pb_phase2(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
+{
     Pb2Args b;
     b.n = p.n; b.NCB = p.NCB; b.SR = p.SR;
     b.sstart = p.sstart; b.slen = p.slen;

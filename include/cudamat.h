@@ -102,20 +102,32 @@ typedef struct cudamat_stats {
     int trsv_fallbacks;
 } cudamat_stats;
 
-/* Collectives for a row-sharded solve, supplied by the host program (e.g. RCCL
- * through torch.distributed).  Both are enqueued on / ordered
- * with the context's stream by the callee and must not block the host longer
- * than the enqueue.  Pointers are device pointers.  Return 0 on success.
+/* Collectives for a row-sharded solve.  Either supplied by the host program (e.g.
+ * torch.distributed) or the library's own RCCL binding
+ * (cudamat_rccl_comm_create below).  allgather / allreduce are enqueued on / ordered
+ * with the context's stream by the callee and must not block the host longer than the
+ * enqueue.  Pointers are device pointers.  Return 0 on success.
  *   allgather: every rank contributes `count` doubles; recv holds world*count.
- *   allreduce: in-place sum of `count` doubles.                                      */
+ *   allreduce: in-place sum of `count` doubles.
+ *   gather_part (optional, NULL = the gather is never overlapped): one PIECE of the
+ *     all-gather.  Every rank calls it with the same (stride, offset, count): rank q's
+ *     send[offset .. offset+count) must arrive at recv[q*stride + offset ..) on every
+ *     OTHER rank (a rank places its own piece itself).  The exchange is enqueued on
+ *     `comm_stream`, a hipStream_t owned by the communicator; the solver orders it
+ *     against its own stream with events, so that phase 1 of the blocked SpMV runs on
+ *     the pieces that have arrived while the next ones are in flight.                  */
 typedef int (*cudamat_allgather_fn)(void *user, const double *send, double *recv, int64_t count);
 typedef int (*cudamat_allreduce_fn)(void *user, double *buf, int count);
+typedef int (*cudamat_gather_part_fn)(void *user, const double *send, double *recv, int64_t stride,
+                                      int64_t offset, int64_t count);
 typedef struct cudamat_comm {
     int rank;
     int world;
     void *user;
     cudamat_allgather_fn allgather;
     cudamat_allreduce_fn allreduce;
+    cudamat_gather_part_fn gather_part;   /* may be NULL */
+    void *comm_stream;                    /* hipStream_t gather_part enqueues on (NULL with gather_part NULL) */
 } cudamat_comm;
 
 int         cudamat_version(void);

@@ -102,13 +102,45 @@ class ThreadComm:
     """cudamat_comm whose collectives are host-synchronised copies between the ranks' buffers:
     slow, but it drives the real C++ sharded loop with W > 1 on a single GPU."""
 
-    def __init__(self, cm, group, rank, ctx):
-        from cuda_mat_amd._lib import ALLGATHER_FN, ALLREDUCE_FN, Comm
+    def __init__(self, cm, group, rank, ctx, pieces=False):
+        """pieces=True also offers gather_part (the overlapped gather) on a stream of its own: a second Context"""
+        from cuda_mat_amd._lib import ALLGATHER_FN, ALLREDUCE_FN, GATHER_PART_FN, Comm
         self.cm, self.g, self.rank, self.ctx = cm, group, rank, ctx
-        self.n_allgather = self.n_allreduce = 0
+        self.n_allgather = self.n_allreduce = self.n_parts = 0
         self._ag = ALLGATHER_FN(self._allgather)
         self._ar = ALLREDUCE_FN(self._allreduce)
-        self.struct = Comm(rank, group.world, None, self._ag, self._ar)
+        self.cctx = None
+        if pieces:
+            self.cctx = cm.Context(ctx.device)
+            stream = C.c_void_p()
+            assert cm.lib().cudamat_ctx_stream(self.cctx.h, C.byref(stream)) == 0
+            self._gp = GATHER_PART_FN(self._gather_part)
+            self.struct = Comm(rank, group.world, None, self._ag, self._ar, self._gp, stream)
+        else:
+            self.struct = Comm(rank, group.world, None, self._ag, self._ar, GATHER_PART_FN(), None)
+
+    def close(self):
+        if self.cctx is not None:
+            self.cctx.close()
+            self.cctx = None
+
+    def _gather_part(self, user, send, recv, stride, offset, count):
+        try:
+            L = self.cm.lib()
+            self.cctx.sync()          # the solver made this stream wait for my producer kernels: my piece is final
+            self.g.send[self.rank] = send
+            self.g.barrier.wait()
+            for r in range(self.g.world):
+                if r != self.rank:
+                    assert L.cudamat_d2d(self.cctx.h, recv + 8 * (stride * r + offset), self.g.send[r] + 8 * offset,
+                                         8 * count) == 0
+            self.cctx.sync()
+            self.g.barrier.wait()                         # nobody overwrites a send buffer early
+            self.n_parts += 1
+            return 0
+        except Exception:                                 # noqa: BLE001
+            self.g.barrier.abort()
+            return 1
 
     def _allgather(self, user, send, recv, count):
         try:
