@@ -30,7 +30,10 @@ class Stats(C.Structure):
                 ("t_analysis", C.c_double), ("t_factor", C.c_double), ("t_solve", C.c_double),
                 ("t_total", C.c_double), ("ms_spmv", C.c_double), ("n_spmv", C.c_int),
                 ("ms_trsv", C.c_double), ("n_trsv", C.c_int), ("n_levels_l", C.c_int),
-                ("n_levels_u", C.c_int), ("trsv_form", C.c_int), ("trsv_fallbacks", C.c_int)]
+                ("n_levels_u", C.c_int), ("trsv_form", C.c_int), ("trsv_fallbacks", C.c_int),
+                ("n_gather", C.c_int), ("n_allreduce", C.c_int), ("ms_gather", C.c_double),
+                ("ms_gather_exposed", C.c_double), ("ms_allreduce", C.c_double), ("overlapped", C.c_int),
+                ("reserved_", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -94,6 +97,10 @@ _SIGS = {
     "cudamat_solver_trsv_form": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "cudamat_solver_precond_apply": (C.c_int, [_P, _P, _P]),
     "cudamat_solver_set_comm": (C.c_int, [_P, C.POINTER(Comm)]),
+    "cudamat_rccl_available": (C.c_int, []),
+    "cudamat_rccl_unique_id": (C.c_int, [_P]),
+    "cudamat_rccl_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(Comm)]),
+    "cudamat_rccl_comm_destroy": (C.c_int, [C.POINTER(Comm)]),
     "cudamat_solver_spmv_mode": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "cudamat_solver_spmv": (C.c_int, [_P, _P, _P]),
     "cudamat_solver_solve": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,

@@ -1,0 +1,204 @@
+// comm_rccl.hip -- the library's own collectives for a row-sharded solve: RCCL over xGMI.
+//
+// The reference is single-GPU (pbicgstab.cu:223-240: one device, default stream); SURVEY.md section 8e
+// adds row-block sharding with an all-gather of the SpMV input and all-reduces of the dot products.
+// This file implements the three cudamat_comm callbacks directly on RCCL, so the solver's hot loop
+// never leaves C++ (no interpreter, no tensor wrappers):
+//   allgather    ncclAllGather on the solver's stream
+//   allreduce    ncclAllReduce (sum, in place) on the solver's stream
+//   gather_part  one piece of the gather as grouped point-to-point transfers on a second stream: on the
+//                full xGMI mesh every peer is one hop away, so a rank sends its piece to all world-1 peers
+//                at once (all links busy) instead of passing it round a ring; the solver overlaps these
+//                pieces with phase 1 of the blocked SpMV (solver.hip, spmv_local)
+// Two communicators: one for the collectives on the solver's stream, one for the pieces on the
+// communicator's own stream, so the two streams never serialise on one communicator's launch order.
+//
+// librccl is bound at run time (dlopen "librccl.so.1"): a process that has already loaded an RCCL (a host
+// program built on PyTorch) gets that very copy, a plain C++ program gets /opt/rocm/lib's; a machine
+// without RCCL can still use every single-GPU entry point of this library.
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and enums only: every entry point is resolved with dlsym
+#include <string.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace cm {
+
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static RcclApi g_api;
+
+static int load_rccl()
+{
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (g_api.lib) return CUDAMAT_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+        set_error("RCCL is not available (dlopen librccl.so.1: %s)", dlerror());
+        return CUDAMAT_ERR_COMM;
+    }
+    RcclApi a;
+    a.lib = h;
+#define CM_SYM(field, name)                                              \
+    a.field = (decltype(a.field))dlsym(h, name);                         \
+    if (!a.field) { set_error("librccl lacks %s", name); dlclose(h); return CUDAMAT_ERR_COMM; }
+    CM_SYM(GetUniqueId, "ncclGetUniqueId")
+    CM_SYM(CommInitRank, "ncclCommInitRank")
+    CM_SYM(CommDestroy, "ncclCommDestroy")
+    CM_SYM(AllGather, "ncclAllGather")
+    CM_SYM(AllReduce, "ncclAllReduce")
+    CM_SYM(Send, "ncclSend")
+    CM_SYM(Recv, "ncclRecv")
+    CM_SYM(GroupStart, "ncclGroupStart")
+    CM_SYM(GroupEnd, "ncclGroupEnd")
+    CM_SYM(GetErrorString, "ncclGetErrorString")
+#undef CM_SYM
+    g_api = a;
+    return CUDAMAT_OK;
+}
+
+#define CM_NCCL(expr)                                                                       \
+    do {                                                                                    \
+        ncclResult_t r__ = (expr);                                                          \
+        if (r__ != ncclSuccess) {                                                           \
+            set_error("RCCL error %d (%s): %s", (int)r__, g_api.GetErrorString(r__), #expr); \
+            return CUDAMAT_ERR_COMM;                                                        \
+        }                                                                                   \
+    } while (0)
+
+struct RcclComm {
+    ncclComm_t coll = nullptr;       // all-gather / all-reduce, on the solver's stream
+    ncclComm_t p2p = nullptr;        // gather_part, on `side`
+    int rank = 0, world = 1, device = 0;
+    hipStream_t main = nullptr;      // the context's stream (not owned)
+    hipStream_t side = nullptr;      // owned
+};
+
+static int rccl_allgather(void *user, const double *send, double *recv, int64_t count)
+{
+    RcclComm *c = (RcclComm *)user;
+    CM_NCCL(g_api.AllGather(send, recv, (size_t)count, ncclDouble, c->coll, c->main));
+    return 0;
+}
+
+static int rccl_allreduce(void *user, double *buf, int count)
+{
+    RcclComm *c = (RcclComm *)user;
+    CM_NCCL(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->coll, c->main));
+    return 0;
+}
+
+// rank q's send[offset, offset + count) -> recv[q * stride + offset, ...) on every other rank
+static int rccl_gather_part(void *user, const double *send, double *recv, int64_t stride, int64_t offset, int64_t count)
+{
+    RcclComm *c = (RcclComm *)user;
+    if (c->world <= 1 || count <= 0) return 0;
+    CM_NCCL(g_api.GroupStart());
+    for (int d = 1; d < c->world; d++) {
+        // peer order rotated by rank: at every position of the group the world's sends hit distinct receivers
+        const int to = (c->rank + d) % c->world, from = (c->rank - d + c->world) % c->world;
+        CM_NCCL(g_api.Send(send + offset, (size_t)count, ncclDouble, to, c->p2p, c->side));
+        CM_NCCL(g_api.Recv(recv + (size_t)from * (size_t)stride + (size_t)offset, (size_t)count, ncclDouble, from, c->p2p, c->side));
+    }
+    CM_NCCL(g_api.GroupEnd());
+    return 0;
+}
+
+}  // namespace cm
+
+using namespace cm;
+
+extern "C" int cudamat_rccl_available(void) { return load_rccl() == CUDAMAT_OK ? 1 : 0; }
+
+extern "C" int cudamat_rccl_unique_id(void *id)
+{
+    CM_ARG(id, "id is NULL");
+    CM_TRY(load_rccl());
+    static_assert(CUDAMAT_RCCL_ID_BYTES == 2 * sizeof(ncclUniqueId), "two communicators, two ids");
+    ncclUniqueId a, b;
+    CM_NCCL(g_api.GetUniqueId(&a));
+    CM_NCCL(g_api.GetUniqueId(&b));
+    memcpy(id, &a, sizeof(a));
+    memcpy((char *)id + sizeof(a), &b, sizeof(b));
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int rank, int world, cudamat_comm *out)
+{
+    CM_ARG(ctx && id && out, "null pointer");
+    CM_ARG(world >= 1 && rank >= 0 && rank < world, "rank / world");
+    CM_TRY(load_rccl());
+    CM_HIP(hipSetDevice(ctx->device));
+    RcclComm *c = new RcclComm();
+    c->rank = rank;
+    c->world = world;
+    c->device = ctx->device;
+    c->main = ctx->stream;
+    int rc = CUDAMAT_OK;
+    do {
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) {
+            set_error("hipStreamCreate failed for the communicator's stream");
+            rc = CUDAMAT_ERR_HIP;
+            break;
+        }
+        ncclUniqueId a, b;
+        memcpy(&a, id, sizeof(a));
+        memcpy(&b, (const char *)id + sizeof(a), sizeof(b));
+        ncclResult_t r = g_api.CommInitRank(&c->coll, world, a, rank);
+        if (r == ncclSuccess) r = g_api.CommInitRank(&c->p2p, world, b, rank);
+        if (r != ncclSuccess) {
+            set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_api.GetErrorString(r));
+            rc = CUDAMAT_ERR_COMM;
+            break;
+        }
+    } while (0);
+    if (rc != CUDAMAT_OK) {
+        if (c->coll) g_api.CommDestroy(c->coll);
+        if (c->p2p) g_api.CommDestroy(c->p2p);
+        if (c->side) hipStreamDestroy(c->side);
+        delete c;
+        return rc;
+    }
+    out->rank = rank;
+    out->world = world;
+    out->user = c;
+    out->allgather = rccl_allgather;
+    out->allreduce = rccl_allreduce;
+    out->gather_part = rccl_gather_part;
+    out->comm_stream = c->side;
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_rccl_comm_destroy(cudamat_comm *comm)
+{
+    if (!comm || !comm->user) return CUDAMAT_OK;
+    CM_ARG(comm->allgather == rccl_allgather, "not a communicator made by cudamat_rccl_comm_create");
+    RcclComm *c = (RcclComm *)comm->user;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->main);
+    hipStreamSynchronize(c->side);
+    if (c->coll) g_api.CommDestroy(c->coll);
+    if (c->p2p) g_api.CommDestroy(c->p2p);
+    if (c->side) hipStreamDestroy(c->side);
+    delete c;
+    memset(comm, 0, sizeof(*comm));
+    return CUDAMAT_OK;
+}

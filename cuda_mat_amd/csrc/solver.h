@@ -60,6 +60,13 @@ struct cudamat_solver {
 
     // profiling events
     std::vector<hipEvent_t> prof_ev;
+    // CUDAMAT_FLAG_PROFILE on a sharded solver: (start, stop) event pairs around the exchanges, by kind:
+    // 0 pieces of an overlapped gather (communicator's stream), 1 the solver's stream waiting for a piece,
+    // 2 a plain all-gather, 3 an all-reduce
+    std::vector<hipEvent_t> comm_ev;
+    std::vector<int> comm_kind;
+    size_t comm_used = 0;
+    bool profiling = false;
 
     // row sharding
     bool sharded = false;

@@ -211,6 +211,7 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     for (int i = 0; i < kRing; i++)
         if (s->ev[i]) hipEventDestroy(s->ev[i]);
     for (hipEvent_t e : s->prof_ev) hipEventDestroy(e);
+    for (hipEvent_t e : s->comm_ev) hipEventDestroy(e);
     if (s->ev_x) hipEventDestroy(s->ev_x);
     for (hipEvent_t e : s->ev_part)
         if (e) hipEventDestroy(e);
@@ -267,6 +268,27 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     return CUDAMAT_OK;
 }
 
+// profiling of the exchanges: one (start, stop) pair per call, pooled per solver
+static hipEvent_t comm_event(cudamat_solver *s)
+{
+    if (s->comm_used == s->comm_ev.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        s->comm_ev.push_back(e);
+    }
+    return s->comm_ev[s->comm_used++];
+}
+static void comm_mark_begin(cudamat_solver *s, int kind, hipStream_t st)
+{
+    if (!s->profiling) return;
+    s->comm_kind.push_back(kind);
+    hipEventRecord(comm_event(s), st);
+}
+static void comm_mark_end(cudamat_solver *s, hipStream_t st)
+{
+    if (s->profiling) hipEventRecord(comm_event(s), st);
+}
+
 // y = (A + diag d) x with x a LOCAL n_pad-long work vector (pad zero); gathers first
 // when sharded.  dot/check as in SpmvArgs.
 static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int dot, const double *w,
@@ -275,10 +297,12 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
     const double *xfull = x_local;
     const bool overlapped = s->sharded && s->overlap && s->spmv_mode == 1;
     if (s->sharded && !overlapped) {
+        comm_mark_begin(s, 2, s->ctx->stream);
         if (s->comm.allgather(s->comm.user, x_local, s->gather, (int64_t)s->n_pad) != 0) {
             set_error("allgather callback failed");
             return CUDAMAT_ERR_COMM;
         }
+        comm_mark_end(s, s->ctx->stream);
     }
     if (s->sharded) xfull = s->gather;
     SpmvArgs a{};
@@ -310,6 +334,7 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
         const PbPlan &p = s->pb;
         CM_HIP(hipEventRecord(s->ev_x, st));
         CM_HIP(hipStreamWaitEvent(cst, s->ev_x, 0));
+        comm_mark_begin(s, 0, cst);
         for (int c = 0; c < p.chunks; c++) {
             const int64_t off = (int64_t)c * p.chunk_len;
             int64_t cnt = (int64_t)s->n_pad - off;
@@ -320,12 +345,15 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
             }
             CM_HIP(hipEventRecord(s->ev_part[c], cst));
         }
+        comm_mark_end(s, cst);
         CM_HIP(hipMemcpyAsync(s->gather + (size_t)s->comm.rank * (size_t)s->n_pad, x_local, sizeof(double) * (size_t)s->n_pad,
                               hipMemcpyDeviceToDevice, st));
         CM_TRY(launch_pb_check(st, a));
         CM_TRY(launch_pb_phase1(st, p, a, 0));
         for (int c = 0; c < p.chunks; c++) {
+            comm_mark_begin(s, 1, st);                     // what the solver's stream idles here is the exposed part
             CM_HIP(hipStreamWaitEvent(st, s->ev_part[c], 0));
+            comm_mark_end(s, st);
             CM_TRY(launch_pb_phase1(st, p, a, 1 + c));
         }
         return launch_pb_phase2(st, p, a);
@@ -405,10 +433,12 @@ static int ensure_spmv_mode(cudamat_solver *s)
 
 static int allreduce(cudamat_solver *s, double *buf, int count)
 {
+    comm_mark_begin(s, 3, s->ctx->stream);
     if (s->comm.allreduce(s->comm.user, buf, count) != 0) {
         set_error("allreduce callback failed");
         return CUDAMAT_ERR_COMM;
     }
+    comm_mark_end(s, s->ctx->stream);
     return CUDAMAT_OK;
 }
 
@@ -538,6 +568,10 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     const ScalarSrc nosrc{nullptr, 0, 1};
     size_t pe = 0;   // profiling events used
 
+    s->comm_used = 0;
+    s->comm_kind.clear();
+    s->profiling = profile && sharded;
+    struct ProfilingOff { cudamat_solver *s; ~ProfilingOff() { s->profiling = false; } } profiling_off{s};
     const double t_loop0 = now_s();
     if (flags & CUDAMAT_FLAG_X0_ONES) CM_TRY(launch_fill(st, n, 1.0, x));
     // r = A x0 (pbicgstab.cu:67 / :645-646); x may be a caller buffer without pad
@@ -738,6 +772,21 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     stt.n_levels_u = s->U.nlevels;
     stt.trsv_form = precond ? trsv_form_code(s) : 0;
     stt.trsv_fallbacks = s->trsv_fallbacks;
+    stt.overlapped = sharded && s->overlap && s->spmv_mode == 1;
+    if (s->profiling) {
+        // exposed part of an overlapped gather: the waits (kind 1), clipped to the gather they wait for only by
+        // construction -- the solver's stream idles there for nothing else
+        for (size_t i = 0; i < s->comm_kind.size() && 2 * i + 1 < s->comm_used; i++) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, s->comm_ev[2 * i], s->comm_ev[2 * i + 1]);
+            switch (s->comm_kind[i]) {
+            case 0: stt.ms_gather += ms; stt.n_gather++; break;
+            case 1: stt.ms_gather_exposed += ms; break;
+            case 2: stt.ms_gather += ms; stt.ms_gather_exposed += ms; stt.n_gather++; break;
+            default: stt.ms_allreduce += ms; stt.n_allreduce++; break;
+            }
+        }
+    }
     if (profile) {
         // events come in (start, stop) pairs; trsv pairs and spmv pairs alternate as recorded
         size_t i = 0;

@@ -13,7 +13,9 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import ALLGATHER_FN, ALLREDUCE_FN, Comm
+from ._lib import ALLGATHER_FN, ALLREDUCE_FN, GATHER_PART_FN, Comm
+
+RCCL_ID_BYTES = 256     # CUDAMAT_RCCL_ID_BYTES
 
 
 def shard_rows(n, world, rank):
@@ -35,7 +37,7 @@ class _CudaPtr:
 class TorchComm:
     """cudamat_comm backed by torch.distributed (one process per GPU)"""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, pieces=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -50,7 +52,51 @@ class TorchComm:
         self._ev = {"allgather": [], "allreduce": []}
         self._ag = ALLGATHER_FN(self._allgather)
         self._ar = ALLREDUCE_FN(self._allreduce)
-        self.struct = Comm(self.rank, self.world, None, self._ag, self._ar)
+        self.n_parts = 0
+        self.side = None
+        if pieces and device is not None:
+            # pieces of the gather on a side stream (cudamat_comm.gather_part / comm_stream)
+            self.side = torch.cuda.Stream(device=device)
+            self._gp = GATHER_PART_FN(self._gather_part)
+            self.struct = Comm(self.rank, self.world, None, self._ag, self._ar, self._gp, self.side.cuda_stream)
+        else:
+            self.struct = Comm(self.rank, self.world, None, self._ag, self._ar)
+
+    def _gather_part(self, user, send, recv, stride, offset, count):
+        """rank q's send[offset, offset+count) -> recv[q*stride + offset, ...) on every other rank, on self.side.
+        NCCL backend: one batch of isend/irecv (asynchronous, ordered on the side stream).  Other backends (gloo
+        rehearsals on one GPU): staged through the host and synchronous -- same data movement, no overlap."""
+        try:
+            torch, dist = self.torch, self.dist
+            mine = self._view(send + 8 * offset, count)
+            with torch.cuda.stream(self.side):
+                if dist.get_backend(self.group) == "nccl":
+                    ops = []
+                    for d in range(1, self.world):
+                        to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+                        ops.append(dist.P2POp(dist.isend, mine, to, self.group))
+                        ops.append(dist.P2POp(dist.irecv, self._view(recv + 8 * (stride * frm + offset), count), frm, self.group))
+                    if ops:
+                        dist.batch_isend_irecv(ops)          # completion is ordered on the side stream
+                else:
+                    self.side.synchronize()                  # the solver made this stream wait for the producer
+                    host = mine.cpu()
+                    bufs, reqs = {}, []
+                    for d in range(1, self.world):
+                        to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+                        bufs[frm] = torch.empty(count, dtype=torch.float64)
+                        reqs.append(dist.isend(host, to, group=self.group))
+                        reqs.append(dist.irecv(bufs[frm], frm, group=self.group))
+                    for r in reqs:
+                        r.wait()
+                    for frm, t in bufs.items():
+                        self._view(recv + 8 * (stride * frm + offset), count).copy_(t)
+                    self.side.synchronize()
+            self.n_parts += 1
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self.error = e
+            return 1
 
     def _view(self, ptr, count):
         key = (ptr, count)
@@ -110,3 +156,39 @@ class TorchComm:
         except Exception as e:  # noqa: BLE001
             self.error = e
             return 1
+
+
+class RcclComm:
+    """The library's own communicator (csrc/comm_rccl.hip): RCCL bound inside libcudamat_hip.so, so the solver's
+    loop calls ncclAllGather / ncclAllReduce / grouped ncclSend+ncclRecv itself and never re-enters Python.
+    Python only carries the 256 id bytes from rank 0 to the others, through `bcast(bytes_or_None) -> bytes`
+    (default: torch.distributed.broadcast_object_list on whatever process group exists, e.g. gloo)."""
+
+    def __init__(self, ctx, rank, world, bcast=None):
+        from . import _lib
+        L = _lib.lib()
+        self.rank, self.world = int(rank), int(world)
+        ident = None
+        if self.rank == 0:
+            buf = C.create_string_buffer(RCCL_ID_BYTES)
+            _lib.check(L.cudamat_rccl_unique_id(buf))
+            ident = buf.raw
+        if self.world > 1:
+            if bcast is None:
+                import torch.distributed as dist
+
+                def bcast(b):
+                    box = [b]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            ident = bcast(ident)
+        assert ident is not None and len(ident) == RCCL_ID_BYTES
+        self.struct = Comm()
+        _lib.check(L.cudamat_rccl_comm_create(ctx.h, ident, self.rank, self.world, C.byref(self.struct)))
+        self.native = True
+
+    def close(self):
+        from . import _lib
+        if self.struct is not None:
+            _lib.check(_lib.lib().cudamat_rccl_comm_destroy(C.byref(self.struct)))
+            self.struct = None

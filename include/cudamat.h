@@ -100,6 +100,14 @@ typedef struct cudamat_stats {
     /* solves of this solver that were discarded and redone level by level because a wait of a
      * dependency-driven launch ran into its bound (0 in a healthy run; the result is the same) */
     int trsv_fallbacks;
+    /* CUDAMAT_FLAG_PROFILE on a row-sharded solver: device time of the exchanges of this solve.
+     * ms_gather: the all-gathers of the SpMV inputs (on the communicator's stream when the
+     * gather is overlapped); ms_gather_exposed: the part of it the solver's stream actually
+     * waited for (all of it without overlap); hidden = ms_gather - ms_gather_exposed.       */
+    int n_gather;       int n_allreduce;
+    double ms_gather;   double ms_gather_exposed;   double ms_allreduce;
+    int overlapped;     /* 1: the gather ran in pieces behind phase 1 of the blocked SpMV     */
+    int reserved_;
 } cudamat_stats;
 
 /* Collectives for a row-sharded solve.  Either supplied by the host program (e.g.
@@ -129,6 +137,20 @@ typedef struct cudamat_comm {
     cudamat_gather_part_fn gather_part;   /* may be NULL */
     void *comm_stream;                    /* hipStream_t gather_part enqueues on (NULL with gather_part NULL) */
 } cudamat_comm;
+
+/* ---- the library's own communicator: RCCL over xGMI, bound at run time ---------------- */
+/* (csrc/comm_rccl.hip; the reference has no counterpart: single device, pbicgstab.cu:223-240)
+ * One rank per GPU, as threads of one process (host/example.cpp -G<n>) or as processes
+ * (bench.py under torch.distributed.run).  Rank 0 makes an id and hands its bytes to the
+ * other ranks by whatever channel the host program has; every rank then creates its
+ * communicator (collective: returns when all `world` ranks have joined), passes it to
+ * cudamat_solver_set_comm and destroys it after the solver.  The collectives run on the
+ * context's stream, the pieces of an overlapped gather on a stream the communicator owns.  */
+#define CUDAMAT_RCCL_ID_BYTES 256
+int cudamat_rccl_available(void);                  /* 1 when librccl could be loaded */
+int cudamat_rccl_unique_id(void *id);              /* fills CUDAMAT_RCCL_ID_BYTES bytes */
+int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int rank, int world, cudamat_comm *out);
+int cudamat_rccl_comm_destroy(cudamat_comm *comm);
 
 int         cudamat_version(void);
 const char *cudamat_last_error(void);

@@ -40,6 +40,23 @@ def main():
         assert comm.n_allgather >= 1 + 2 * st.iters and comm.n_allreduce >= 1 + 3 * st.iters
         x = tx.cpu().numpy()
         s.close()
+        # the library's own RCCL binding (csrc/comm_rccl.hip) at world size 1: librccl is bound with dlopen (the copy
+        # this process has already loaded), a communicator pair is created, and the loop's all-gathers / all-reduces
+        # are real ncclAllGather / ncclAllReduce calls made from C++
+        from cuda_mat_amd.dist import RcclComm
+        assert cm.lib().cudamat_rccl_available() == 1
+        rc = RcclComm(ctx, 0, 1)
+        s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+        s.set_comm(rc.struct)
+        tx2 = torch.ones(n, dtype=torch.float64, device=dev)
+        st2 = s.solve(tb, tx2, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8, flags=cm.FLAG_PROFILE)
+        stream.synchronize()
+        assert (st2.iters, st2.converged, st2.half_exit) == (st.iters, st.converged, st.half_exit)
+        assert torch.equal(tx2, tx), "native RCCL collectives must reproduce the torch.distributed run bit for bit"
+        assert st2.n_gather >= 1 + 2 * st.iters and st2.n_allreduce >= 1 + 3 * st.iters and st2.ms_gather > 0
+        assert st2.overlapped == 0 and abs(st2.ms_gather - st2.ms_gather_exposed) < 1e-9
+        s.close()
+        rc.close()
         ctx.close()
     dist.destroy_process_group()
     xo, so = O.pbicgstab(A, b, maxit=200, tol=1e-8)
