@@ -136,7 +136,7 @@ def main():
 def run_bench(args):
     import torch
     import cuda_mat_amd as cm
-    from cuda_mat_amd.dist import TorchComm, shard_rows
+    from cuda_mat_amd.dist import RcclComm, TorchComm, shard_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -156,12 +156,27 @@ def run_bench(args):
     # CUDAMAT_FORCE_SHARDED=1 under torchrun --nproc-per-node 1 exercises the whole N > 1 code path
     # (process group, TorchComm callbacks, sharded loop) on a single GPU
     use_dist = world > 1 or (os.environ.get("CUDAMAT_FORCE_SHARDED") == "1" and "MASTER_ADDR" in os.environ)
+    # Collectives of the data path.  "rccl" (default): the library's own RCCL binding, called from the C++ loop
+    # (csrc/comm_rccl.hip); torch.distributed then only carries the communicator id, the barriers and the final
+    # max over ranks, over a CPU (gloo) group.  "torch": round 1's callbacks into torch.distributed (NCCL = RCCL
+    # backend, or gloo for one-GPU rehearsals).
+    comm_kind = os.environ.get("CUDAMAT_BENCH_COMM", "rccl" if backend == "nccl" else "torch")
     if use_dist:
         import torch.distributed as dist
-        if backend == "nccl":
+        if backend == "nccl" and comm_kind == "torch":
             dist.init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo" if backend == "nccl" else backend)
+
+    def host_allreduce(value, op="sum"):
+        """a scalar over the ranks through a CPU tensor (works on every backend)"""
+        if not use_dist:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        return float(t.item())
 
     if args.workload == "mat10000":
         args.workload, args.rows, args.nx = "poisson5", 10000, 100
@@ -197,23 +212,82 @@ def run_bench(args):
         solver = cm.Solver(ctx, nloc, n, nnz, rp, ci, va, 0)
         del rp, ci, va
         torch.cuda.empty_cache()
-        comm = None
-        if use_dist and not replicas:
-            comm = TorchComm(device=dev)
-            solver.set_comm(comm.struct)
         xs = torch.empty(nloc, dtype=torch.float64, device=dev)
         b = torch.empty(nloc, dtype=torch.float64, device=dev)
         x = torch.empty(nloc, dtype=torch.float64, device=dev)
         ctx.gen_xstar(row0, row1, args.seed + 1, xs)
-        solver.spmv(xs, b)                    # b = A x*
         precond = {"none": cm.PRECOND_NONE, "ilu0": cm.PRECOND_ILU0, "bjilu0": cm.PRECOND_BLOCK_ILU0}[args.precond]
-        if precond == cm.PRECOND_ILU0:
-            solver.ilu0()
-        elif precond:
-            solver.block_ilu0()
         flags = cm.FLAG_NO_EXIT | cm.FLAG_X0_ONES
 
+        def gate():
+            """correctness gate (real stopping rule): b = A x*, solve; the recursive residual the loop reports must be
+            the true residual ||b - A x||, and where the solve converges x must equal x*.  Returns (stats, error)."""
+            solver.spmv(xs, b)                    # b = A x*
+            if precond == cm.PRECOND_ILU0:
+                solver.ilu0()
+            elif precond:
+                solver.block_ilu0()
+            st = solver.solve(b, x, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8, flags=cm.FLAG_X0_ONES)
+            ax = torch.empty(nloc, dtype=torch.float64, device=dev)
+            solver.spmv(x, ax)
+            res2 = float(((b - ax) ** 2).sum().item())
+            if use_dist and not replicas:
+                res2 = host_allreduce(res2)
+            true_res = res2 ** 0.5
+            if not abs(true_res - st.nrm) <= 1e-6 * st.nrm0 + 1e-3 * st.nrm:
+                return st, "true residual %g vs loop residual %g" % (true_res, st.nrm)
+            err = float((x - xs).abs().max().item())
+            if st.converged and not err < 2e-5:          # 1e-5 relative (SURVEY 8c); x* lies in [1, 2)
+                return st, "converged but max|x-x*|=%g" % err
+            return st, None
+
+        # The exchange forms, most capable first; a form whose gate fails on ANY rank is dropped by ALL ranks (the
+        # multi-GPU forms cannot be rehearsed on the one-GPU development box, so the bench checks before it times).
+        comm = None
+        comm_desc = None
+        ladder = [None]
+        if use_dist and not replicas:
+            # (after the rccl forms the last resort is torch.distributed over the CPU group this process has: slow,
+            # but it keeps a scaling run from ending without a number; the JSON names the form that was timed)
+            ladder = [("rccl", True), ("rccl", False), ("torch", False)] if comm_kind == "rccl" else [("torch", True), ("torch", False)]
+            if os.environ.get("CUDAMAT_BENCH_FORMS"):        # tests: e.g. "torch:0" pins one form
+                ladder = [(f.split(":")[0], f.split(":")[1] == "1") for f in os.environ["CUDAMAT_BENCH_FORMS"].split(",")]
+        gate_log = []
+        st = None
+        for form in ladder:
+            failure = None
+            try:
+                if form is not None:
+                    kind, overlap = form
+                    os.environ["CUDAMAT_OVERLAP"] = "1" if overlap else "0"
+                    if comm is None or comm_desc[0] != kind:
+                        solver.set_comm(None)
+                        if comm is not None and hasattr(comm, "close"):
+                            comm.close()
+                        comm = RcclComm(ctx, rank, world) if kind == "rccl" else TorchComm(device=dev, pieces=True)
+                    solver.set_comm(comm.struct)
+                    comm_desc = form
+                st, failure = gate()
+            except Exception as e:  # noqa: BLE001 - a failing form must not take the bench down
+                failure = "%s: %s" % (type(e).__name__, e)
+            bad = host_allreduce(1.0 if failure else 0.0) if use_dist else (1.0 if failure else 0.0)
+            gate_log.append({"form": None if form is None else {"comm": form[0], "overlap": form[1]},
+                             "failed_ranks": int(bad), "rank0_failure": failure})
+            if bad == 0:
+                break
+        else:
+            raise SystemExit("parity gate failed for every exchange form: %s" % json.dumps(gate_log))
+        conv_iters = st.iters if st.converged else None
+        # digest of the gate's solution over all ranks: two runs whose exchange forms differ must print the same one
+        import hashlib
+        digest = hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest()
+        if use_dist:
+            box = [None] * world
+            dist.all_gather_object(box, digest)
+            digest = hashlib.sha256("".join(box).encode()).hexdigest()
+
         timed_steps = [0]      # steps of the timed region that carried per-kernel / per-collective events
+        exch = {}              # exchange timings of those steps (cudamat_stats, HIP events inside the C++ loop)
 
         def run(steps, fl):
             """`steps` iterations in chunks of CHUNK.  With N > 1 ranks only the FIRST chunk carries the HIP events
@@ -226,16 +300,17 @@ def run_bench(args):
                 k = min(left, CHUNK)
                 events = first or world == 1
                 f = fl if events else fl & ~cm.FLAG_PROFILE
-                if comm is not None and not events:
-                    comm.timing = False
                 st = solver.solve(b, x, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=k, tol=1e-8, flags=f)
                 assert st.iters == k, (st.iters, k)
                 ms_spmv += st.ms_spmv
                 n_spmv += st.n_spmv
                 ms_trsv += st.ms_trsv
                 n_trsv += st.n_trsv
-                if events and (fl & cm.FLAG_PROFILE or (comm is not None and comm.timing)):
+                if events and (f & cm.FLAG_PROFILE):
                     timed_steps[0] += k
+                    for key in ("ms_gather", "ms_gather_exposed", "ms_allreduce", "n_gather", "n_allreduce"):
+                        exch[key] = exch.get(key, 0) + getattr(st, key)
+                    exch["overlapped"] = st.overlapped
                 left -= k
                 first = False
             return ms_spmv, n_spmv, ms_trsv, n_trsv, st
@@ -246,29 +321,9 @@ def run_bench(args):
                 dist.barrier()
             torch.cuda.synchronize()
 
-        # ---- correctness gate (real stopping rule): the recursive residual the loop reports must
-        # be the true residual ||b - A x||, and where the solve converges x must equal x*
-        st = solver.solve(b, x, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8,
-                          flags=cm.FLAG_X0_ONES)
-        ax = torch.empty(nloc, dtype=torch.float64, device=dev)
-        solver.spmv(x, ax)
-        res2 = ((b - ax) ** 2).sum()
-        if use_dist and not replicas:
-            dist.all_reduce(res2)
-        true_res = float(res2.sqrt().item())
-        assert abs(true_res - st.nrm) <= 1e-6 * st.nrm0 + 1e-3 * st.nrm, \
-            "parity gate failed: true residual %g vs loop residual %g" % (true_res, st.nrm)
-        err = float((x - xs).abs().max().item())
-        if st.converged:
-            # 1e-5 relative; x* lies in [1, 2)
-            assert err < 2e-5, "parity gate failed: converged but max|x-x*|=%g" % err
-        conv_iters = st.iters if st.converged else None
-        del ax
-
         run(args.warmup, flags)
         timed_steps[0] = 0
-        if comm is not None:
-            comm.reset_timing(True)       # events around every collective (first chunk of the timed region)
+        exch.clear()
         barrier()
         t0 = time.perf_counter()
         # per-launch SpMV timing = HIP events around every SpMV inside the loop; on L2-resident systems
@@ -278,10 +333,7 @@ def run_bench(args):
         ms_spmv, n_spmv, ms_trsv, n_trsv, st = run(args.steps, flags | (0 if latency_bound else cm.FLAG_PROFILE))
         barrier()
         dt = time.perf_counter() - t0
-        if use_dist:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
+        dt = host_allreduce(dt, "max")
 
     its = args.steps / dt * (world if replicas else 1)      # replicas: N independent solves in the same time
     spmv_ms = ms_spmv / max(n_spmv, 1)
@@ -307,7 +359,6 @@ def run_bench(args):
                 traffic = sum(g["hbm_bytes_per_launch_corrected"] for g in got)
                 traffic_src = os.path.relpath(f, ROOT)
                 break
-    comm_ms = comm.elapsed_ms() if comm is not None else None
     out = None
     if rank == 0:
         out = {
@@ -326,7 +377,7 @@ def run_bench(args):
                                       "independent replicas" if replicas else "row-sharded", world),
                        "rows": n, "nnz_per_rank": nnz,
                        "parallelism": ("replicas x%d (preconditioned path does not shard)" % world) if replicas else "rows/%d" % world,
-                       "converges_in_iters": conv_iters},
+                       "converges_in_iters": conv_iters, "gate_x_sha256": digest},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -336,11 +387,20 @@ def run_bench(args):
                          "iteration_frac": (2 * b_spmv + vec_bytes) * (args.steps / dt) / 1e9 / HBM_PEAK_GBS},
             "spmv_gbs": achieved, "spmv_form": "blocked two-phase" if blocked else "csr (lanes-per-row / stream tiles)",
         }
-        if comm_ms is not None:
-            # time the rank-0 stream spent inside the collectives of the timed region (HIP events)
+        if comm is not None:
+            # rank 0's exchanges inside the timed region (HIP events recorded by the C++ loop, cudamat_stats): the
+            # all-gathers of the SpMV inputs, the part of them rank 0's stream actually waited for ("exposed"; the
+            # rest ran behind phase 1 of the blocked SpMV), and the all-reduces of the dot products
             ts = max(timed_steps[0], 1)
-            out["comm"] = {"allgather_ms_per_step": comm_ms[0] / ts, "allreduce_ms_per_step": comm_ms[1] / ts,
-                           "steps_with_events": timed_steps[0], "backend": backend}
+            out["comm"] = {"form": {"comm": "rccl (csrc/comm_rccl.hip, called from the C++ loop)" if comm_desc[0] == "rccl"
+                                    else "torch.distributed callbacks (%s)" % dist.get_backend(),
+                                    "gather": "in pieces, overlapped with phase 1" if exch.get("overlapped") else "plain all-gather"},
+                           "gather_ms_per_step": exch.get("ms_gather", 0.0) / ts,
+                           "gather_exposed_ms_per_step": exch.get("ms_gather_exposed", 0.0) / ts,
+                           "gather_hidden_ms_per_step": (exch.get("ms_gather", 0.0) - exch.get("ms_gather_exposed", 0.0)) / ts,
+                           "allreduce_ms_per_step": exch.get("ms_allreduce", 0.0) / ts,
+                           "gathers_per_step": exch.get("n_gather", 0) / ts, "allreduces_per_step": exch.get("n_allreduce", 0) / ts,
+                           "steps_with_events": timed_steps[0], "gate": gate_log}
         if precond:
             out["trsv_ms_per_apply"] = ms_trsv / max(n_trsv / 2, 1)
             if ms_trsv > 0:
@@ -359,6 +419,8 @@ def run_bench(args):
         if world == 1 and args.cpu_baseline != "off":
             out["cpu_baseline"] = cpu_baseline(args)
     solver.close()
+    if comm is not None and hasattr(comm, "close"):
+        comm.close()
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

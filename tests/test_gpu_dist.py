@@ -211,17 +211,28 @@ def test_bench_two_processes_share_the_gpu_over_gloo():
     port = sk.getsockname()[1]
     sk.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CUDAMAT_BENCH_ONE_DEVICE="1", CUDAMAT_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--rows", "600000", "--steps", "6", "--warmup", "1", "--cpu-baseline", "off"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["converges_in_iters"] <= 10
-    assert out["scaling"] == "strong" and "roofline" in out
+    outs = {}
+    # the gather in pieces (phase 1 of the blocked SpMV per piece, pieces exchanged with isend/irecv) and the plain
+    # all-gather: two real processes, the same iterates bit for bit
+    for form in ("torch:1", "torch:0"):
+        env = dict(os.environ, CUDAMAT_BENCH_ONE_DEVICE="1", CUDAMAT_BENCH_BACKEND="gloo", CUDAMAT_BENCH_FORMS=form,
+                   CUDAMAT_SPMV_MODE="pb")           # (the pieces ride on the blocked SpMV; at this size the tuner may pick CSR)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                            "--gpus", "2", "--rows", "600000", "--steps", "6", "--warmup", "1", "--cpu-baseline", "off"],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["converges_in_iters"] <= 10
+        assert out["scaling"] == "strong" and "roofline" in out
+        assert out["comm"]["gate"][-1]["failed_ranks"] == 0 and len(out["comm"]["gate"]) == 1
+        outs[form] = out
+    assert outs["torch:1"]["comm"]["form"]["gather"].startswith("in pieces")
+    assert outs["torch:0"]["comm"]["form"]["gather"] == "plain all-gather"
+    assert outs["torch:1"]["config"]["gate_x_sha256"] == outs["torch:0"]["config"]["gate_x_sha256"]
+    assert outs["torch:1"]["config"]["converges_in_iters"] == outs["torch:0"]["config"]["converges_in_iters"]
 
 
 def _block_jacobi_vm(oracle, A, world):
