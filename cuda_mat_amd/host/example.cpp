@@ -5,7 +5,9 @@
 // "method failed"):
 //     -M<matrix.mtx>  -V<vector.mtx>  -D (trace)  -P (print x)  -N<dim> -R<P(zero)> (random system)
 //     device=<num> is accepted and ignored (one GPU per process)
-// and adds  -T<tol>  -I<maxit>  -S<seed>  -C<0|1|2>:
+// and adds  -G<ngpu> (row-shard the solve over that many GPUs of the node: RCCL all-gather of the SpMV input and
+// all-reduce of the dot products, one host thread per device; with -C2 every GPU factors its diagonal block)
+// and  -T<tol>  -I<maxit>  -S<seed>  -C<0|1|2>:
 //     2 = ILU(0)-preconditioned (the reference's only mode; default)
 //     0 = no preconditioner
 //     1 = the (A0 + I*d) entry point, with A's diagonal split off and x0 = 1
@@ -36,6 +38,7 @@ struct Options {
     double tol = 1e-6;
     int method = 2;
     long seed = -1;
+    int gpus = 1;
 };
 
 struct System {
@@ -74,6 +77,7 @@ bool parse(int argc, char **argv, Options &o)
         case 'I': o.maxit = std::stoi(value); break;
         case 'C': o.method = std::stoi(value); break;
         case 'S': o.seed = std::stol(value); break;
+        case 'G': o.gpus = std::stoi(value); break;
         default:
             fprintf(stderr, "Unknown switch '-%s'\n", arg + 1);
             return false;
@@ -181,6 +185,15 @@ int main(int argc, char *argv[])
     if (cudamat_device_count(&devices) != CUDAMAT_OK || devices < 1) {
         fprintf(stderr, "!!!! no HIP device: %s\n", cudamat_last_error());
         return EXIT_FAILURE;
+    }
+
+    if (opt.gpus > 1) {
+        if (opt.gpus > devices && !getenv("CUDAMAT_SHARDED_ONE_DEVICE")) {
+            fprintf(stderr, "!!!! -G%d: only %d HIP device(s) visible\n", opt.gpus, devices);
+            return EXIT_FAILURE;
+        }
+        cudamat_use_gpus(opt.gpus);
+        printf("Using %d GPUs (row blocks of %d rows)\n", opt.gpus, (opt.matrix_file ? 0 : opt.dim + opt.gpus - 1) / opt.gpus);
     }
 
     System sys;

@@ -8,6 +8,9 @@
 #include "pbicgstab.h"
 
 static thread_local cudamat_stats g_last;
+static int g_gpus = 1;
+
+void cudamat_use_gpus(int ngpu) { g_gpus = ngpu > 1 ? ngpu : 1; }
 
 const cudamat_stats *cudamat_last_stats() { return &g_last; }
 
@@ -42,7 +45,17 @@ static bool run(int n, int nnz, double *A, int *iA, int *jA, double *d, double *
                 int maxit, double tol, bool debug, double *x, double *dtAlg, bool always_true)
 {
     std::memset(&g_last, 0, sizeof(g_last));
-    const int rc = cudamat_solve(n, nnz, A, iA, jA, d, x0, b, precond, loop, maxit, tol, debug ? 1 : 0, x, &g_last);
+    int rc;
+    if (g_gpus > 1) {
+        if (precond == CUDAMAT_PRECOND_ILU0) {
+            std::fprintf(stderr, "cudamat: %d GPUs: ILU(0) of each GPU's diagonal block (block-Jacobi) stands in for ILU(0) "
+                                 "of the whole matrix\n", g_gpus);
+            precond = CUDAMAT_PRECOND_BLOCK_ILU0;
+        }
+        rc = cudamat_solve_sharded(g_gpus, n, nnz, A, iA, jA, d, x0, b, precond, loop, maxit, tol, debug ? 1 : 0, x, &g_last);
+    } else {
+        rc = cudamat_solve(n, nnz, A, iA, jA, d, x0, b, precond, loop, maxit, tol, debug ? 1 : 0, x, &g_last);
+    }
     if (dtAlg) *dtAlg = g_last.t_solve;
     if (rc != CUDAMAT_OK) {
         std::fprintf(stderr, "!!!! cudamat: %s\n", cudamat_last_error());

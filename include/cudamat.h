@@ -254,6 +254,15 @@ int cudamat_solve(int n, int nnz, const double *A, const int *iA, const int *jA,
                   int loop, int maxit, double tol, int debug, double *x,
                   cudamat_stats *st);
 
+/* The same over `ngpu` GPUs of this node, from one process: uniform row blocks, one host
+ * thread and one RCCL rank per device (csrc/sharded.cpp).  precond: NONE or BLOCK_ILU0 (each
+ * rank's diagonal block; ILU0 of the whole matrix does not shard => CUDAMAT_ERR_ARG).
+ * ngpu <= 1 is cudamat_solve.  st receives rank 0's statistics (all ranks decide alike).     */
+int cudamat_solve_sharded(int ngpu, int n, int nnz, const double *A, const int *iA, const int *jA,
+                          const double *d, const double *x0, const double *b, int precond,
+                          int loop, int maxit, double tol, int debug, double *x,
+                          cudamat_stats *st);
+
 /* ---- synthetic inputs, generated in HBM ------------------------ */
 int64_t cudamat_poisson5_nnz(int nx, int ny);
 int cudamat_gen_poisson5(cudamat_ctx *ctx, int nx, int ny, int64_t row0, int64_t row1,

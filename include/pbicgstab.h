@@ -134,3 +134,9 @@ bool bicgstab_lu_precond(int n, int nnz,
 
 /* statistics of the last solve issued by the calling thread */
 const cudamat_stats *cudamat_last_stats();
+
+/* Addition to the reference's interface: spread the solves of this process over `ngpu` GPUs of the
+ * node (uniform row blocks, RCCL; cudamat_solve_sharded).  The ILU(0) entry point then factors every
+ * GPU's diagonal block (block-Jacobi: a weaker preconditioner than ILU(0) of the whole matrix, which
+ * does not shard).  Default 1 = the reference's single-device behaviour. */
+void cudamat_use_gpus(int ngpu);

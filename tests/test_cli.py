@@ -67,3 +67,35 @@ def test_cli_solves_the_shipped_fixtures(built):
     assert ("success" in r.stdout) == (r.returncode == 0)
     r = subprocess.run([built, "-M" + os.path.join(GOLD, "mat900.mtx"), "-C0", "-T1e-8"], capture_output=True, text=True)
     assert r.returncode == 0 and "iterations = " in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_row_shards_over_gpus(built):
+    """-G<n>: one host thread per rank, uniform row blocks, the sharded C++ loop (csrc/sharded.cpp).  A one-GPU box
+    runs the ranks on device 0 with host-synchronised copies in place of RCCL (CUDAMAT_SHARDED_ONE_DEVICE=1); with
+    enough devices the same command line uses one GPU per rank over RCCL."""
+    import re
+    import cuda_mat_amd as cm
+    mat = "-M" + os.path.join(GOLD, "mat10000.mtx")
+    ref = subprocess.run([built, mat, "-C0", "-T1e-8", "-P", "-S3"], capture_output=True, text=True)
+    assert ref.returncode == 0, ref.stderr
+    runs = [(dict(os.environ, CUDAMAT_SHARDED_ONE_DEVICE="1"), n) for n in (2, 3)]
+    if cm.device_count() >= 2:
+        runs.append((dict(os.environ), 2))                  # the real thing: RCCL between two GPUs
+    for env, n in runs:
+        r = subprocess.run([built, mat, "-C0", "-T1e-8", "-P", "-S3", "-G%d" % n], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "success" in r.stdout and "Using %d GPUs" % n in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+        it0 = int(re.search(r"iterations = (\d+)", ref.stdout).group(1))
+        it1 = int(re.search(r"iterations = (\d+)", r.stdout).group(1))
+        assert abs(it0 - it1) <= max(2, it0 // 10)
+        x0 = [float(v) for v in re.search(r"result:\s*\(([^)]*)\)", ref.stdout).group(1).split()]
+        x1 = [float(v) for v in re.search(r"result:\s*\(([^)]*)\)", r.stdout).group(1).split()]
+        assert len(x0) == len(x1) == 10000 and max(abs(a - b) for a, b in zip(x0, x1)) <= 2e-5
+    # the preconditioned entry point shards as block-Jacobi and says so
+    env = dict(os.environ, CUDAMAT_SHARDED_ONE_DEVICE="1")
+    r = subprocess.run([built, mat, "-T1e-8", "-G2"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "block-Jacobi" in r.stderr and "success" in r.stdout
+    # more ranks than devices without the emulation switch is refused up front
+    if cm.device_count() < 7:
+        r = subprocess.run([built, mat, "-G7"], capture_output=True, text=True)
+        assert r.returncode != 0 and "only" in r.stderr
