@@ -51,6 +51,9 @@ def lib():
         L.orc_nrm2.restype = C.c_double
         L.orc_bicg.argtypes = [C.c_int, i32p, i32p, f64p, f64p, f64p, C.c_int, C.c_double,
                                C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.orc_bicg_timed.argtypes = [C.c_int, i32p, i32p, f64p, f64p, f64p, C.c_int, C.c_double,
+                                     C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]
         L.orc_pbicgstab.argtypes = [C.c_int, i32p, i32p, f64p, C.c_void_p, f64p, f64p, C.c_int,
                                     C.c_double, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_pbicgstab2.argtypes = [C.c_int, i32p, i32p, f64p, C.c_void_p, f64p, f64p, C.c_int,
@@ -142,6 +145,18 @@ def bicg(A, b, maxit=2000, eps=1e-6, int_transpose=False, parallel_vec=False):
     lib().orc_bicg(A.n, A.rowptr, A.colidx, A.val, _f(b), x, maxit, eps, int(int_transpose),
                    int(parallel_vec), C.byref(it))
     return x, it.value
+
+
+def bicg_timed(A, b, maxit=2000, eps=1e-6, int_transpose=False, parallel_vec=False, fast_transpose=True):
+    """bicg() with the seconds of the transposition and of the iteration loop (bicstab.cpp:146-182) apart; the
+    transposition may use every thread (same arrays, see oracle_solvers.c transpose2_par).
+    Returns (x, iterations, t_transpose, t_loop)."""
+    x = np.empty(A.n)
+    it = C.c_int(0)
+    tt, tl = C.c_double(0.0), C.c_double(0.0)
+    lib().orc_bicg_timed(A.n, A.rowptr, A.colidx, A.val, _f(b), x, maxit, eps, int(int_transpose),
+                         int(parallel_vec), C.byref(it), int(fast_transpose), C.byref(tt), C.byref(tl))
+    return x, it.value, tt.value, tl.value
 
 
 def ilu0(A):

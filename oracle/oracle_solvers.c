@@ -4,6 +4,7 @@
  */
 #include "oracle.h"
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -44,9 +45,69 @@ static void transpose2(int n, int nz, const int *rp, const int *ci, const double
     }
 }
 
+/* The same A^T arrays (a stable counting sort by column gives one result) built with every OpenMP thread:
+ * per-thread column histograms over contiguous row ranges, offsets by (column, thread), scatter in row order.
+ * NOT part of the reference's path -- its transposition is the serial loop above, ~70 s for the 5e8 entries of
+ * the 1e7-row bench matrix; bench.py's CPU baseline uses this one so that it can time the reference's
+ * iteration loop (bicstab.cpp:146-182) on the FULL matrix within seconds.  Checked against transpose2 in
+ * tests/test_oracle_golden.py. */
+static void transpose2_par(int n, int nz, const int *rp, const int *ci, const double *v,
+                           int *trp, int *tci, double *tv, int int_transpose)
+{
+    const int T = omp_get_max_threads();
+    int *hist = (int *)calloc((size_t)T * (size_t)(n + 1), sizeof(int));
+    if (!hist) { transpose2(n, nz, rp, ci, v, trp, tci, tv, int_transpose); return; }
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        const long long r0 = (long long)n * t / T, r1 = (long long)n * (t + 1) / T;
+        int *h = hist + (size_t)t * (size_t)(n + 1);
+        for (long long i = r0; i < r1; i++)
+            for (int j = rp[i]; j < rp[i + 1]; j++) h[ci[j]]++;
+#pragma omp barrier
+        /* column totals -> trp[c + 1]; per-thread counts -> exclusive prefix inside the column */
+#pragma omp for schedule(static)
+        for (int c = 0; c < n; c++) {
+            int run = 0;
+            for (int q = 0; q < T; q++) {
+                int *e = hist + (size_t)q * (size_t)(n + 1) + c;
+                const int cnt = *e;
+                *e = run;
+                run += cnt;
+            }
+            trp[c + 1] = run;
+        }
+#pragma omp single
+        {
+            trp[0] = 0;
+            for (int c = 0; c < n; c++) trp[c + 1] += trp[c];
+        }
+        for (long long i = r0; i < r1; i++)
+            for (int j = rp[i]; j < rp[i + 1]; j++) {
+                const int c = ci[j];
+                const int pos = trp[c] + h[c]++;
+                tv[pos] = int_transpose ? (double)(int)v[j] : v[j];
+                tci[pos] = (int)i;
+            }
+    }
+    free(hist);
+}
+
+static double wall_s(void) { return omp_get_wtime(); }
+
 int orc_bicg(int n, const int *rp_in, const int *ci_in, const double *v,
              const double *b, double *x, int maxit, double eps,
              int int_transpose, int parallel_vec, int *iters)
+{
+    return orc_bicg_timed(n, rp_in, ci_in, v, b, x, maxit, eps, int_transpose, parallel_vec, iters, 0, NULL, NULL);
+}
+
+/* orc_bicg with (optionally) the threaded transposition and with the seconds spent in the transposition and in
+ * the iteration loop (bicstab.cpp:146-182) reported separately */
+int orc_bicg_timed(int n, const int *rp_in, const int *ci_in, const double *v,
+                   const double *b, double *x, int maxit, double eps,
+                   int int_transpose, int parallel_vec, int *iters, int fast_transpose,
+                   double *t_transpose, double *t_loop)
 {
     /* the reference program is 0-based (bicstab.cpp:198-214); rebase if needed */
     const int base = rp_in[0];
@@ -59,7 +120,10 @@ int orc_bicg(int n, const int *rp_in, const int *ci_in, const double *v,
     int *trp = (int *)malloc(sizeof(int) * (size_t)(n + 1));
     int *tci = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));
     double *tv = (double *)malloc(sizeof(double) * (size_t)(nz > 0 ? nz : 1));
-    transpose2(n, nz, rp, ci, v, trp, tci, tv, int_transpose);          /* :99  */
+    const double tt0 = wall_s();
+    if (fast_transpose) transpose2_par(n, nz, rp, ci, v, trp, tci, tv, int_transpose);
+    else transpose2(n, nz, rp, ci, v, trp, tci, tv, int_transpose);     /* :99  */
+    if (t_transpose) *t_transpose = wall_s() - tt0;
 
     double *R = dalloc(n), *biR = dalloc(n), *nR = dalloc(n), *nbiR = dalloc(n);
     double *P = dalloc(n), *biP = dalloc(n), *nP = dalloc(n), *nbiP = dalloc(n);
@@ -73,6 +137,7 @@ int orc_bicg(int n, const int *rp_in, const int *ci_in, const double *v,
     for (i = 0; i < n; i++)
         R[i] = biR[i] = P[i] = biP[i] = b[i] - multAP[i];               /* :144 */
 
+    const double tl0 = wall_s();
     for (iter = 0; iter < maxit; iter++) {                              /* :146 */
         orc_spmv(n, rp, ci, v, P, multAP);                              /* :147 */
         orc_spmv(n, trp, tci, tv, biP, multAtbiP);                      /* :148 */
@@ -101,6 +166,7 @@ int orc_bicg(int n, const int *rp_in, const int *ci_in, const double *v,
         tmp = biP; biP = nbiP; nbiP = tmp;                              /* :181 */
     }
     if (iters) *iters = iter;
+    if (t_loop) *t_loop = wall_s() - tl0;
 
     free(R); free(biR); free(nR); free(nbiR);
     free(P); free(biP); free(nP); free(nbiP);
