@@ -99,3 +99,11 @@ def test_cli_row_shards_over_gpus(built):
     if cm.device_count() < 7:
         r = subprocess.run([built, mat, "-G7"], capture_output=True, text=True)
         assert r.returncode != 0 and "only" in r.stderr
+
+
+def test_host_selftest_under_address_sanitizer():
+    """SURVEY section 5 (sanitizers for the host side): the loader, toDenseVector and Matrix.h built with
+    -fsanitize=address,undefined and run on the shipped fixtures and on hostile files (no GPU involved)"""
+    r = subprocess.run(["make", "-C", HOST, "asan-check"], capture_output=True, text=True)
+    assert r.returncode == 0 and "SELFTEST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
