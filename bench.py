@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--precond", default="none", choices=["none", "ilu0", "bjilu0"],
                     help="ilu0: the reference's preconditioner (N > 1: independent replicas); bjilu0: block-Jacobi "
                          "ILU(0) of each rank's diagonal block, row-sharded (different maths for N > 1, SURVEY 8 f4)")
+    ap.add_argument("--loop", default="pbicgstab", choices=["pbicgstab", "pipelined"],
+                    help="pbicgstab: the reference's loop (pbicgstab.cu:45-154), the headline; pipelined: the same "
+                         "recurrences re-arranged so that the reductions run beside the SpMVs (SURVEY 8 f4; no preconditioner)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-iters", type=int, default=25)
@@ -245,6 +248,7 @@ def run_bench(args):
         ctx.gen_xstar(row0, row1, args.seed + 1, xs)
         precond = {"none": cm.PRECOND_NONE, "ilu0": cm.PRECOND_ILU0, "bjilu0": cm.PRECOND_BLOCK_ILU0}[args.precond]
         flags = cm.FLAG_NO_EXIT | cm.FLAG_X0_ONES
+        loop = cm.LOOP_PIPELINED if args.loop == "pipelined" else cm.LOOP_PBICGSTAB
 
         def gate():
             """correctness gate (real stopping rule): b = A x*, solve; the recursive residual the loop reports must be
@@ -254,7 +258,7 @@ def run_bench(args):
                 solver.ilu0()
             elif precond:
                 solver.block_ilu0()
-            st = solver.solve(b, x, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8, flags=cm.FLAG_X0_ONES)
+            st = solver.solve(b, x, precond=precond, loop=loop, maxit=200, tol=1e-8, flags=cm.FLAG_X0_ONES)
             ax = torch.empty(nloc, dtype=torch.float64, device=dev)
             solver.spmv(x, ax)
             res2 = float(((b - ax) ** 2).sum().item())
@@ -327,7 +331,7 @@ def run_bench(args):
                 k = min(left, CHUNK)
                 events = first or world == 1
                 f = fl if events else fl & ~cm.FLAG_PROFILE
-                st = solver.solve(b, x, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=k, tol=1e-8, flags=f)
+                st = solver.solve(b, x, precond=precond, loop=loop, maxit=k, tol=1e-8, flags=f)
                 assert st.iters == k, (st.iters, k)
                 ms_spmv += st.ms_spmv
                 n_spmv += st.n_spmv
@@ -404,7 +408,8 @@ def run_bench(args):
                                       "independent replicas" if replicas else "row-sharded", world),
                        "rows": n, "nnz_per_rank": nnz,
                        "parallelism": ("replicas x%d (preconditioned path does not shard)" % world) if replicas else "rows/%d" % world,
-                       "converges_in_iters": conv_iters, "gate_x_sha256": digest},
+                       "converges_in_iters": conv_iters, "gate_x_sha256": digest,
+                       "loop": "pbicgstab.cu:45-154" if args.loop == "pbicgstab" else "pipelined BiCGStab (not a reference loop)"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,

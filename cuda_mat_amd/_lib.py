@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcudamat_hip.so")
 
 OK = 0
 PRECOND_NONE, PRECOND_ILU0, PRECOND_BLOCK_ILU0 = 0, 1, 2
-LOOP_PBICGSTAB, LOOP_PBICGSTAB2 = 0, 1
+LOOP_PBICGSTAB, LOOP_PBICGSTAB2, LOOP_PIPELINED = 0, 1, 2
 FLAG_DEBUG, FLAG_PROFILE, FLAG_NO_EXIT, FLAG_X0_ONES = 1, 2, 4, 8
 
 
@@ -50,7 +50,8 @@ class Comm(C.Structure):
     """struct cudamat_comm"""
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("user", C.c_void_p),
                 ("allgather", ALLGATHER_FN), ("allreduce", ALLREDUCE_FN),
-                ("gather_part", GATHER_PART_FN), ("comm_stream", C.c_void_p)]
+                ("gather_part", GATHER_PART_FN), ("comm_stream", C.c_void_p),
+                ("allreduce_side", ALLREDUCE_FN), ("reduce_stream", C.c_void_p)]
 
 
 def build(force=False):

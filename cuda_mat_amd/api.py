@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (FLAG_DEBUG, FLAG_NO_EXIT, FLAG_PROFILE, FLAG_X0_ONES, LOOP_PBICGSTAB,
-                   LOOP_PBICGSTAB2, PRECOND_BLOCK_ILU0, PRECOND_ILU0, PRECOND_NONE, Comm, CudamatError, Stats, check)
+                   LOOP_PBICGSTAB2, LOOP_PIPELINED, PRECOND_BLOCK_ILU0, PRECOND_ILU0, PRECOND_NONE, Comm, CudamatError, Stats, check)
 
 
 def _np(a, dtype):

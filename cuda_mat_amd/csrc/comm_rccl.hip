@@ -10,8 +10,9 @@
 //                full xGMI mesh every peer is one hop away, so a rank sends its piece to all world-1 peers
 //                at once (all links busy) instead of passing it round a ring; the solver overlaps these
 //                pieces with phase 1 of the blocked SpMV (solver.hip, spmv_local)
-// Two communicators: one for the collectives on the solver's stream, one for the pieces on the
-// communicator's own stream, so the two streams never serialise on one communicator's launch order.
+// Three communicators, one per stream: the collectives on the solver's stream, the pieces on the communicator's
+// own stream, and the all-reduces the pipelined loop runs beside an SpMV on a third stream -- so no two streams
+// ever serialise on one communicator's launch order.
 //
 // librccl is bound at run time (dlopen "librccl.so.1"): a process that has already loaded an RCCL (a host
 // program built on PyTorch) gets that very copy, a plain C++ program gets /opt/rocm/lib's; a machine
@@ -87,9 +88,11 @@ static int load_rccl()
 struct RcclComm {
     ncclComm_t coll = nullptr;       // all-gather / all-reduce, on the solver's stream
     ncclComm_t p2p = nullptr;        // gather_part, on `side`
+    ncclComm_t red = nullptr;        // allreduce_side, on `rstream`
     int rank = 0, world = 1, device = 0;
     hipStream_t main = nullptr;      // the context's stream (not owned)
     hipStream_t side = nullptr;      // owned
+    hipStream_t rstream = nullptr;   // owned
 };
 
 static int rccl_allgather(void *user, const double *send, double *recv, int64_t count)
@@ -103,6 +106,13 @@ static int rccl_allreduce(void *user, double *buf, int count)
 {
     RcclComm *c = (RcclComm *)user;
     CM_NCCL(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->coll, c->main));
+    return 0;
+}
+
+static int rccl_allreduce_side(void *user, double *buf, int count)
+{
+    RcclComm *c = (RcclComm *)user;
+    CM_NCCL(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->red, c->rstream));
     return 0;
 }
 
@@ -132,12 +142,12 @@ extern "C" int cudamat_rccl_unique_id(void *id)
 {
     CM_ARG(id, "id is NULL");
     CM_TRY(load_rccl());
-    static_assert(CUDAMAT_RCCL_ID_BYTES == 2 * sizeof(ncclUniqueId), "two communicators, two ids");
-    ncclUniqueId a, b;
-    CM_NCCL(g_api.GetUniqueId(&a));
-    CM_NCCL(g_api.GetUniqueId(&b));
-    memcpy(id, &a, sizeof(a));
-    memcpy((char *)id + sizeof(a), &b, sizeof(b));
+    static_assert(CUDAMAT_RCCL_ID_BYTES == 3 * sizeof(ncclUniqueId), "three communicators, three ids");
+    for (int k = 0; k < 3; k++) {
+        ncclUniqueId a;
+        CM_NCCL(g_api.GetUniqueId(&a));
+        memcpy((char *)id + (size_t)k * sizeof(a), &a, sizeof(a));
+    }
     return CUDAMAT_OK;
 }
 
@@ -154,16 +164,19 @@ extern "C" int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int ra
     c->main = ctx->stream;
     int rc = CUDAMAT_OK;
     do {
-        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->rstream, hipStreamNonBlocking) != hipSuccess) {
             set_error("hipStreamCreate failed for the communicator's stream");
             rc = CUDAMAT_ERR_HIP;
             break;
         }
-        ncclUniqueId a, b;
+        ncclUniqueId a, b, d;
         memcpy(&a, id, sizeof(a));
         memcpy(&b, (const char *)id + sizeof(a), sizeof(b));
+        memcpy(&d, (const char *)id + 2 * sizeof(a), sizeof(d));
         ncclResult_t r = g_api.CommInitRank(&c->coll, world, a, rank);
         if (r == ncclSuccess) r = g_api.CommInitRank(&c->p2p, world, b, rank);
+        if (r == ncclSuccess) r = g_api.CommInitRank(&c->red, world, d, rank);
         if (r != ncclSuccess) {
             set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_api.GetErrorString(r));
             rc = CUDAMAT_ERR_COMM;
@@ -173,7 +186,9 @@ extern "C" int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int ra
     if (rc != CUDAMAT_OK) {
         if (c->coll) g_api.CommDestroy(c->coll);
         if (c->p2p) g_api.CommDestroy(c->p2p);
+        if (c->red) g_api.CommDestroy(c->red);
         if (c->side) hipStreamDestroy(c->side);
+        if (c->rstream) hipStreamDestroy(c->rstream);
         delete c;
         return rc;
     }
@@ -184,6 +199,8 @@ extern "C" int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int ra
     out->allreduce = rccl_allreduce;
     out->gather_part = rccl_gather_part;
     out->comm_stream = c->side;
+    out->allreduce_side = rccl_allreduce_side;
+    out->reduce_stream = c->rstream;
     return CUDAMAT_OK;
 }
 
@@ -195,9 +212,12 @@ extern "C" int cudamat_rccl_comm_destroy(cudamat_comm *comm)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->main);
     hipStreamSynchronize(c->side);
+    hipStreamSynchronize(c->rstream);
     if (c->coll) g_api.CommDestroy(c->coll);
     if (c->p2p) g_api.CommDestroy(c->p2p);
+    if (c->red) g_api.CommDestroy(c->red);
     if (c->side) hipStreamDestroy(c->side);
+    if (c->rstream) hipStreamDestroy(c->rstream);
     delete c;
     memset(comm, 0, sizeof(*comm));
     return CUDAMAT_OK;

@@ -65,6 +65,7 @@ struct LoopState {
     double nrm0;
     double tolabs;   // tol * nrm0
     double nrm;      // last residual norm evaluated
+    double alpha2[2];  // pipelined loop: alpha of iteration k in slot k & 1
 };
 
 enum Check { CHECK_NONE = 0, CHECK_HALF = 1, CHECK_FULL = 2 };

@@ -103,6 +103,14 @@ int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, 
 int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, const double *sv,
                 double *r, const double *t, const double *rw, double *parts, int *nparts,
                 ScalarSrc half = ScalarSrc{nullptr, 0, 1});
+// pipelined BiCGStab (kernels.hip, "pipelined BiCGStab"): partials of k_pipe_a have stride 3, of k_pipe_b stride 5
+int launch_pipe_seed(hipStream_t s, ScalarSrc init, ScalarSrc rww, double *out5);
+int launch_pipe_a(hipStream_t s, LoopArgs la, ScalarSrc B, int64_t n, const double *r, const double *w, const double *t,
+                  const double *v, double *p, double *sv, double *z, double *q, double *y, const double *x, double *xh,
+                  double *parts, int *nparts);
+int launch_pipe_b(hipStream_t s, LoopArgs la, ScalarSrc A, int64_t n, const double *q, const double *y, const double *t,
+                  const double *v, const double *rw, const double *sv, const double *z, const double *xh, double *x, double *r,
+                  double *w, double *parts, int *nparts);
 // standalone stopping tests (one workgroup)
 int launch_check(hipStream_t s, LoopArgs la, ScalarSrc src, int which);
 // out[k] = sum of partials, k < K (one workgroup)

@@ -44,6 +44,11 @@ struct cudamat_solver {
     double *gather = nullptr;  // world * n_pad doubles (sharded runs)
     double *x0_save = nullptr; // the caller's x0, kept while a dependency-driven preconditioner may have to be redone
     double *v2 = nullptr;      // second v buffer of the fused small-system loop (p and r double-buffer in pw and s)
+    // CUDAMAT_LOOP_PIPELINED: z = A s, w = A r, q, y = A q, xh = x + alpha p (n_pad each), partials of k_pipe_a / k_pipe_b,
+    // reduced scalars ([0..2] phase A, [8..12] phase B), events ordering the side-stream reductions
+    double *pz = nullptr, *pww = nullptr, *pq = nullptr, *py = nullptr, *pxh = nullptr;
+    double *pipeA = nullptr, *pipeB = nullptr, *red_pipe = nullptr;
+    hipEvent_t ev_red[2] = {}, ev_red_done[2] = {};
 
     // reduction workspace: four stages of per-workgroup partials + reduced scalars
     double *parts_full = nullptr, *parts_rv = nullptr, *parts_half = nullptr, *parts_tt = nullptr;

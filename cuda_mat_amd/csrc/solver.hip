@@ -44,7 +44,8 @@ static int dev_alloc(void **p, size_t bytes)
 
 static void free_work(cudamat_solver *s)
 {
-    double **vs[] = {&s->r, &s->rw, &s->p, &s->pw, &s->s, &s->t, &s->v, &s->gather, &s->x0_save, &s->v2};
+    double **vs[] = {&s->r, &s->rw, &s->p, &s->pw, &s->s, &s->t, &s->v, &s->gather, &s->x0_save, &s->v2,
+                     &s->pz, &s->pww, &s->pq, &s->py, &s->pxh, &s->pipeA, &s->pipeB, &s->red_pipe};
     for (double **q : vs) {
         if (*q) hipFree(*q);
         *q = nullptr;
@@ -212,6 +213,10 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
         if (s->ev[i]) hipEventDestroy(s->ev[i]);
     for (hipEvent_t e : s->prof_ev) hipEventDestroy(e);
     for (hipEvent_t e : s->comm_ev) hipEventDestroy(e);
+    for (int e = 0; e < 2; e++) {
+        if (s->ev_red[e]) hipEventDestroy(s->ev_red[e]);
+        if (s->ev_red_done[e]) hipEventDestroy(s->ev_red_done[e]);
+    }
     if (s->ev_x) hipEventDestroy(s->ev_x);
     for (hipEvent_t e : s->ev_part)
         if (e) hipEventDestroy(e);
@@ -532,7 +537,8 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     CM_ARG(s && b && x, "null pointer");
     CM_ARG(precond == CUDAMAT_PRECOND_NONE || precond == CUDAMAT_PRECOND_ILU0 || precond == CUDAMAT_PRECOND_BLOCK_ILU0,
            "precond");
-    CM_ARG(loop == CUDAMAT_LOOP_PBICGSTAB || loop == CUDAMAT_LOOP_PBICGSTAB2, "loop");
+    CM_ARG(loop == CUDAMAT_LOOP_PBICGSTAB || loop == CUDAMAT_LOOP_PBICGSTAB2 || loop == CUDAMAT_LOOP_PIPELINED, "loop");
+    CM_ARG(!(loop == CUDAMAT_LOOP_PIPELINED && precond), "the pipelined loop has no preconditioned form here");
     CM_ARG(maxit >= 0, "maxit");
     CM_ARG(!(precond == CUDAMAT_PRECOND_ILU0 && s->sharded),
            "ILU(0) of the whole matrix is single-GPU only (SURVEY 8e); sharded runs take CUDAMAT_PRECOND_BLOCK_ILU0");
@@ -550,7 +556,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
 
     // residual history: two entries per iteration (half / full step) or one; capped at 2^20 entries (8 MB) -- a solve
     // with a larger maxit keeps the first 2^20 (the kernels check the capacity)
-    const long long want_hist = (long long)(loop == CUDAMAT_LOOP_PBICGSTAB ? 2 : 1) * (maxit > 0 ? maxit : 1);
+    const long long want_hist = (long long)(loop != CUDAMAT_LOOP_PBICGSTAB2 ? 2 : 1) * (maxit > 0 ? maxit : 1);
     const int need_hist = (int)(want_hist < (1LL << 20) ? want_hist : (1LL << 20));
     if (need_hist > s->hist_cap) {
         if (s->hist) { CM_HIP(hipStreamSynchronize(st)); hipFree(s->hist); s->hist = nullptr; }
@@ -587,6 +593,67 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     }
     CM_TRY(launch_init_finish(st, s->st, full_src, tol));
 
+    // Pipelined BiCGStab (kernels.hip): extra vectors, w0 = A r0 (with rw.w0), t0 = A w0, and the seed
+    // [rw.r0, rw.w0, 0, 0, r0.r0] of the first k_pipe_a.  A reduction phase = the per-workgroup partials of a
+    // kernel summed (and, sharded, all-reduced) into red_pipe: on the communicator's reduce stream when it has one,
+    // so that it runs beside the SpMV that follows the kernel.
+    const bool pipelined = loop == CUDAMAT_LOOP_PIPELINED;
+    ScalarSrc pipeB_src{nullptr, 0, 1};
+    hipStream_t rst = nullptr;
+    if (pipelined) {
+        const size_t nb = sizeof(double) * (size_t)(s->n_pad > 0 ? s->n_pad : 1);
+        if (!s->pz) {
+            double **vs[] = {&s->pz, &s->pww, &s->pq, &s->py, &s->pxh};
+            for (double **q : vs) {
+                CM_TRY(dev_alloc((void **)q, nb));
+                CM_HIP(hipMemsetAsync(*q, 0, nb, st));
+            }
+            CM_TRY(dev_alloc((void **)&s->pipeA, sizeof(double) * 3 * kVecGridMax));
+            CM_TRY(dev_alloc((void **)&s->pipeB, sizeof(double) * 5 * kVecGridMax));
+            CM_TRY(dev_alloc((void **)&s->red_pipe, sizeof(double) * 16));
+        }
+        if (sharded && s->comm.allreduce_side && s->comm.reduce_stream) {
+            rst = (hipStream_t)s->comm.reduce_stream;
+            for (int e = 0; e < 2; e++) {
+                if (!s->ev_red[e]) CM_HIP(hipEventCreateWithFlags(&s->ev_red[e], hipEventDisableTiming));
+                if (!s->ev_red_done[e]) CM_HIP(hipEventCreateWithFlags(&s->ev_red_done[e], hipEventDisableTiming));
+            }
+        }
+        CM_TRY(spmv_local(s, s->r, s->pww, 1, s->rw, s->parts_rv, la_none, CHECK_NONE, nosrc));     // w0 = A r0, rw.w0
+        ScalarSrc rww{s->parts_rv, spmv_parts(s), 2};
+        if (sharded) {
+            CM_TRY(launch_reduce_parts(st, rww, 1, s->red + 0, 0));
+            CM_TRY(allreduce(s, s->red + 0, 1));
+            rww = ScalarSrc{s->red + 0, 0, 1};
+        }
+        CM_TRY(spmv_local(s, s->pww, s->t, 0, nullptr, nullptr, la_none, CHECK_NONE, nosrc));       // t0 = A w0
+        CM_TRY(launch_pipe_seed(st, full_src, rww, s->red_pipe + 8));
+        pipeB_src = ScalarSrc{s->red_pipe + 8, 0, 1};
+    }
+    // one reduction phase of the pipelined loop: partials -> K sums in `out` (all-reduced when sharded); returns
+    // the source the consumer kernel reads.  With a reduce stream the work is queued there, behind `slot`'s event.
+    auto pipe_reduce = [&](ScalarSrc parts, int K, double *out, int slot) -> int {
+        if (!sharded) return CUDAMAT_OK;                     // the consumer sums the partials itself
+        if (rst) {
+            CM_HIP(hipEventRecord(s->ev_red[slot], st));
+            CM_HIP(hipStreamWaitEvent(rst, s->ev_red[slot], 0));
+            CM_TRY(launch_reduce_parts(rst, parts, K, out, 0));
+            comm_mark_begin(s, 3, rst);
+            if (s->comm.allreduce_side(s->comm.user, out, K) != 0) { set_error("allreduce_side callback failed"); return CUDAMAT_ERR_COMM; }
+            comm_mark_end(s, rst);
+            CM_HIP(hipEventRecord(s->ev_red_done[slot], rst));
+        } else {
+            CM_TRY(launch_reduce_parts(st, parts, K, out, 0));
+            CM_TRY(allreduce(s, out, K));
+        }
+        return CUDAMAT_OK;
+    };
+    auto pipe_wait = [&](int slot) -> int {
+        if (sharded && rst) CM_HIP(hipStreamWaitEvent(st, s->ev_red_done[slot], 0));
+        return CUDAMAT_OK;
+    };
+    int np_a = 0, np_b = 0;
+
     // Small systems (vectors resident in L2): three launches per iteration instead of five -- the vector updates
     // in front of the two SpMVs are folded into them (kernels.hip, "fused loop"); p, v and r are double-buffered.
     bool fused = false;
@@ -598,7 +665,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
         const char *fe = getenv("CUDAMAT_FUSED");
         const bool forced = fe && fe[0] != '\0';
         const long long max_rows = forced ? atoll(fe) : 300000;
-        fused = !sharded && !precond && s->spmv_mode == 0 && fused_spmv_supported(s->plan) && n > 0 && n <= max_rows &&
+        fused = loop != CUDAMAT_LOOP_PIPELINED && !sharded && !precond && s->spmv_mode == 0 && fused_spmv_supported(s->plan) && n > 0 && n <= max_rows &&
                 (forced || s->plan.stream_rows > 0);
         if (fused && !s->v2) {
             const size_t nb = sizeof(double) * (size_t)(s->n_pad > 0 ? s->n_pad : 1);
@@ -632,6 +699,29 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             if ((unsigned)(w & 0xffffffffULL) != 0u) break;
         }
         la.k = k;
+        if (pipelined) {
+            // full-step test of iteration k-1, beta, alpha, the five recurrences; dots (q.y, y.y, q.q)
+            CM_TRY(launch_pipe_a(st, la, pipeB_src, n, s->r, s->pww, s->t, s->v, s->p, s->s, s->pz, s->pq, s->py, x, s->pxh,
+                                 s->pipeA, &np_a));
+            ScalarSrc a_src{s->pipeA, np_a, 3};
+            CM_TRY(pipe_reduce(a_src, 3, s->red_pipe + 0, 0));
+            if (sharded) a_src = ScalarSrc{s->red_pipe + 0, 0, 1};
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            CM_TRY(spmv_local(s, s->pz, s->v, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));           // v = A z
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            CM_TRY(pipe_wait(0));
+            // half-step test, omega, x, r, w; dots (rw.r, rw.w, rw.s, rw.z, r.r); i++
+            CM_TRY(launch_pipe_b(st, la, a_src, n, s->pq, s->py, s->t, s->v, s->rw, s->s, s->pz, s->pxh, x, s->r, s->pww,
+                                 s->pipeB, &np_b));
+            pipeB_src = ScalarSrc{s->pipeB, np_b, 5};
+            CM_TRY(pipe_reduce(pipeB_src, 5, s->red_pipe + 8, 1));
+            if (sharded) pipeB_src = ScalarSrc{s->red_pipe + 8, 0, 1};
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            CM_TRY(spmv_local(s, s->pww, s->t, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));          // t = A w
+            if (profile) hipEventRecord(prof_event(s, pe++), st);
+            CM_TRY(pipe_wait(1));
+            continue;
+        }
         if (fused) {
             SpmvArgs a{};
             a.n = n; a.rp = s->rp; a.ci = s->ci; a.val = s->val; a.x = nullptr; a.d = s->d; a.xd = nullptr;
@@ -730,7 +820,10 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
         }
     }
     // the full-step test of the last iteration has not been looked at yet
-    CM_TRY(launch_check(st, la, full_src, CHECK_FULL));
+    if (pipelined)      // (check_full wants (., r.r): the last two of the five phase-B scalars)
+        CM_TRY(launch_check(st, la, ScalarSrc{pipeB_src.ptr + 3, pipeB_src.count, pipeB_src.stride}, CHECK_FULL));
+    else
+        CM_TRY(launch_check(st, la, full_src, CHECK_FULL));
     CM_HIP(hipMemcpyAsync(&s->st_ring[0], s->st, sizeof(LoopState), hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));                              // :372
     const double t_loop1 = now_s();
@@ -754,7 +847,11 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
         }
     }
     const LoopState fin = s->st_ring[0];
-    s->hist_count = (loop == CUDAMAT_LOOP_PBICGSTAB) ? 2 * fin.it + (fin.state == 1 ? 1 : 0) : fin.it;
+    if (pipelined && fin.state == 1) {      // left through the half step: the iterate is x + alpha p, kept in xh
+        CM_HIP(hipMemcpyAsync(x, s->pxh, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        CM_HIP(hipStreamSynchronize(st));
+    }
+    s->hist_count = (loop != CUDAMAT_LOOP_PBICGSTAB2) ? 2 * fin.it + (fin.state == 1 ? 1 : 0) : fin.it;
     if (s->hist_count > s->hist_cap) s->hist_count = s->hist_cap;
 
     cudamat_stats stt;
@@ -805,7 +902,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
         std::vector<double> h((size_t)(s->hist_count > 0 ? s->hist_count : 1));
         if (s->hist_count > 0)
             hipMemcpy(h.data(), s->hist, sizeof(double) * (size_t)s->hist_count, hipMemcpyDeviceToHost);
-        if (loop == CUDAMAT_LOOP_PBICGSTAB) {
+        if (loop != CUDAMAT_LOOP_PBICGSTAB2) {
             printf("gpu, init residual:norm %20.16f\n", fin.nrm0);            // :77
             for (int i = 0; i < s->hist_count; i++) {
                 if ((i & 1) == 0) printf("i = %d, residual norm (before precond) = %g\n", i / 2, h[i]);  // :114

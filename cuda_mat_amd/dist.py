@@ -15,7 +15,7 @@ import numpy as np
 
 from ._lib import ALLGATHER_FN, ALLREDUCE_FN, GATHER_PART_FN, Comm
 
-RCCL_ID_BYTES = 256     # CUDAMAT_RCCL_ID_BYTES
+RCCL_ID_BYTES = 384     # CUDAMAT_RCCL_ID_BYTES
 
 
 def shard_rows(n, world, rank):

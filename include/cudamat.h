@@ -67,6 +67,10 @@ extern "C" {
                                        against tol*||r0||, no breakdown guard           */
 #define CUDAMAT_LOOP_PBICGSTAB2 1   /* pbicgstab.cu:581-754: end-of-iteration exit,
                                        |omega| < 1e-5 / NaN guard => not converged      */
+#define CUDAMAT_LOOP_PIPELINED  2   /* pipelined BiCGStab (Cools & Vanroose 2017, Alg. 4): the recurrences of
+                                     * LOOP_PBICGSTAB re-arranged so that both reduction phases of an iteration run
+                                     * while an SpMV runs; same stopping rules and history layout;
+                                     * no preconditioner; iterates equal BiCGSTAB's up to rounding              */
 
 /* flags for cudamat_solver_solve */
 #define CUDAMAT_FLAG_DEBUG      1   /* print the reference's debug lines                */
@@ -136,6 +140,10 @@ typedef struct cudamat_comm {
     cudamat_allreduce_fn allreduce;
     cudamat_gather_part_fn gather_part;   /* may be NULL */
     void *comm_stream;                    /* hipStream_t gather_part enqueues on (NULL with gather_part NULL) */
+    /* optional: allreduce enqueued on `reduce_stream` (a third stream of the communicator) instead of the
+     * context's stream, so that CUDAMAT_LOOP_PIPELINED can run a reduction while an SpMV runs              */
+    cudamat_allreduce_fn allreduce_side;  /* may be NULL: the pipelined loop then reduces on its own stream */
+    void *reduce_stream;
 } cudamat_comm;
 
 /* ---- the library's own communicator: RCCL over xGMI, bound at run time ---------------- */
@@ -146,7 +154,7 @@ typedef struct cudamat_comm {
  * communicator (collective: returns when all `world` ranks have joined), passes it to
  * cudamat_solver_set_comm and destroys it after the solver.  The collectives run on the
  * context's stream, the pieces of an overlapped gather on a stream the communicator owns.  */
-#define CUDAMAT_RCCL_ID_BYTES 256
+#define CUDAMAT_RCCL_ID_BYTES 384
 int cudamat_rccl_available(void);                  /* 1 when librccl could be loaded */
 int cudamat_rccl_unique_id(void *id);              /* fills CUDAMAT_RCCL_ID_BYTES bytes */
 int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int rank, int world, cudamat_comm *out);

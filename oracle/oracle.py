@@ -56,6 +56,8 @@ def lib():
                                      C.POINTER(C.c_double)]
         L.orc_pbicgstab.argtypes = [C.c_int, i32p, i32p, f64p, C.c_void_p, f64p, f64p, C.c_int,
                                     C.c_double, C.c_void_p, C.c_int, C.POINTER(Stats)]
+        L.orc_pipelined_bicgstab.argtypes = [C.c_int, i32p, i32p, f64p, f64p, f64p, C.c_int, C.c_double,
+                                             C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_pbicgstab2.argtypes = [C.c_int, i32p, i32p, f64p, C.c_void_p, f64p, f64p, C.c_int,
                                      C.c_double, f64p, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_ilu0.argtypes = [C.c_int, i32p, i32p, f64p]
@@ -197,6 +199,17 @@ def pbicgstab(A, f, x0=None, vm=None, maxit=2000, tol=1e-6, want_hist=False):
     lib().orc_pbicgstab(A.n, A.rowptr, A.colidx, A.val, vmp, _f(f), x, maxit, tol,
                         None if hist is None else hist.ctypes.data_as(C.c_void_p),
                         0 if hist is None else len(hist), C.byref(st))
+    return (x, st, hist) if want_hist else (x, st)
+
+
+def pipelined_bicgstab(A, f, x0=None, maxit=2000, tol=1e-6, want_hist=False):
+    """pipelined BiCGStab (Cools & Vanroose 2017, Alg. 4), stopping rules of pbicgstab.cu:116,147; x0 defaults to ones"""
+    x = np.ones(A.n) if x0 is None else _f(x0).copy()
+    st = Stats()
+    hist = np.full(2 * maxit, np.nan) if want_hist else None
+    lib().orc_pipelined_bicgstab(A.n, A.rowptr, A.colidx, A.val, _f(f), x, maxit, tol,
+                                 None if hist is None else hist.ctypes.data_as(C.c_void_p),
+                                 0 if hist is None else len(hist), C.byref(st))
     return (x, st, hist) if want_hist else (x, st)
 
 

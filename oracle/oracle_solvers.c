@@ -366,3 +366,85 @@ int orc_pbicgstab2(int n, const int *rp, const int *ci, const double *a0,
     free(p); free(p_); free(s); free(t); free(h);
     return result;
 }
+
+
+/* =========================================================================
+ * Pipelined BiCGStab (second half).  NOT in the reference: a re-arrangement of the
+ * recurrences of pbicgstab.cu:45-154 (M = I) after Cools & Vanroose, "The communication-hiding pipelined
+ * BiCGStab method for the parallel solution of large unsymmetric linear systems", Parallel Computing 65
+ * (2017), Alg. 4, so that each of the two reduction phases of an iteration can run WHILE an SpMV runs.
+ * In exact arithmetic the iterates are those of BiCGSTAB; in floating point they differ by rounding.
+ *   s = A p, z = A s, v = A z, w = A r, t = A w, q = r - alpha s ("s" of pbicgstab.cu:109), y = A q
+ *   p_i = r_i + beta (p - omega s);  s_i = w_i + beta (s - omega z);  z_i = t_i + beta (z - omega v)
+ *   q_i = r_i - alpha s_i;  y_i = w_i - alpha z_i;               [dots (q,y) (y,y) (q,q)]  ||  v_i = A z_i
+ *   omega = (q,y)/(y,y);  x += alpha p + omega q;  r' = q - omega y;  w' = y - omega (t - alpha v)
+ *                                    [dots (rw,r') (rw,w') (rw,s) (rw,z) (r',r')]  ||  t' = A w'
+ *   beta = (alpha/omega) (rw,r')/(rw,r);  alpha' = (rw,r') / ((rw,w') + beta (rw,s) - beta omega (rw,z))
+ * Stopping tests as in the reference loop: half step on ||q|| (:116, x += alpha p only), full step on ||r'||
+ * (:147), both against tol * ||r0||; x0 as passed.  hist as orc_pbicgstab.
+ * ========================================================================= */
+int orc_pipelined_bicgstab(int n, const int *rp, const int *ci, const double *a, const double *f, double *x,
+                           int maxit, double tol, double *hist, int hist_cap, orc_stats *st)
+{
+    double *r = dalloc(n), *rw = dalloc(n), *p = dalloc(n), *s = dalloc(n), *z = dalloc(n), *v = dalloc(n);
+    double *w = dalloc(n), *t = dalloc(n), *q = dalloc(n), *y = dalloc(n);
+    double alpha = 0.0, beta = 0.0, omega = 0.0, rho, rho_new, rw_w, rw_s = 0.0, rw_z = 0.0, nrmr, nrmr0;
+    int i = 0, k, half_exit = 0, converged = 0;
+
+    orc_csrmv(n, rp, ci, a, 1.0, x, 0.0, r);
+    for (k = 0; k < n; k++) r[k] = f[k] - r[k];               /* r0 = f - A x0 (:67-70) */
+    memcpy(rw, r, sizeof(double) * (size_t)n);                /* shadow residual (:72)  */
+    nrmr0 = orc_nrm2(n, r);
+    nrmr = nrmr0;
+    orc_csrmv(n, rp, ci, a, 1.0, r, 0.0, w);                  /* w0 = A r0 */
+    orc_csrmv(n, rp, ci, a, 1.0, w, 0.0, t);                  /* t0 = A w0 */
+    rho = orc_dot(n, rw, r);
+    rw_w = orc_dot(n, rw, w);
+    if (nrmr0 == 0.0) { converged = 1; maxit = 0; }
+    for (i = 0; i < maxit;) {
+        if (i == 0) {
+            alpha = rho / rw_w;
+            for (k = 0; k < n; k++) { p[k] = r[k]; s[k] = w[k]; z[k] = t[k]; }
+        } else {
+            alpha = rho / (rw_w + beta * rw_s - beta * omega * rw_z);
+            for (k = 0; k < n; k++) {
+                p[k] = r[k] + beta * (p[k] - omega * s[k]);
+                s[k] = w[k] + beta * (s[k] - omega * z[k]);
+                z[k] = t[k] + beta * (z[k] - omega * v[k]);
+            }
+        }
+        for (k = 0; k < n; k++) { q[k] = r[k] - alpha * s[k]; y[k] = w[k] - alpha * z[k]; }
+        const double qy = orc_dot(n, q, y), yy = orc_dot(n, y, y);
+        nrmr = orc_nrm2(n, q);
+        orc_csrmv(n, rp, ci, a, 1.0, z, 0.0, v);              /* v = A z   (overlaps the reduction) */
+        if (hist && 2 * i < hist_cap) hist[2 * i] = nrmr;
+        if (nrmr < tol * nrmr0) {                             /* half-step exit (:116) */
+            for (k = 0; k < n; k++) x[k] += alpha * p[k];
+            half_exit = 1; converged = 1;
+            break;
+        }
+        omega = qy / yy;
+        for (k = 0; k < n; k++) {
+            x[k] += alpha * p[k] + omega * q[k];
+            r[k] = q[k] - omega * y[k];
+            w[k] = y[k] - omega * (t[k] - alpha * v[k]);
+        }
+        rho_new = orc_dot(n, rw, r);
+        rw_w = orc_dot(n, rw, w);
+        rw_s = orc_dot(n, rw, s);
+        rw_z = orc_dot(n, rw, z);
+        nrmr = orc_nrm2(n, r);
+        orc_csrmv(n, rp, ci, a, 1.0, w, 0.0, t);              /* t = A w   (overlaps the reduction) */
+        beta = (alpha / omega) * (rho_new / rho);
+        rho = rho_new;
+        if (hist && 2 * i + 1 < hist_cap) hist[2 * i + 1] = nrmr;
+        i++;
+        if (nrmr < tol * nrmr0) { converged = 1; break; }     /* full-step exit (:147) */
+    }
+    if (st) {
+        st->iters = i; st->half_exit = half_exit; st->converged = converged; st->breakdown = 0;
+        st->nrm0 = nrmr0; st->nrm = nrmr;
+    }
+    free(r); free(rw); free(p); free(s); free(z); free(v); free(w); free(t); free(q); free(y);
+    return 0;
+}

@@ -55,6 +55,12 @@ def main():
         assert torch.equal(tx2, tx), "native RCCL collectives must reproduce the torch.distributed run bit for bit"
         assert st2.n_gather >= 1 + 2 * st.iters and st2.n_allreduce >= 1 + 3 * st.iters and st2.ms_gather > 0
         assert st2.overlapped == 0 and abs(st2.ms_gather - st2.ms_gather_exposed) < 1e-9
+        # the pipelined loop: its reductions are ncclAllReduce calls on the communicator's third stream
+        tx3 = torch.ones(n, dtype=torch.float64, device=dev)
+        st3 = s.solve(tb, tx3, loop=cm.LOOP_PIPELINED, maxit=200, tol=1e-8, flags=cm.FLAG_PROFILE)
+        stream.synchronize()
+        assert st3.converged and abs(st3.iters - st.iters) <= 1 and st3.n_allreduce >= 2 * st3.iters
+        assert float((tx3 - tx).abs().max()) <= 1e-7
         s.close()
         rc.close()
         ctx.close()

@@ -102,27 +102,44 @@ class ThreadComm:
     """cudamat_comm whose collectives are host-synchronised copies between the ranks' buffers:
     slow, but it drives the real C++ sharded loop with W > 1 on a single GPU."""
 
-    def __init__(self, cm, group, rank, ctx, pieces=False):
-        """pieces=True also offers gather_part (the overlapped gather) on a stream of its own: a second Context"""
+    def __init__(self, cm, group, rank, ctx, pieces=False, side_reduce=False):
+        """pieces=True also offers gather_part (the overlapped gather) on a stream of its own: a second Context;
+        side_reduce=True offers allreduce_side on a third one (the pipelined loop's reductions beside an SpMV)"""
         from cuda_mat_amd._lib import ALLGATHER_FN, ALLREDUCE_FN, GATHER_PART_FN, Comm
         self.cm, self.g, self.rank, self.ctx = cm, group, rank, ctx
-        self.n_allgather = self.n_allreduce = self.n_parts = 0
+        self.n_allgather = self.n_allreduce = self.n_parts = self.n_side = 0
         self._ag = ALLGATHER_FN(self._allgather)
         self._ar = ALLREDUCE_FN(self._allreduce)
-        self.cctx = None
+        self.cctx = self.rctx = None
+        gp, gstream, ars, rstream = GATHER_PART_FN(), None, ALLREDUCE_FN(), None
         if pieces:
             self.cctx = cm.Context(ctx.device)
-            stream = C.c_void_p()
-            assert cm.lib().cudamat_ctx_stream(self.cctx.h, C.byref(stream)) == 0
-            self._gp = GATHER_PART_FN(self._gather_part)
-            self.struct = Comm(rank, group.world, None, self._ag, self._ar, self._gp, stream)
-        else:
-            self.struct = Comm(rank, group.world, None, self._ag, self._ar, GATHER_PART_FN(), None)
+            gstream = C.c_void_p()
+            assert cm.lib().cudamat_ctx_stream(self.cctx.h, C.byref(gstream)) == 0
+            self._gp = gp = GATHER_PART_FN(self._gather_part)
+        if side_reduce:
+            self.rctx = cm.Context(ctx.device)
+            rstream = C.c_void_p()
+            assert cm.lib().cudamat_ctx_stream(self.rctx.h, C.byref(rstream)) == 0
+            self._ars = ars = ALLREDUCE_FN(self._allreduce_side)
+        self.struct = Comm(rank, group.world, None, self._ag, self._ar, gp, gstream, ars, rstream)
 
     def close(self):
-        if self.cctx is not None:
-            self.cctx.close()
-            self.cctx = None
+        for c in (self.cctx, self.rctx):
+            if c is not None:
+                c.close()
+        self.cctx = self.rctx = None
+
+    def _allreduce_side(self, user, buf, count):
+        """the same sum as _allreduce, ordered on the reduce stream (synchronised here: the emulation is host-driven)"""
+        try:
+            self.rctx.sync()              # the partial sums were reduced into buf on this stream
+            rc = self._reduce_with(self.rctx, buf, count)
+            self.n_side += 1
+            return rc
+        except Exception:                                 # noqa: BLE001
+            self.g.barrier.abort()
+            return 1
 
     def _gather_part(self, user, send, recv, stride, offset, count):
         try:
@@ -158,20 +175,24 @@ class ThreadComm:
             self.g.barrier.abort()
             return 1
 
+    def _reduce_with(self, ctx, buf, count):
+        L = self.cm.lib()
+        mine = np.empty(count)
+        assert L.cudamat_d2h(ctx.h, _p(mine), buf, 8 * count) == 0
+        self.g.vals[self.rank] = mine
+        self.g.barrier.wait()
+        tot = np.zeros(count)
+        for r in range(self.g.world):                     # fixed order: identical on every rank
+            tot = tot + self.g.vals[r]
+        self.g.barrier.wait()
+        assert L.cudamat_h2d(ctx.h, buf, _p(tot), 8 * count) == 0
+        return 0
+
     def _allreduce(self, user, buf, count):
         try:
-            L = self.cm.lib()
-            mine = np.empty(count)
-            assert L.cudamat_d2h(self.ctx.h, _p(mine), buf, 8 * count) == 0
-            self.g.vals[self.rank] = mine
-            self.g.barrier.wait()
-            tot = np.zeros(count)
-            for r in range(self.g.world):                 # fixed order: identical on every rank
-                tot = tot + self.g.vals[r]
-            self.g.barrier.wait()
-            assert L.cudamat_h2d(self.ctx.h, buf, _p(tot), 8 * count) == 0
+            rc = self._reduce_with(self.ctx, buf, count)
             self.n_allreduce += 1
-            return 0
+            return rc
         except Exception:                                 # noqa: BLE001
             self.g.barrier.abort()
             return 1

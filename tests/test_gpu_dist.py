@@ -29,7 +29,7 @@ def cm():
     return cm
 
 
-def _run_rank(cm, group, rank, n, A, b, out, pieces=False, **kw):
+def _run_rank(cm, group, rank, n, A, b, out, pieces=False, side_reduce=False, **kw):
     import dist_sim
     from cuda_mat_amd.dist import shard_rows
     try:
@@ -38,7 +38,7 @@ def _run_rank(cm, group, rank, n, A, b, out, pieces=False, **kw):
         rp = (A.rowptr[row0:row1 + 1] - A.rowptr[row0]).astype(np.int32)
         k0, k1 = A.rowptr[row0], A.rowptr[row1]
         s = cm.Solver.from_host_csr(ctx, rp, A.colidx[k0:k1], A.val[k0:k1], n_cols=n)
-        comm = dist_sim.ThreadComm(cm, group, rank, ctx, pieces=pieces)
+        comm = dist_sim.ThreadComm(cm, group, rank, ctx, pieces=pieces, side_reduce=side_reduce)
         s.set_comm(comm.struct)
         db, dx = ctx.array(b[row0:row1]), ctx.array(np.ones(row1 - row0))
         # y = A x through the sharded SpMV entry point
@@ -47,7 +47,7 @@ def _run_rank(cm, group, rank, n, A, b, out, pieces=False, **kw):
         y = dy.download()
         st = s.solve(db, dx, **kw)
         out[rank] = (row0, row1, dx.download(), st.as_dict(), s.history(), y, comm.n_allgather, comm.n_allreduce,
-                     comm.n_parts)
+                     comm.n_parts, comm.n_side)
         s.close()
         comm.close()
         ctx.close()
@@ -196,6 +196,48 @@ def test_overlapped_gather_is_bit_identical(cm, oracle, monkeypatch, world, n, p
     np.testing.assert_array_equal(y, oracle.spmv(A, b))
     x = np.concatenate([o[2] for o in on])
     np.testing.assert_allclose(x, xs, rtol=1e-7)
+
+
+@pytest.mark.parametrize("world,n,per_row", [(4, 30011, 24), (2, 20000, 50)])
+def test_pipelined_loop_sharded(cm, oracle, monkeypatch, world, n, per_row):
+    """CUDAMAT_LOOP_PIPELINED row-sharded: the reductions of an iteration on the communicator's reduce stream
+    (beside the SpMV) or on the solver's stream give the same iterates bit for bit; the sharded solve agrees with
+    the oracle's pipelined restatement (history 1e-9, same exit) and returns x*; 2 all-gathers and 2 all-reduces per
+    iteration (the standard loop needs 3)"""
+    import dist_sim
+    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "pb")
+    A = oracle.rand_rows(n, per_row, 0xBEEF)
+    xs = oracle.xstar(n, 0x5EEE)
+    b = oracle.spmv(A, xs)
+    res = {}
+    for side in (True, False):
+        group = dist_sim.ThreadGroup(world)
+        out = [None] * world
+        th = [threading.Thread(target=_run_rank, args=(cm, group, r, n, A, b, out),
+                               kwargs=dict(pieces=True, side_reduce=side, loop=cm.LOOP_PIPELINED, maxit=200, tol=1e-8))
+              for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=180)
+        for o in out:
+            assert not isinstance(o, Exception) and o is not None, o
+        res[side] = out
+    for a, c in zip(res[True], res[False]):
+        np.testing.assert_array_equal(a[2], c[2])
+        np.testing.assert_array_equal(a[4], c[4])
+        assert a[3]["iters"] == c[3]["iters"] and a[3]["half_exit"] == c[3]["half_exit"] and a[3]["converged"]
+    o0 = res[True][0]
+    it, half = o0[3]["iters"], o0[3]["half_exit"]
+    ran = it + (1 if half else 0)
+    assert 2 * ran <= o0[9] <= 2 * (ran + 3) and res[False][0][9] == 0            # side all-reduces: 2 per iteration
+    xo, so, ho = oracle.pipelined_bicgstab(A, b, maxit=200, tol=1e-8, want_hist=True)
+    assert (it, half) == (so.iters, so.half_exit)
+    k = min(len(o0[4]), 6)
+    np.testing.assert_allclose(o0[4][:k], ho[:k], rtol=1e-9)
+    x = np.concatenate([o[2] for o in res[True]])
+    np.testing.assert_allclose(x, xs, rtol=1e-7)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
 
 
 def test_bench_two_processes_share_the_gpu_over_gloo():

@@ -1071,3 +1071,71 @@ def test_exact_initial_guess_returns_at_once(cm, ctx, oracle, precond):
         x, st, h = _solve_dev(cm, ctx, A, b, precond=precond, loop=loop, maxit=50, tol=1e-8)
         assert st.converged and st.iters == 0 and not st.breakdown and st.nrm0 == 0.0
         np.testing.assert_array_equal(x, np.ones(A.n))
+
+
+# ------------------------------------------------------------- pipelined BiCGStab
+@pytest.mark.parametrize("name,tol", [("mat900", 1e-8), ("mat10000", 1e-8), ("rand20000", 1e-8), ("poisson", 1e-8)])
+def test_pipelined_bicgstab_vs_oracle(cm, ctx, oracle, golden_dir, name, tol):
+    """CUDAMAT_LOOP_PIPELINED (Cools & Vanroose 2017, Alg. 4) is NOT a reference algorithm: its parity statement is
+    (a) the oracle's restatement of the published recurrences (oracle_solvers.c orc_pipelined_bicgstab): residual
+    history 1e-8 relative over the first iterations, iteration count +-15 % (>= +-2: the longer recurrences carry
+    rounding differences forward, so late iterations of a 60-70 iteration solve wander by a few), solution 1e-6;
+    (b) the reference loop it re-arranges (pbicgstab.cu:45-154, M = I): same solution to 1e-5, iteration count
+    within +-15 %; (c) the true residual under 10 tol ||r0||."""
+    if name == "rand20000":
+        A = oracle.rand_rows(20000, 50, 0x5EED)
+    elif name == "poisson":
+        A = oracle.poisson5(300, 200)
+    else:
+        A = _load(oracle, golden_dir, name)
+    xs = 1.0 + np.sin(np.arange(A.n))
+    b = oracle.spmv(A, xs)
+    before = oracle.num_threads()
+    oracle.set_num_threads(1)                # fixed summation order in the checker
+    try:
+        xo, so, ho = oracle.pipelined_bicgstab(A, b, maxit=2000, tol=tol, want_hist=True)
+        xr, sr = oracle.pbicgstab(A, b, maxit=2000, tol=tol)
+    finally:
+        oracle.set_num_threads(before)
+    x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PIPELINED, maxit=2000, tol=tol)
+    assert st.converged and so.converged
+    assert abs(st.iters - so.iters) <= max(2, 0.15 * so.iters)
+    assert abs(st.iters - sr.iters) <= max(2, 0.15 * sr.iters)
+    k = min(len(h), 8, 2 * so.iters)
+    np.testing.assert_allclose(h[:k], ho[:k], rtol=1e-8)
+    assert len(h) == 2 * st.iters + (1 if st.half_exit else 0)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+    assert np.linalg.norm(x - xr) / np.linalg.norm(xr) <= 1e-5
+    r0 = np.linalg.norm(b - oracle.spmv(A, np.ones(A.n)))
+    assert np.linalg.norm(b - oracle.spmv(A, x)) <= 10 * tol * r0
+    # the standard loop on the GPU agrees too
+    x2, st2, h2 = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=2000, tol=tol)
+    assert np.linalg.norm(x - x2) / np.linalg.norm(x2) <= 1e-5
+
+
+def test_pipelined_bicgstab_exits_and_limits(cm, ctx, oracle):
+    """half-step exit returns x + alpha p (kept in a side buffer), maxit stops without convergence, an exact initial
+    guess converges in 0 iterations, NO_EXIT runs the full window, preconditioners are refused"""
+    A = oracle.rand_rows(5000, 12, 7)
+    xs = oracle.xstar(A.n, 3)
+    b = oracle.spmv(A, xs)
+    seen_half = seen_full = False
+    for tol in (1e-3, 1e-5, 1e-8, 1e-11):
+        x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PIPELINED, maxit=100, tol=tol)
+        xo, so = oracle.pipelined_bicgstab(A, b, maxit=100, tol=tol)
+        assert st.converged and (st.iters, st.half_exit) == (so.iters, so.half_exit), (tol, st.iters, so.iters)
+        np.testing.assert_allclose(x, xo, rtol=1e-9, atol=1e-12)
+        seen_half |= bool(st.half_exit)
+        seen_full |= not st.half_exit
+    assert seen_half and seen_full, "the tolerances above were chosen to leave through both tests"
+    x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PIPELINED, maxit=2, tol=1e-14)
+    assert st.iters == 2 and not st.converged and len(h) == 4
+    x, st, h = _solve_dev(cm, ctx, A, b, x0=xs, loop=cm.LOOP_PIPELINED, maxit=50, tol=1e-8)
+    assert st.converged and st.iters == 0 and np.array_equal(x, xs)
+    x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PIPELINED, maxit=4, tol=1e-2, flags=cm.FLAG_NO_EXIT)
+    assert st.iters == 4 and len(h) == 8
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+    with pytest.raises(cm.CudamatError) as e:
+        s.solve(ctx.array(b), ctx.array(np.ones(A.n)), precond=cm.PRECOND_ILU0, loop=cm.LOOP_PIPELINED)
+    assert e.value.code == 2
+    s.close()
