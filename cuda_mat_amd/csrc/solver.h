@@ -4,6 +4,7 @@
 
 #include "kernels.h"
 #include "spmv_pb.h"
+#include "spmv_sell.h"
 
 namespace cm {
 
@@ -33,10 +34,11 @@ struct cudamat_solver {
     double *val = nullptr;
     const double *d = nullptr;
     cm::SpmvPlan plan{};
-    int spmv_mode = -1;        // -1 undecided, 0 CSR wave-per-row kernel, 1 propagation-blocking kernels
+    int spmv_mode = -1;        // -1 undecided, 0 CSR forms, 1 blocked two-phase kernels, 2 SELL-C-sigma
     bool cols_sorted = true;   // every row's columns strictly increasing (checked at creation)
     cm::PbPlan pb{};
-    double ms_csr = 0.0, ms_pb = 0.0;   // auto-tune timings
+    cm::SellPlan sell{};
+    double ms_csr = 0.0, ms_pb = 0.0, ms_sell = 0.0;   // auto-tune timings
 
     // work vectors (n_pad doubles each, pad kept zero)
     double *r = nullptr, *rw = nullptr, *p = nullptr, *pw = nullptr, *s = nullptr, *t = nullptr,

@@ -201,6 +201,7 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     hipStreamSynchronize(s->ctx->stream);
     ilu0_release(s);
     pb_free(&s->pb);
+    sell_free(&s->sell);
     free_work(s);
     plan_spmv_free(&s->plan);
     void *ptrs[] = {s->rp, s->ci, s->val, s->parts_full, s->parts_rv, s->parts_half, s->parts_tt,
@@ -237,6 +238,7 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     hipStreamSynchronize(s->ctx->stream);
     free_work(s);
     pb_free(&s->pb);
+    sell_free(&s->sell);
     ilu0_release(s);           // factors belong to the old partition
     s->spmv_mode = -1;
     s->overlap = false;
@@ -364,15 +366,22 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
         return launch_pb_phase2(st, p, a);
     }
     if (s->spmv_mode == 1) return launch_spmv_pb(s->ctx->stream, s->pb, a);
+    if (s->spmv_mode == 2) return launch_spmv_sell(s->ctx->stream, s->sell, a);
     return launch_spmv(s->ctx->stream, s->plan, a);
 }
 
 // number of per-workgroup partial sums an SpMV launch leaves in `parts`
-static int spmv_parts(const cudamat_solver *s) { return s->spmv_mode == 1 ? s->pb.NRB : plan_spmv_parts(s->plan); }
+static int spmv_parts(const cudamat_solver *s)
+{
+    return s->spmv_mode == 1 ? s->pb.NRB : s->spmv_mode == 2 ? s->sell.grid : plan_spmv_parts(s->plan);
+}
 
-// Choose the SpMV implementation for this matrix (once): the blocked two-phase kernels when the
-// columns are scattered over a vector far larger than L2 AND they measure faster than the
-// wave-per-row CSR kernel on this device.  CUDAMAT_SPMV_MODE=csr|pb overrides.
+// Choose the SpMV implementation for this matrix (once), by TIMING the candidates on this device:
+//   0  the CSR forms (lanes per row / stream tiles / nnz-balanced tiles, plan_spmv_refine) -- always a candidate;
+//   1  the blocked two-phase kernels, when the columns are scattered over a vector far larger than L2 (pb_candidate);
+//   2  SELL-C-sigma, when row lengths vary (the lanes-per-row plan wastes lane-iterations) and the padded copy
+//      stays below 1.5 x the entries.
+// CUDAMAT_SPMV_MODE=csr|pb|sell overrides.
 static int ensure_spmv_mode(cudamat_solver *s)
 {
     if (s->spmv_mode >= 0) return CUDAMAT_OK;
@@ -380,44 +389,59 @@ static int ensure_spmv_mode(cudamat_solver *s)
     const char *env = getenv("CUDAMAT_SPMV_MODE");
     const bool force_csr = env && !strcmp(env, "csr");
     const bool force_pb = env && !strcmp(env, "pb");
+    const bool force_sell = env && !strcmp(env, "sell");
     s->spmv_mode = 0;
     if (force_csr || s->n == 0 || s->nnz == 0) return CUDAMAT_OK;
-    if (!s->cols_sorted) {        // the blocked builder ranks entries by runs of equal column block: needs sorted rows
-        if (force_pb) { set_error("the blocked SpMV needs rows with increasing column indices"); return CUDAMAT_ERR_ARG; }
-        return CUDAMAT_OK;
+    bool have[3] = {true, false, false};
+    // ---- blocked two-phase copy
+    if (!force_sell) {
+        if (!s->cols_sorted) {    // the blocked builder ranks entries by runs of equal column block: needs sorted rows
+            if (force_pb) { set_error("the blocked SpMV needs rows with increasing column indices"); return CUDAMAT_ERR_ARG; }
+        } else if (force_pb || pb_candidate(st, s->n, s->n_cols, s->nnz, s->rp, s->ci)) {
+            // a sharded solver cuts the column blocks at the slices (and, for an overlapped gather, the pieces) of the
+            // gathered vector; the gather buffer's index IS the column id (uniform slices of n_pad)
+            PbCols cols;
+            const bool can_overlap = s->sharded && s->comm.world > 1 && s->comm.gather_part && s->comm.comm_stream;
+            if (s->sharded && s->comm.world > 1) {
+                cols.per = s->n_pad;
+                cols.rank = s->comm.rank;
+                cols.chunks = can_overlap ? s->overlap_chunks : 1;
+            }
+            const int rc = pb_build(st, s->n, s->n_cols, s->nnz, s->rp, s->ci, s->val, &s->pb, &cols);
+            if (rc != CUDAMAT_OK && force_pb) return rc;
+            have[1] = rc == CUDAMAT_OK;          // e.g. out of memory for the blocked copy: keep the others
+        }
+        if (force_pb) { s->spmv_mode = 1; return CUDAMAT_OK; }
     }
-    if (!force_pb && !pb_candidate(st, s->n, s->n_cols, s->nnz, s->rp, s->ci)) return CUDAMAT_OK;
-    // a sharded solver cuts the column blocks at the slices (and, for an overlapped gather, the pieces) of the
-    // gathered vector; the gather buffer's index IS the column id (uniform slices of n_pad)
-    PbCols cols;
-    const bool can_overlap = s->sharded && s->comm.world > 1 && s->comm.gather_part && s->comm.comm_stream;
-    if (s->sharded && s->comm.world > 1) {
-        cols.per = s->n_pad;
-        cols.rank = s->comm.rank;
-        cols.chunks = can_overlap ? s->overlap_chunks : 1;
+    // ---- SELL-C-sigma copy: rows of 8 entries and more (shorter rows belong to the stream kernel, which measures
+    // faster there: C3 0.174 vs 0.191 ms) whose padded copy stays below 1.5 x the entries.  Measured on 2e6-row banded
+    // matrices (scripts/sell_probe.py): row lengths 14..70 0.46 ms vs 0.94 (CSR forms) / 0.66 (blocked); 13..20 0.18
+    // vs 0.40 / 0.26; with scattered columns the blocked form wins (0.48 vs 1.07) -- hence: time them.
+    const char *se = getenv("CUDAMAT_SPMV_SELL");
+    const bool sell_off = se && se[0] == '0';
+    if (force_sell || (!sell_off && s->n >= 4096 && s->nnz >= (1 << 16) && s->plan.stream_rows == 0 && s->nnz >= 8 * (int64_t)s->n)) {
+        const int rc = sell_build(st, s->n, s->nnz, s->rp, s->ci, s->val, &s->sell, force_sell ? 0.0 : 1.5);
+        if (rc != CUDAMAT_OK && force_sell) return rc;
+        have[2] = rc == CUDAMAT_OK;
+        if (force_sell) { s->spmv_mode = 2; return CUDAMAT_OK; }
     }
-    int rc = pb_build(st, s->n, s->n_cols, s->nnz, s->rp, s->ci, s->val, &s->pb, &cols);
-    if (rc != CUDAMAT_OK) {
-        if (force_pb) return rc;
-        return CUDAMAT_OK;            // e.g. out of memory for the blocked copy: keep CSR
-    }
-    if (force_pb) { s->spmv_mode = 1; return CUDAMAT_OK; }
+    if (!have[1] && !have[2]) return CUDAMAT_OK;
     const LoopArgs la_none{nullptr, nullptr, 0, 0, 0};
     const ScalarSrc nosrc{nullptr, 0, 1};
     const double *xin = s->sharded ? s->gather : s->p;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    float ms[2] = {0.f, 0.f};
-    for (int mode = 0; mode < 2; mode++) {
-        s->spmv_mode = mode;
+    float ms[3] = {0.f, 0.f, 0.f};
+    int rc = CUDAMAT_OK;
+    for (int mode = 0; mode < 3 && rc == CUDAMAT_OK; mode++) {
+        if (!have[mode]) continue;
         SpmvArgs a{};
         a.n = s->n; a.rp = s->rp; a.ci = s->ci; a.val = s->val; a.x = xin; a.d = nullptr; a.xd = s->p;
         a.alpha = 1.0; a.beta = 0.0; a.y = s->v; a.dot = 0; a.loop = la_none; a.check = CHECK_NONE; a.half = nosrc;
-        for (int rep = 0; rep < 3; rep++) {
+        for (int rep = 0; rep < 3 && rc == CUDAMAT_OK; rep++) {
             if (rep == 1) hipEventRecord(e0, st);
-            rc = mode ? launch_spmv_pb(st, s->pb, a) : launch_spmv(st, s->plan, a);
-            if (rc) break;
+            rc = mode == 1 ? launch_spmv_pb(st, s->pb, a) : mode == 2 ? launch_spmv_sell(st, s->sell, a) : launch_spmv(st, s->plan, a);
         }
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
@@ -428,11 +452,18 @@ static int ensure_spmv_mode(cudamat_solver *s)
     CM_HIP(hipMemsetAsync(s->v, 0, sizeof(double) * (size_t)(s->n_pad > 0 ? s->n_pad : 1), st));
     s->ms_csr = ms[0] / 2;
     s->ms_pb = ms[1] / 2;
-    s->spmv_mode = (rc == CUDAMAT_OK && ms[1] < ms[0]) ? 1 : 0;
-    if (s->spmv_mode == 0) pb_free(&s->pb);
+    s->ms_sell = ms[2] / 2;
+    int best = 0;
+    if (rc == CUDAMAT_OK)
+        for (int mode = 1; mode < 3; mode++)
+            if (have[mode] && ms[mode] < ms[best]) best = mode;
+    s->spmv_mode = best;
+    if (best != 1) pb_free(&s->pb);
+    if (best != 2) sell_free(&s->sell);
     if (getenv("CUDAMAT_VERBOSE"))
-        fprintf(stderr, "cudamat: SpMV auto-tune csr %.3f ms, blocked %.3f ms (build %.3f s) -> %s\n", s->ms_csr, s->ms_pb,
-                s->pb.build_seconds, s->spmv_mode ? "blocked" : "csr");
+        fprintf(stderr, "cudamat: SpMV auto-tune csr %.3f ms, blocked %s%.3f ms, sell %s%.3f ms (fill %.2f) -> %s\n", s->ms_csr,
+                have[1] ? "" : "(n/a) ", s->ms_pb, have[2] ? "" : "(n/a) ", s->ms_sell, s->sell.fill,
+                best == 1 ? "blocked" : best == 2 ? "sell" : "csr");
     return CUDAMAT_OK;
 }
 

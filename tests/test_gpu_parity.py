@@ -569,7 +569,7 @@ def test_spmv_random_shapes_all_forms(cm, ctx, oracle, seed, monkeypatch):
     d = rng.integers(-2, 3, n).astype(np.float64)
     want = oracle.spmv(A, x)
     want_d = oracle.csrmv(A, 1.0, x, 1.0, x * d)
-    for mode in ("csr", "pb"):
+    for mode in ("csr", "pb", "sell"):
         monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), want_d)
@@ -1139,3 +1139,74 @@ def test_pipelined_bicgstab_exits_and_limits(cm, ctx, oracle):
         s.solve(ctx.array(b), ctx.array(np.ones(A.n)), precond=cm.PRECOND_ILU0, loop=cm.LOOP_PIPELINED)
     assert e.value.code == 2
     s.close()
+
+
+# ------------------------------------------------------------- SELL-C-sigma
+@pytest.mark.parametrize("case", ["rand_real", "poisson_real", "pareto", "hubs", "empties", "mixed", "tiny", "window_edge"])
+def test_sell_spmv_is_bit_exact(cm, ctx, oracle, case, monkeypatch):
+    """SELL-64-1024 (csrc/spmv_sell.hip): one lane per row, products added in column order with one rounding each =
+    the rounding sequence of bicstab.cpp:72-77 => bit-exact vs the oracle on REAL-valued data, whatever the row
+    lengths; padding slots are never multiplied, so an Inf in x only reaches the rows that reference it"""
+    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "sell")
+    rng = np.random.default_rng(21)
+    if case == "rand_real":
+        A = oracle.rand_rows(20000, 50, 0x5EED)
+    elif case == "poisson_real":
+        A = oracle.poisson5(173, 59)
+    elif case == "tiny":
+        A = oracle.rand_rows(7, 50, 1)
+    elif case == "window_edge":                 # n just past a 1024-row window and a 64-row chunk
+        A = oracle.rand_rows(1024 * 3 + 65, 9, 4)
+    else:
+        A = _skewed_matrix(oracle, case, rng)
+    A.val[:] = rng.standard_normal(A.nnz)
+    x = rng.standard_normal(A.n)
+    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
+    d = rng.standard_normal(A.n)
+    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
+    # non-finite input: only the rows that hold column 3 see it
+    x2 = x.copy()
+    x2[3] = np.inf
+    y2 = _spmv_via_solver(cm, ctx, A, x2)
+    base = int(A.rowptr[0])
+    rows = np.repeat(np.arange(A.n), np.diff(A.rowptr))[(A.colidx - base) == 3]
+    untouched = np.setdiff1d(np.arange(A.n), rows)
+    assert np.all(np.isfinite(y2[untouched])) and not np.any(np.isfinite(y2[rows]))
+
+
+def test_sell_in_the_solver_loop_and_auto_selection(cm, ctx, oracle, monkeypatch):
+    """(a) forced: the BiCGSTAB loop on the SELL form (fused dot partials, half-step test launch) reproduces the CSR
+    run's iterates to rounding and the oracle's solution; (b) not forced: on a matrix with varying row lengths
+    the tuner times SELL against the CSR forms and keeps the faster one -- either way the result is the oracle's."""
+    rng = np.random.default_rng(5)
+    import scipy.sparse as sp
+    n = 60000
+    lens = rng.integers(14, 70, n)                                  # row lengths vary by 5x around a mean of ~40
+    rows = np.repeat(np.arange(n), lens)
+    cols = (rows + rng.integers(-2000, 2000, rows.size)) % n
+    S = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(n, n))
+    S.sum_duplicates()
+    S.data[:] = rng.integers(-2, 3, S.nnz)
+    S.setdiag(np.abs(S).sum(axis=1).A1 + 1.0)
+    S.eliminate_zeros()
+    S.sort_indices()
+    A = oracle.Csr(n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), n)
+    xs = 1.0 + np.sin(np.arange(n))
+    b = oracle.spmv(A, xs)
+    xo, so = oracle.pbicgstab(A, b, maxit=200, tol=1e-8)
+    res = {}
+    for mode in ("sell", "csr", None):
+        if mode:
+            monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
+        else:
+            monkeypatch.delenv("CUDAMAT_SPMV_MODE")
+        s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+        chosen = s.spmv_mode()
+        db, dx = ctx.array(b), ctx.array(np.ones(n))
+        st = s.solve(db, dx, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8)
+        res[mode] = (dx.download(), st.iters, chosen)
+        assert st.converged and abs(st.iters - so.iters) <= 1
+        assert np.linalg.norm(res[mode][0] - xo) / np.linalg.norm(xo) <= 1e-8
+        s.close()
+    assert res["sell"][2] == 2 and res["csr"][2] == 0 and res[None][2] in (0, 2)
+    assert np.linalg.norm(res["sell"][0] - res["csr"][0]) / np.linalg.norm(xo) <= 1e-10
