@@ -6,6 +6,7 @@ R=/root/repo
 O=$R/gpurun_out
 run() { # name, bench args...
   name=$1; shift
+  rm -rf $O/prof_$name $O/pmcf_$name $O/pmcw_$name
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- python3 $R/bench.py "$@" --cpu-baseline off > $O/prof_$name.json 2> $O/prof_$name.err
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmcf_$name -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --cpu-baseline off > /dev/null 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmcw_$name -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --cpu-baseline off > /dev/null 2>&1
@@ -14,3 +15,4 @@ run() { # name, bench args...
 run rand50 --steps 10 --warmup 2
 run poisson5 --workload poisson5 --steps 20 --warmup 2
 run ilu0 --precond ilu0 --steps 4 --warmup 1
+run mat10000 --workload mat10000 --steps 200 --warmup 20

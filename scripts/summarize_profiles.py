@@ -2,7 +2,7 @@
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main(tag):
-    for name in ("rand50", "poisson5", "ilu0"):
+    for name in ("rand50", "poisson5", "ilu0", "mat10000"):
         src = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s" % name, "*", "*_kernel_stats.csv"))
         if not src:
             continue
@@ -16,7 +16,7 @@ def main(tag):
         for r in csv.DictReader(open(tr)):
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            if (d > 20000 or "trsv" in k) and not k.startswith("at::") and "rocclr" not in k:
+            if (d > (2000 if name == "mat10000" else 20000) or "trsv" in k) and not k.startswith("at::") and "rocclr" not in k:
                 dur[k].append(d)
         out = {"_note": "rocprofv3 --kernel-trace (durations of launches > 20 us: the rest are frozen no-ops past the stopping "
                         "point) and separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; counters in KB per launch; on gfx950 "
@@ -32,7 +32,7 @@ def main(tag):
             for r in csv.DictReader(open(fs[0])):
                 d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
                 k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-                if (d > 20000 or "trsv" in k) and k in out:
+                if (d > (2000 if name == "mat10000" else 20000) or "trsv" in k) and k in out:
                     acc[k].append(float(r["Counter_Value"]))
             for k, v in acc.items():
                 out[k][cn + "_KB_avg"] = sum(v) / len(v)
@@ -46,4 +46,4 @@ def main(tag):
                 print("  %-28s n=%3d avg %9.1f us  hbm %s" % (k[:28], v["launches"], v["avg_us"],
                       "%.3f GB" % (v["hbm_bytes_per_launch_corrected"] / 1e9) if "hbm_bytes_per_launch_corrected" in v else "-"))
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
