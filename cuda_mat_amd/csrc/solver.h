@@ -84,6 +84,11 @@ struct cudamat_solver {
     bool agreed = false;       // the ranks have compared their setup outcomes since the last set_comm
     int overlap_chunks = 4;
     hipEvent_t ev_x = nullptr, ev_part[cm::kPbMaxChunks] = {};
+    // phase 1 of piece c runs on its own stream (waits: x ready, piece arrived), so that the small launches of the
+    // pieces and of the local slice fill the GPU together instead of one after the other
+    hipStream_t part_stream[cm::kPbMaxChunks] = {};
+    hipEvent_t ev_p1[cm::kPbMaxChunks] = {};
+    double ms_spmv_alone = 0.0;   // the chosen SpMV form with x in place, as the tuner timed it (0: not timed)
 
     // ILU(0)
     bool has_ilu = false;

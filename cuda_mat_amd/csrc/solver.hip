@@ -221,6 +221,10 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     if (s->ev_x) hipEventDestroy(s->ev_x);
     for (hipEvent_t e : s->ev_part)
         if (e) hipEventDestroy(e);
+    for (hipEvent_t e : s->ev_p1)
+        if (e) hipEventDestroy(e);
+    for (hipStream_t q : s->part_stream)
+        if (q) { hipStreamSynchronize(q); hipStreamDestroy(q); }
     delete s;
     return CUDAMAT_OK;
 }
@@ -266,7 +270,11 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     s->n_pad = (int)per;
     if (comm->gather_part && comm->comm_stream && !s->ev_x) {
         CM_HIP(hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming));
-        for (int c = 0; c < kPbMaxChunks; c++) CM_HIP(hipEventCreateWithFlags(&s->ev_part[c], hipEventDisableTiming));
+        for (int c = 0; c < kPbMaxChunks; c++) {
+            CM_HIP(hipEventCreateWithFlags(&s->ev_part[c], hipEventDisableTiming));
+            CM_HIP(hipEventCreateWithFlags(&s->ev_p1[c], hipEventDisableTiming));
+            CM_HIP(hipStreamCreateWithFlags(&s->part_stream[c], hipStreamNonBlocking));
+        }
     }
     if (const char *ch = getenv("CUDAMAT_OVERLAP_CHUNKS")) {
         const int v = atoi(ch);
@@ -330,13 +338,17 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
     a.check = check;
     a.half = half;
     if (overlapped) {
-        // The gather in pieces on the communicator's stream, phase 1 piece by piece behind it on ours:
-        //   comm stream:  [wait x ready] piece 0 | piece 1 | ...
-        //   our stream :  own slice -> gather buffer, test, phase 1 (local blocks) | wait 0, phase 1 (piece 0) | ... | phase 2
-        // The products do not depend on the order of the phase-1 launches and phase 2 adds them in column order as
-        // always, so the result is bit-identical to the plain gather + SpMV.  Hazards: the next SpMV's pieces wait
-        // for its `ev_x`, recorded on our stream behind this SpMV's phase 1 (the gather buffer is free by then); our
-        // stream has waited for every piece (= all of this rank's sends) before anything may overwrite x_local.
+        // The gather in pieces on the communicator's stream, phase 1 piece by piece behind it:
+        //   comm stream  :  [wait x ready] piece 0 | piece 1 | ...
+        //   part stream c:  [wait x ready, piece c] phase 1 of the blocks of piece c          (c = 0 .. pieces-1)
+        //   our stream   :  own slice -> gather buffer, test, phase 1 (local blocks) | wait for every part | phase 2
+        // One stream per piece, because a piece's launch alone (and the local slice's: 1/world of the blocks) does
+        // not fill the GPU: back to back on one stream they would cost a round of workgroups each (5 rounds instead
+        // of 3 at 8 ranks and 4 pieces).  The products do not depend on the order of the phase-1 launches and
+        // phase 2 adds them in column order as always, so the result is bit-identical to the plain gather + SpMV.
+        // Hazards: every stream waits for `ev_x`, recorded on our stream behind the previous SpMV (the product and
+        // gather buffers are free by then); our stream has waited for every part, hence for every piece (= all of
+        // this rank's sends), before anything may overwrite x_local.
         hipStream_t st = s->ctx->stream, cst = (hipStream_t)s->comm.comm_stream;
         const PbPlan &p = s->pb;
         CM_HIP(hipEventRecord(s->ev_x, st));
@@ -358,11 +370,13 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
         CM_TRY(launch_pb_check(st, a));
         CM_TRY(launch_pb_phase1(st, p, a, 0));
         for (int c = 0; c < p.chunks; c++) {
-            comm_mark_begin(s, 1, st);                     // what the solver's stream idles here is the exposed part
-            CM_HIP(hipStreamWaitEvent(st, s->ev_part[c], 0));
-            comm_mark_end(s, st);
-            CM_TRY(launch_pb_phase1(st, p, a, 1 + c));
+            hipStream_t ps = s->part_stream[c];
+            CM_HIP(hipStreamWaitEvent(ps, s->ev_x, 0));
+            CM_HIP(hipStreamWaitEvent(ps, s->ev_part[c], 0));
+            CM_TRY(launch_pb_phase1(ps, p, a, 1 + c));
+            CM_HIP(hipEventRecord(s->ev_p1[c], ps));
         }
+        for (int c = 0; c < p.chunks; c++) CM_HIP(hipStreamWaitEvent(st, s->ev_p1[c], 0));
         return launch_pb_phase2(st, p, a);
     }
     if (s->spmv_mode == 1) return launch_spmv_pb(s->ctx->stream, s->pb, a);
@@ -411,7 +425,8 @@ static int ensure_spmv_mode(cudamat_solver *s)
             if (rc != CUDAMAT_OK && force_pb) return rc;
             have[1] = rc == CUDAMAT_OK;          // e.g. out of memory for the blocked copy: keep the others
         }
-        if (force_pb) { s->spmv_mode = 1; return CUDAMAT_OK; }
+        if (force_pb && !s->sharded) { s->spmv_mode = 1; return CUDAMAT_OK; }
+        if (force_pb) { have[0] = false; }      // sharded: still time it (ms_spmv_alone feeds the exposed-gather figure)
     }
     // ---- SELL-C-sigma copy: rows of 8 entries and more (shorter rows belong to the stream kernel, which measures
     // faster there: C3 0.174 vs 0.191 ms) whose padded copy stays below 1.5 x the entries.  Measured on 2e6-row banded
@@ -419,13 +434,15 @@ static int ensure_spmv_mode(cudamat_solver *s)
     // vs 0.40 / 0.26; with scattered columns the blocked form wins (0.48 vs 1.07) -- hence: time them.
     const char *se = getenv("CUDAMAT_SPMV_SELL");
     const bool sell_off = se && se[0] == '0';
-    if (force_sell || (!sell_off && s->n >= 4096 && s->nnz >= (1 << 16) && s->plan.stream_rows == 0 && s->nnz >= 8 * (int64_t)s->n)) {
+    if (force_sell || (!force_pb && !sell_off && s->n >= 4096 && s->nnz >= (1 << 16) && s->plan.stream_rows == 0 && s->nnz >= 8 * (int64_t)s->n)) {
         const int rc = sell_build(st, s->n, s->nnz, s->rp, s->ci, s->val, &s->sell, force_sell ? 0.0 : 1.5);
         if (rc != CUDAMAT_OK && force_sell) return rc;
         have[2] = rc == CUDAMAT_OK;
         if (force_sell) { s->spmv_mode = 2; return CUDAMAT_OK; }
     }
     if (!have[1] && !have[2]) return CUDAMAT_OK;
+    if (force_pb && !have[1]) { set_error("the blocked copy could not be built"); return CUDAMAT_ERR_NOMEM; }
+    if (force_pb) have[2] = false;
     const LoopArgs la_none{nullptr, nullptr, 0, 0, 0};
     const ScalarSrc nosrc{nullptr, 0, 1};
     const double *xin = s->sharded ? s->gather : s->p;
@@ -453,11 +470,12 @@ static int ensure_spmv_mode(cudamat_solver *s)
     s->ms_csr = ms[0] / 2;
     s->ms_pb = ms[1] / 2;
     s->ms_sell = ms[2] / 2;
-    int best = 0;
+    int best = have[0] ? 0 : 1;
     if (rc == CUDAMAT_OK)
         for (int mode = 1; mode < 3; mode++)
-            if (have[mode] && ms[mode] < ms[best]) best = mode;
+            if (have[mode] && (!have[best] || ms[mode] < ms[best])) best = mode;
     s->spmv_mode = best;
+    s->ms_spmv_alone = ms[best] / 2;
     if (best != 1) pb_free(&s->pb);
     if (best != 2) sell_free(&s->sell);
     if (getenv("CUDAMAT_VERBOSE"))
@@ -901,6 +919,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     stt.trsv_form = precond ? trsv_form_code(s) : 0;
     stt.trsv_fallbacks = s->trsv_fallbacks;
     stt.overlapped = sharded && s->overlap && s->spmv_mode == 1;
+    stt.ms_spmv_alone = s->ms_spmv_alone;
     if (s->profiling) {
         // exposed part of an overlapped gather: the waits (kind 1), clipped to the gather they wait for only by
         // construction -- the solver's stream idles there for nothing else
@@ -909,7 +928,6 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             hipEventElapsedTime(&ms, s->comm_ev[2 * i], s->comm_ev[2 * i + 1]);
             switch (s->comm_kind[i]) {
             case 0: stt.ms_gather += ms; stt.n_gather++; break;
-            case 1: stt.ms_gather_exposed += ms; break;
             case 2: stt.ms_gather += ms; stt.ms_gather_exposed += ms; stt.n_gather++; break;
             default: stt.ms_allreduce += ms; stt.n_allreduce++; break;
             }
@@ -925,7 +943,13 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             const size_t pair = (i / 2) % per_it_pairs;
             const bool is_trsv = precond && (pair == 0 || pair == 2);
             if (is_trsv) { stt.ms_trsv += ms; stt.n_trsv += 2; }
-            else { stt.ms_spmv += ms; stt.n_spmv += 1; }
+            else {
+                stt.ms_spmv += ms;
+                stt.n_spmv += 1;
+                // overlapped gather: what an SpMV took beyond the same SpMV with x already in place (the tuner's
+                // timing) is the part of the exchange that was NOT hidden behind it
+                if (stt.overlapped && s->ms_spmv_alone > 0.0 && ms > s->ms_spmv_alone) stt.ms_gather_exposed += ms - s->ms_spmv_alone;
+            }
         }
     }
 

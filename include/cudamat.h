@@ -106,12 +106,15 @@ typedef struct cudamat_stats {
     int trsv_fallbacks;
     /* CUDAMAT_FLAG_PROFILE on a row-sharded solver: device time of the exchanges of this solve.
      * ms_gather: the all-gathers of the SpMV inputs (on the communicator's stream when the
-     * gather is overlapped); ms_gather_exposed: the part of it the solver's stream actually
-     * waited for (all of it without overlap); hidden = ms_gather - ms_gather_exposed.       */
+     * gather is overlapped); ms_gather_exposed: the part of it that was not hidden behind
+     * the SpMV (all of it without overlap); hidden = ms_gather - ms_gather_exposed.         */
     int n_gather;       int n_allreduce;
     double ms_gather;   double ms_gather_exposed;   double ms_allreduce;
     int overlapped;     /* 1: the gather ran in pieces behind phase 1 of the blocked SpMV     */
     int reserved_;
+    double ms_spmv_alone;  /* the selected SpMV form with its input in place, as timed when it was selected
+                            * (0: never timed); an overlapped gather's exposed part is what the SpMVs of the
+                            * loop took beyond this                                                            */
 } cudamat_stats;
 
 /* Collectives for a row-sharded solve.  Either supplied by the host program (e.g.
