@@ -100,6 +100,8 @@ _SIGS = {
     "cudamat_solver_set_comm": (C.c_int, [_P, C.POINTER(Comm)]),
     "cudamat_solve_sharded": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                                         C.c_double, C.c_int, _P, C.POINTER(Stats)]),
+    "cudamat_comm_dry_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(Comm)]),
+    "cudamat_comm_dry_destroy": (C.c_int, [C.POINTER(Comm)]),
     "cudamat_rccl_available": (C.c_int, []),
     "cudamat_rccl_unique_id": (C.c_int, [_P]),
     "cudamat_rccl_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(Comm)]),

@@ -237,3 +237,53 @@ extern "C" int cudamat_solve_sharded(int ngpu, int n, int nnz, const double *A, 
     }
     return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// "Dry" communicator: every exchange is SKIPPED (the streams and the call sequence are real).  For timing one
+// rank's share of a sharded solve on a single GPU (scripts/rank_probe.py): the iterates are meaningless.
+namespace {
+struct DryComm {
+    hipStream_t side = nullptr, red = nullptr;
+};
+int dry_allgather(void *, const double *, double *, int64_t) { return 0; }
+int dry_allreduce(void *, double *, int) { return 0; }
+int dry_gather_part(void *, const double *, double *, int64_t, int64_t, int64_t) { return 0; }
+}  // namespace
+
+extern "C" int cudamat_comm_dry_create(cudamat_ctx *ctx, int rank, int world, cudamat_comm *out)
+{
+    CM_ARG(ctx && out && world >= 1 && rank >= 0 && rank < world, "bad argument");
+    CM_HIP(hipSetDevice(ctx->device));
+    DryComm *c = new DryComm();
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->red, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        cm::set_error("hipStreamCreate failed");
+        return CUDAMAT_ERR_HIP;
+    }
+    memset(out, 0, sizeof(*out));
+    out->rank = rank;
+    out->world = world;
+    out->user = c;
+    out->allgather = dry_allgather;
+    out->allreduce = dry_allreduce;
+    out->gather_part = dry_gather_part;
+    out->comm_stream = c->side;
+    out->allreduce_side = dry_allreduce;
+    out->reduce_stream = c->red;
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_comm_dry_destroy(cudamat_comm *comm)
+{
+    if (!comm || !comm->user) return CUDAMAT_OK;
+    CM_ARG(comm->allgather == dry_allgather, "not a dry communicator");
+    DryComm *c = (DryComm *)comm->user;
+    hipStreamSynchronize(c->side);
+    hipStreamSynchronize(c->red);
+    hipStreamDestroy(c->side);
+    hipStreamDestroy(c->red);
+    delete c;
+    memset(comm, 0, sizeof(*comm));
+    return CUDAMAT_OK;
+}

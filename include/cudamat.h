@@ -163,6 +163,11 @@ int cudamat_rccl_unique_id(void *id);              /* fills CUDAMAT_RCCL_ID_BYTE
 int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int rank, int world, cudamat_comm *out);
 int cudamat_rccl_comm_destroy(cudamat_comm *comm);
 
+/* A communicator whose exchanges are SKIPPED (streams and call sequence are real): times one rank's share of a
+ * sharded solve on a single GPU (scripts/rank_probe.py).  The iterates of such a solve are meaningless.        */
+int cudamat_comm_dry_create(cudamat_ctx *ctx, int rank, int world, cudamat_comm *out);
+int cudamat_comm_dry_destroy(cudamat_comm *comm);
+
 int         cudamat_version(void);
 const char *cudamat_last_error(void);
 int         cudamat_device_count(int *count);
