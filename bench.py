@@ -426,7 +426,8 @@ def run_bench(args):
             ts = max(timed_steps[0], 1)
             out["comm"] = {"form": {"comm": "rccl (csrc/comm_rccl.hip, called from the C++ loop)" if comm_desc[0] == "rccl"
                                     else "torch.distributed callbacks (%s)" % dist.get_backend(),
-                                    "gather": "in pieces, overlapped with phase 1" if exch.get("overlapped") else "plain all-gather"},
+                                    "gather": {1: "in pieces, overlapped with phase 1", 2: "windows only (halo): %.4f of a whole gather"
+                                                                                             % st.gather_fraction}.get(exch.get("overlapped"), "plain all-gather")},
                            "gather_ms_per_step": exch.get("ms_gather", 0.0) / ts,
                            "gather_exposed_ms_per_step": exch.get("ms_gather_exposed", 0.0) / ts,
                            "gather_hidden_ms_per_step": (exch.get("ms_gather", 0.0) - exch.get("ms_gather_exposed", 0.0)) / ts,

@@ -33,7 +33,7 @@ class Stats(C.Structure):
                 ("n_levels_u", C.c_int), ("trsv_form", C.c_int), ("trsv_fallbacks", C.c_int),
                 ("n_gather", C.c_int), ("n_allreduce", C.c_int), ("ms_gather", C.c_double),
                 ("ms_gather_exposed", C.c_double), ("ms_allreduce", C.c_double), ("overlapped", C.c_int),
-                ("reserved_", C.c_int), ("ms_spmv_alone", C.c_double)]
+                ("reserved_", C.c_int), ("gather_fraction", C.c_double), ("ms_spmv_alone", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -44,6 +44,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
 
 
 GATHER_PART_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64)
+_I64P = C.POINTER(C.c_int64)
+GATHER_WINDOW_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _I64P, _I64P, _I64P, _I64P)
 
 
 class Comm(C.Structure):
@@ -51,7 +53,8 @@ class Comm(C.Structure):
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("user", C.c_void_p),
                 ("allgather", ALLGATHER_FN), ("allreduce", ALLREDUCE_FN),
                 ("gather_part", GATHER_PART_FN), ("comm_stream", C.c_void_p),
-                ("allreduce_side", ALLREDUCE_FN), ("reduce_stream", C.c_void_p)]
+                ("allreduce_side", ALLREDUCE_FN), ("reduce_stream", C.c_void_p),
+                ("gather_window", GATHER_WINDOW_FN)]
 
 
 def build(force=False):

@@ -132,6 +132,25 @@ static int rccl_gather_part(void *user, const double *send, double *recv, int64_
     return 0;
 }
 
+// windowed gather (halo): per-peer ranges, one group on the solver's stream
+static int rccl_gather_window(void *user, const double *send, double *recv, int64_t stride, const int64_t *send_off,
+                              const int64_t *send_cnt, const int64_t *recv_off, const int64_t *recv_cnt)
+{
+    RcclComm *c = (RcclComm *)user;
+    if (c->world <= 1) return 0;
+    CM_NCCL(g_api.GroupStart());
+    for (int d = 1; d < c->world; d++) {
+        const int to = (c->rank + d) % c->world, from = (c->rank - d + c->world) % c->world;
+        if (send_cnt[to] > 0)
+            CM_NCCL(g_api.Send(send + send_off[to], (size_t)send_cnt[to], ncclDouble, to, c->coll, c->main));
+        if (recv_cnt[from] > 0)
+            CM_NCCL(g_api.Recv(recv + (size_t)from * (size_t)stride + (size_t)recv_off[from], (size_t)recv_cnt[from], ncclDouble,
+                               from, c->coll, c->main));
+    }
+    CM_NCCL(g_api.GroupEnd());
+    return 0;
+}
+
 }  // namespace cm
 
 using namespace cm;
@@ -201,6 +220,7 @@ extern "C" int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int ra
     out->comm_stream = c->side;
     out->allreduce_side = rccl_allreduce_side;
     out->reduce_stream = c->rstream;
+    out->gather_window = rccl_gather_window;
     return CUDAMAT_OK;
 }
 

@@ -89,6 +89,13 @@ struct cudamat_solver {
     hipStream_t part_stream[cm::kPbMaxChunks] = {};
     hipEvent_t ev_p1[cm::kPbMaxChunks] = {};
     double ms_spmv_alone = 0.0;   // the chosen SpMV form with x in place, as the tuner timed it (0: not timed)
+    // windowed gather (halo): the part [lo, hi) of every other slice this rank's rows reference, exchanged with the
+    // ranks at setup (setup_agree); used in place of the whole gather when every rank needs less than half of it
+    bool windowed = false;
+    bool windows_known = false;
+    std::vector<int64_t> w_send_off, w_send_cnt, w_recv_off, w_recv_cnt;
+    double gather_fraction = 1.0;
+    double *need_dev = nullptr;   // 2 * world (mine) + 2 * world^2 (everybody's) doubles
 
     // ILU(0)
     bool has_ilu = false;

@@ -214,6 +214,7 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
         if (s->ev[i]) hipEventDestroy(s->ev[i]);
     for (hipEvent_t e : s->prof_ev) hipEventDestroy(e);
     for (hipEvent_t e : s->comm_ev) hipEventDestroy(e);
+    if (s->need_dev) hipFree(s->need_dev);
     for (int e = 0; e < 2; e++) {
         if (s->ev_red[e]) hipEventDestroy(s->ev_red[e]);
         if (s->ev_red_done[e]) hipEventDestroy(s->ev_red_done[e]);
@@ -247,6 +248,9 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     s->spmv_mode = -1;
     s->overlap = false;
     s->agreed = false;
+    s->windowed = false;
+    s->windows_known = false;
+    if (s->need_dev) { hipFree(s->need_dev); s->need_dev = nullptr; }
     const char *force = getenv("CUDAMAT_FORCE_SHARDED");
     const bool forced = comm && comm->world == 1 && force && force[0] == '1';
     if (!comm || (comm->world <= 1 && !forced)) {
@@ -310,8 +314,21 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
                       double *parts, LoopArgs la, int check, ScalarSrc half)
 {
     const double *xfull = x_local;
-    const bool overlapped = s->sharded && s->overlap && s->spmv_mode == 1;
-    if (s->sharded && !overlapped) {
+    const bool windowed = s->sharded && s->windowed;
+    const bool overlapped = s->sharded && !windowed && s->overlap && s->spmv_mode == 1;
+    if (windowed) {
+        // only the parts of the other slices that this rank's rows reference travel (a halo for banded matrices)
+        hipStream_t st = s->ctx->stream;
+        CM_HIP(hipMemcpyAsync(s->gather + (size_t)s->comm.rank * (size_t)s->n_pad, x_local, sizeof(double) * (size_t)s->n_pad,
+                              hipMemcpyDeviceToDevice, st));
+        comm_mark_begin(s, 2, st);
+        if (s->comm.gather_window(s->comm.user, x_local, s->gather, (int64_t)s->n_pad, s->w_send_off.data(), s->w_send_cnt.data(),
+                                  s->w_recv_off.data(), s->w_recv_cnt.data()) != 0) {
+            set_error("gather_window callback failed");
+            return CUDAMAT_ERR_COMM;
+        }
+        comm_mark_end(s, st);
+    } else if (s->sharded && !overlapped) {
         comm_mark_begin(s, 2, s->ctx->stream);
         if (s->comm.allgather(s->comm.user, x_local, s->gather, (int64_t)s->n_pad) != 0) {
             set_error("allgather callback failed");
@@ -496,6 +513,97 @@ static int allreduce(cudamat_solver *s, double *buf, int count)
     return CUDAMAT_OK;
 }
 
+// ---- windowed gather (halo): which part of every other rank's slice do the local rows reference?
+// lo[q] / hi[q]: smallest / one past the largest column of slice q (relative to the slice) among the local entries.
+// Each thread walks a contiguous run of entries and only touches the workgroup's LDS tables when an entry leaves
+// the range it has already reported for that slice (rows are mostly sorted, so that is rare).
+__global__ __launch_bounds__(kBlock) void k_col_windows(long long nnz, const int *ci, int per, int world, int *lo, int *hi)
+{
+    extern __shared__ int tab[];              // lo_s[world], hi_s[world]
+    int *lo_s = tab, *hi_s = tab + world;
+    for (int q = threadIdx.x; q < world; q += kBlock) { lo_s[q] = per; hi_s[q] = 0; }
+    __syncthreads();
+    const long long per_thread = (nnz + (long long)gridDim.x * kBlock - 1) / ((long long)gridDim.x * kBlock);
+    const long long k0 = ((long long)blockIdx.x * kBlock + threadIdx.x) * per_thread;
+    const long long k1 = k0 + per_thread < nnz ? k0 + per_thread : nnz;
+    int cq = -1, clo = 0, chi = 0;
+    for (long long k = k0; k < k1; k++) {
+        const int c = ci[k], q = c / per, w = c - q * per;
+        if (q == cq && w >= clo && w < chi) continue;
+        if (q != cq) { cq = q; clo = w; chi = w + 1; }
+        else { clo = w < clo ? w : clo; chi = w + 1 > chi ? w + 1 : chi; }
+        atomicMin(&lo_s[q], w);
+        atomicMax(&hi_s[q], w + 1);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < world; q += kBlock) {
+        if (hi_s[q] > 0) { atomicMin(&lo[q], lo_s[q]); atomicMax(&hi[q], hi_s[q]); }
+    }
+}
+
+// collective: every rank learns what every rank needs from every slice; decides (identically everywhere) whether
+// the windows replace the whole gather
+static int compute_windows(cudamat_solver *s)
+{
+    s->windows_known = true;
+    s->windowed = false;
+    s->gather_fraction = 1.0;
+    const int W = s->comm.world, me = s->comm.rank;
+    if (!s->comm.gather_window || W <= 1 || W > 4096) return CUDAMAT_OK;
+    hipStream_t st = s->ctx->stream;
+    const int per = s->n_pad;
+    int *d_lohi = nullptr;
+    std::vector<int> h((size_t)2 * W);
+    CM_HIP(hipMalloc((void **)&d_lohi, sizeof(int) * 2 * (size_t)W));
+    for (int q = 0; q < W; q++) { h[(size_t)q] = per; h[(size_t)W + q] = 0; }
+    CM_HIP(hipMemcpyAsync(d_lohi, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, st));
+    if (s->nnz > 0) {
+        int grid = (int)((s->nnz + 4096LL * kBlock - 1) / (4096LL * kBlock));
+        grid = grid < 1 ? 1 : grid > 4096 ? 4096 : grid;
+        hipLaunchKernelGGL(k_col_windows, dim3(grid), dim3(kBlock), sizeof(int) * 2 * (size_t)W, st, (long long)s->nnz, s->ci, per, W,
+                           d_lohi, d_lohi + W);
+    }
+    hipError_t e = hipMemcpyAsync(h.data(), d_lohi, sizeof(int) * h.size(), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d_lohi);
+    CM_HIP(e);
+    std::vector<double> mine((size_t)2 * W, 0.0), all((size_t)2 * W * W, 0.0);
+    for (int q = 0; q < W; q++)
+        if (q != me && h[(size_t)W + q] > h[(size_t)q]) { mine[(size_t)2 * q] = h[(size_t)q]; mine[(size_t)2 * q + 1] = h[(size_t)W + q]; }
+    if (!s->need_dev) CM_TRY(dev_alloc((void **)&s->need_dev, sizeof(double) * ((size_t)2 * W + (size_t)2 * W * W)));
+    CM_HIP(hipMemcpyAsync(s->need_dev, mine.data(), sizeof(double) * mine.size(), hipMemcpyHostToDevice, st));
+    CM_HIP(hipStreamSynchronize(st));
+    if (s->comm.allgather(s->comm.user, s->need_dev, s->need_dev + 2 * W, (int64_t)2 * W) != 0) {
+        set_error("allgather callback failed");
+        return CUDAMAT_ERR_COMM;
+    }
+    CM_HIP(hipMemcpyAsync(all.data(), s->need_dev + 2 * W, sizeof(double) * all.size(), hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    s->w_send_off.assign((size_t)W, 0); s->w_send_cnt.assign((size_t)W, 0);
+    s->w_recv_off.assign((size_t)W, 0); s->w_recv_cnt.assign((size_t)W, 0);
+    double worst = 0.0;
+    for (int p = 0; p < W; p++) {             // p needs [lo, hi) of slice q
+        double tot = 0.0;
+        for (int q = 0; q < W; q++) {
+            const double lo = all[((size_t)p * W + q) * 2], hi = all[((size_t)p * W + q) * 2 + 1];
+            if (q == p || hi <= lo) continue;
+            tot += hi - lo;
+            if (p == me) { s->w_recv_off[(size_t)q] = (int64_t)lo; s->w_recv_cnt[(size_t)q] = (int64_t)(hi - lo); }
+            if (q == me) { s->w_send_off[(size_t)p] = (int64_t)lo; s->w_send_cnt[(size_t)p] = (int64_t)(hi - lo); }
+        }
+        const double frac = tot / ((double)(W - 1) * (double)per);
+        if (p == me) s->gather_fraction = frac;
+        worst = frac > worst ? frac : worst;
+    }
+    const char *env = getenv("CUDAMAT_WINDOWED");
+    s->windowed = worst <= 0.5 && !(env && env[0] == '0');
+    if (!s->windowed) s->gather_fraction = 1.0;
+    if (getenv("CUDAMAT_VERBOSE"))
+        fprintf(stderr, "cudamat: rank %d references %.4f of the other slices (worst rank %.4f) -> %s\n", me,
+                s->windowed ? s->gather_fraction : worst, worst, s->windowed ? "windowed gather" : "whole gather");
+    return CUDAMAT_OK;
+}
+
 // Sharded runs: the ranks agree on the outcome of the rank-local setup steps BEFORE the first collective of the
 // data path -- a rank whose blocked copy, ILU(0) or allocation failed makes every rank return an error (instead of
 // leaving its peers inside a collective for ever), and the gather is overlapped only if every rank runs the
@@ -516,6 +624,7 @@ static int setup_agree(cudamat_solver *s, int rc_local)
     s->overlap = s->comm.world > 1 && s->comm.gather_part && s->comm.comm_stream && s->ev_x && s->pb.chunks >= 1 &&
                  h[1] == (double)s->comm.world && !(ov && ov[0] == '0');
     s->agreed = true;
+    if (h[0] == 0.0 && !s->windows_known) CM_TRY(compute_windows(s));       // collective: same call on every rank
     if (h[0] != 0.0) {
         if (rc_local != CUDAMAT_OK) { set_error("%s", saved); return rc_local; }
         set_error("%d rank(s) of the sharded solver failed during setup", (int)h[0]);
@@ -918,7 +1027,8 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     stt.n_levels_u = s->U.nlevels;
     stt.trsv_form = precond ? trsv_form_code(s) : 0;
     stt.trsv_fallbacks = s->trsv_fallbacks;
-    stt.overlapped = sharded && s->overlap && s->spmv_mode == 1;
+    stt.overlapped = sharded && s->windowed ? 2 : (sharded && s->overlap && s->spmv_mode == 1) ? 1 : 0;
+    stt.gather_fraction = sharded ? s->gather_fraction : 0.0;
     stt.ms_spmv_alone = s->ms_spmv_alone;
     if (s->profiling) {
         // exposed part of an overlapped gather: the waits (kind 1), clipped to the gather they wait for only by
@@ -948,7 +1058,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
                 stt.n_spmv += 1;
                 // overlapped gather: what an SpMV took beyond the same SpMV with x already in place (the tuner's
                 // timing) is the part of the exchange that was NOT hidden behind it
-                if (stt.overlapped && s->ms_spmv_alone > 0.0 && ms > s->ms_spmv_alone) stt.ms_gather_exposed += ms - s->ms_spmv_alone;
+                if (stt.overlapped == 1 && s->ms_spmv_alone > 0.0 && ms > s->ms_spmv_alone) stt.ms_gather_exposed += ms - s->ms_spmv_alone;
             }
         }
     }

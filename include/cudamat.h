@@ -110,8 +110,10 @@ typedef struct cudamat_stats {
      * the SpMV (all of it without overlap); hidden = ms_gather - ms_gather_exposed.         */
     int n_gather;       int n_allreduce;
     double ms_gather;   double ms_gather_exposed;   double ms_allreduce;
-    int overlapped;     /* 1: the gather ran in pieces behind phase 1 of the blocked SpMV     */
+    int overlapped;     /* 1: the gather ran in pieces behind phase 1 of the blocked SpMV; 2: only the windows
+                         * of the other slices that this rank's rows reference were exchanged (halo)            */
     int reserved_;
+    double gather_fraction; /* doubles received per SpMV / doubles of a whole gather ((world-1) slices)        */
     double ms_spmv_alone;  /* the selected SpMV form with its input in place, as timed when it was selected
                             * (0: never timed); an overlapped gather's exposed part is what the SpMVs of the
                             * loop took beyond this                                                            */
@@ -135,6 +137,13 @@ typedef int (*cudamat_allgather_fn)(void *user, const double *send, double *recv
 typedef int (*cudamat_allreduce_fn)(void *user, double *buf, int count);
 typedef int (*cudamat_gather_part_fn)(void *user, const double *send, double *recv, int64_t stride,
                                       int64_t offset, int64_t count);
+/* optional: a WINDOWED gather for matrices whose rows reference only part of every other slice (banded matrices:
+ * a halo).  This rank sends send[send_off[q] .. + send_cnt[q]) to rank q and receives rank q's
+ * [recv_off[q] .. + recv_cnt[q]) into recv[q*stride + recv_off[q] ..); the four arrays have `world` entries
+ * (host memory, valid during the call; entry `rank` is ignored; counts may be 0).  Enqueued on the context's stream. */
+typedef int (*cudamat_gather_window_fn)(void *user, const double *send, double *recv, int64_t stride,
+                                        const int64_t *send_off, const int64_t *send_cnt,
+                                        const int64_t *recv_off, const int64_t *recv_cnt);
 typedef struct cudamat_comm {
     int rank;
     int world;
@@ -147,6 +156,7 @@ typedef struct cudamat_comm {
      * context's stream, so that CUDAMAT_LOOP_PIPELINED can run a reduction while an SpMV runs              */
     cudamat_allreduce_fn allreduce_side;  /* may be NULL: the pipelined loop then reduces on its own stream */
     void *reduce_stream;
+    cudamat_gather_window_fn gather_window;   /* may be NULL: every SpMV input is gathered whole */
 } cudamat_comm;
 
 /* ---- the library's own communicator: RCCL over xGMI, bound at run time ---------------- */

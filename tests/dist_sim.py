@@ -102,12 +102,13 @@ class ThreadComm:
     """cudamat_comm whose collectives are host-synchronised copies between the ranks' buffers:
     slow, but it drives the real C++ sharded loop with W > 1 on a single GPU."""
 
-    def __init__(self, cm, group, rank, ctx, pieces=False, side_reduce=False):
+    def __init__(self, cm, group, rank, ctx, pieces=False, side_reduce=False, windows=False):
         """pieces=True also offers gather_part (the overlapped gather) on a stream of its own: a second Context;
         side_reduce=True offers allreduce_side on a third one (the pipelined loop's reductions beside an SpMV)"""
-        from cuda_mat_amd._lib import ALLGATHER_FN, ALLREDUCE_FN, GATHER_PART_FN, Comm
+        from cuda_mat_amd._lib import ALLGATHER_FN, ALLREDUCE_FN, GATHER_PART_FN, GATHER_WINDOW_FN, Comm
         self.cm, self.g, self.rank, self.ctx = cm, group, rank, ctx
-        self.n_allgather = self.n_allreduce = self.n_parts = self.n_side = 0
+        self.n_allgather = self.n_allreduce = self.n_parts = self.n_side = self.n_windows = 0
+        self.window_doubles = 0
         self._ag = ALLGATHER_FN(self._allgather)
         self._ar = ALLREDUCE_FN(self._allreduce)
         self.cctx = self.rctx = None
@@ -122,7 +123,35 @@ class ThreadComm:
             rstream = C.c_void_p()
             assert cm.lib().cudamat_ctx_stream(self.rctx.h, C.byref(rstream)) == 0
             self._ars = ars = ALLREDUCE_FN(self._allreduce_side)
-        self.struct = Comm(rank, group.world, None, self._ag, self._ar, gp, gstream, ars, rstream)
+        gw = GATHER_WINDOW_FN()
+        if windows:
+            self._gw = gw = GATHER_WINDOW_FN(self._gather_window)
+        self.struct = Comm(rank, group.world, None, self._ag, self._ar, gp, gstream, ars, rstream, gw)
+
+    def _gather_window(self, user, send, recv, stride, send_off, send_cnt, recv_off, recv_cnt):
+        """windowed gather (halo): only [recv_off[q], +recv_cnt[q]) of every other slice; checks that what the peers
+        say they send is what this rank expects to receive"""
+        try:
+            L = self.cm.lib()
+            W = self.g.world
+            self.ctx.sync()
+            self.g.send[self.rank] = (send, [(send_off[q], send_cnt[q]) for q in range(W)])
+            self.g.barrier.wait()
+            for q in range(W):
+                if q == self.rank or recv_cnt[q] == 0:
+                    continue
+                ptr, ranges = self.g.send[q]
+                assert ranges[self.rank] == (recv_off[q], recv_cnt[q]), "sender and receiver disagree on a window"
+                assert L.cudamat_d2d(self.ctx.h, recv + 8 * (stride * q + recv_off[q]), ptr + 8 * recv_off[q],
+                                     8 * recv_cnt[q]) == 0
+                self.window_doubles += recv_cnt[q]
+            self.ctx.sync()
+            self.g.barrier.wait()
+            self.n_windows += 1
+            return 0
+        except Exception:                                 # noqa: BLE001
+            self.g.barrier.abort()
+            return 1
 
     def close(self):
         for c in (self.cctx, self.rctx):

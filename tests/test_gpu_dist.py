@@ -29,7 +29,7 @@ def cm():
     return cm
 
 
-def _run_rank(cm, group, rank, n, A, b, out, pieces=False, side_reduce=False, **kw):
+def _run_rank(cm, group, rank, n, A, b, out, pieces=False, side_reduce=False, windows=False, **kw):
     import dist_sim
     from cuda_mat_amd.dist import shard_rows
     try:
@@ -38,7 +38,7 @@ def _run_rank(cm, group, rank, n, A, b, out, pieces=False, side_reduce=False, **
         rp = (A.rowptr[row0:row1 + 1] - A.rowptr[row0]).astype(np.int32)
         k0, k1 = A.rowptr[row0], A.rowptr[row1]
         s = cm.Solver.from_host_csr(ctx, rp, A.colidx[k0:k1], A.val[k0:k1], n_cols=n)
-        comm = dist_sim.ThreadComm(cm, group, rank, ctx, pieces=pieces, side_reduce=side_reduce)
+        comm = dist_sim.ThreadComm(cm, group, rank, ctx, pieces=pieces, side_reduce=side_reduce, windows=windows)
         s.set_comm(comm.struct)
         db, dx = ctx.array(b[row0:row1]), ctx.array(np.ones(row1 - row0))
         # y = A x through the sharded SpMV entry point
@@ -47,7 +47,7 @@ def _run_rank(cm, group, rank, n, A, b, out, pieces=False, side_reduce=False, **
         y = dy.download()
         st = s.solve(db, dx, **kw)
         out[rank] = (row0, row1, dx.download(), st.as_dict(), s.history(), y, comm.n_allgather, comm.n_allreduce,
-                     comm.n_parts, comm.n_side)
+                     comm.n_parts, comm.n_side, comm.n_windows, comm.window_doubles)
         s.close()
         comm.close()
         ctx.close()
@@ -238,6 +238,68 @@ def test_pipelined_loop_sharded(cm, oracle, monkeypatch, world, n, per_row):
     x = np.concatenate([o[2] for o in res[True]])
     np.testing.assert_allclose(x, xs, rtol=1e-7)
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
+
+
+@pytest.mark.parametrize("world,name", [(4, "poisson"), (3, "band"), (2, "rand")])
+def test_windowed_gather_halo(cm, oracle, monkeypatch, world, name):
+    """a banded matrix needs a halo, not the whole gather.  With gather_window in the communicator the ranks
+    exchange, once, which part of every other slice their rows reference; when every rank needs at most half of the
+    whole gather, only those windows travel.  Same iterates as the whole gather bit for bit; a scattered matrix keeps
+    the whole gather."""
+    import dist_sim
+    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")     # one SpMV form in both runs (the tuner's pick may differ by timing)
+    if name == "poisson":
+        A = oracle.poisson5(100, 120)
+    elif name == "band":
+        import scipy.sparse as sp
+        rng = np.random.default_rng(4)
+        n0 = 30011
+        rows = np.repeat(np.arange(n0), 21)
+        cols = np.clip(rows + rng.integers(-900, 901, rows.size), 0, n0 - 1)
+        S = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(n0, n0))
+        S.sum_duplicates()
+        S.data[:] = -1.0
+        S.setdiag(25.0)
+        S.sort_indices()
+        A = oracle.Csr(n0, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), n0)
+    else:
+        A = oracle.rand_rows(20000, 30, 0xBEEF)
+    n = A.n
+    xs = oracle.xstar(n, 0x5EEE)
+    b = oracle.spmv(A, xs)
+    res = {}
+    for windows in (True, False):
+        group = dist_sim.ThreadGroup(world)
+        out = [None] * world
+        th = [threading.Thread(target=_run_rank, args=(cm, group, r, n, A, b, out),
+                               kwargs=dict(windows=windows, loop=cm.LOOP_PBICGSTAB, maxit=1000, tol=1e-8)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=180)
+        for o in out:
+            assert not isinstance(o, Exception) and o is not None, o
+        res[windows] = out
+    for a, c in zip(res[True], res[False]):
+        np.testing.assert_array_equal(a[5], c[5])             # y = A b
+        np.testing.assert_array_equal(a[2], c[2])             # x
+        np.testing.assert_array_equal(a[4], c[4])             # residual history
+    y = np.concatenate([o[5] for o in res[True]])
+    np.testing.assert_array_equal(y, oracle.spmv(A, b))
+    on = res[True]
+    per = (n + world - 1) // world
+    if name == "rand":
+        assert all(o[10] == 0 and o[3]["overlapped"] == 0 and o[3]["gather_fraction"] == 1.0 for o in on), "scattered columns: whole gather"
+    else:
+        assert all(o[10] > 0 and o[3]["overlapped"] == 2 for o in on)
+        assert all(o[6] == 1 for o in on), "one all-gather: the exchange of the windows themselves"
+        # the doubles that travelled are the halo, a small fraction of (world - 1) slices per gather
+        for o in on:
+            assert o[11] <= 0.1 * o[10] * (world - 1) * per
+            assert 0 < o[3]["gather_fraction"] <= 0.1
+    assert on[0][3]["converged"]
+    x = np.concatenate([o[2] for o in on])
+    np.testing.assert_allclose(x, xs, rtol=5e-5)      # tol 1e-8 on the residual of a Laplacian (kappa ~ 1e3-1e4)
 
 
 def test_bench_two_processes_share_the_gpu_over_gloo():
