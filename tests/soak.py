@@ -29,7 +29,7 @@ for case in range(ncase):
     A = O.Csr(n, (S.indptr + base).astype(np.int32), (S.indices + base).astype(np.int32), S.data.copy(), n)
     x = rng.standard_normal(n); want = O.spmv(A, x)
     msgs = []
-    for mode in ("csr", "tiles", "pb", None):
+    for mode in ("csr", "tiles", "pb", "sell", None):
         os.environ.pop("CUDAMAT_SPMV_FORM", None)
         if mode == "tiles": os.environ["CUDAMAT_SPMV_MODE"] = "csr"; os.environ["CUDAMAT_SPMV_FORM"] = "tiles"
         elif mode: os.environ["CUDAMAT_SPMV_MODE"] = mode
@@ -37,8 +37,8 @@ for case in range(ncase):
         s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
         dx, dy = ctx.array(x), ctx.empty(n)
         s.spmv(dx, dy); y = dy.download()
-        if mode == "pb":
-            if not np.array_equal(y, want): msgs.append("pb spmv not bit-exact")
+        if mode in ("pb", "sell"):
+            if not np.array_equal(y, want): msgs.append("%s spmv not bit-exact" % mode)
         else:
             absA = O.Csr(n, A.rowptr, A.colidx, np.abs(A.val), n)
             bound = 4 * (np.diff(A.rowptr).max() + 1) * 2.3e-16 * O.spmv(absA, np.abs(x)) + 1e-300
@@ -46,7 +46,7 @@ for case in range(ncase):
         for a in (dx, dy): a.free()
         s.close()
     xs = 1.0 + rng.random(n); b = O.spmv(A, xs)
-    for loop in (0, 1):
+    for loop in (0, 1, 2):                     # 2 = pipelined BiCGStab: checked against its own restatement
         for precond in ((0, 1) if loop == 0 else (0,)):
             s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
             db, dxx = ctx.array(b), ctx.array(np.ones(n))
@@ -56,6 +56,7 @@ for case in range(ncase):
                 msgs.append("solve error %s" % e); s.close(); continue
             xg = dxx.download()
             if loop == 0: xo, so = O.pbicgstab(A, b, vm=O.ilu0(A) if precond else None, maxit=500, tol=1e-9)
+            elif loop == 2: xo, so = O.pipelined_bicgstab(A, b, maxit=500, tol=1e-9)
             else: ok, xo, so = O.pbicgstab2(A, b, maxit=500, tol=1e-9)
             # hundreds of un-preconditioned iterations on hub matrices are chaotic in the rounding order: there only
             # "the GPU must not do worse than the oracle by more than 2x" is checked
