@@ -13,7 +13,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import ALLGATHER_FN, ALLREDUCE_FN, GATHER_PART_FN, Comm
+from ._lib import ALLGATHER_FN, ALLREDUCE_FN, GATHER_PART_FN, GATHER_WINDOW_FN, Comm
 
 RCCL_ID_BYTES = 384     # CUDAMAT_RCCL_ID_BYTES
 
@@ -54,13 +54,50 @@ class TorchComm:
         self._ar = ALLREDUCE_FN(self._allreduce)
         self.n_parts = 0
         self.side = None
+        self.n_windows = 0
+        gw = GATHER_WINDOW_FN(self._gather_window) if device is not None else GATHER_WINDOW_FN()
+        self._gw = gw
         if pieces and device is not None:
             # pieces of the gather on a side stream (cudamat_comm.gather_part / comm_stream)
             self.side = torch.cuda.Stream(device=device)
             self._gp = GATHER_PART_FN(self._gather_part)
-            self.struct = Comm(self.rank, self.world, None, self._ag, self._ar, self._gp, self.side.cuda_stream)
+            self.struct = Comm(self.rank, self.world, None, self._ag, self._ar, self._gp, self.side.cuda_stream,
+                               ALLREDUCE_FN(), None, gw)
         else:
-            self.struct = Comm(self.rank, self.world, None, self._ag, self._ar)
+            self.struct = Comm(self.rank, self.world, None, self._ag, self._ar, GATHER_PART_FN(), None, ALLREDUCE_FN(), None, gw)
+
+    def _gather_window(self, user, send, recv, stride, send_off, send_cnt, recv_off, recv_cnt):
+        """windowed gather (halo) on the current stream: this rank sends send[send_off[q] .. + send_cnt[q]) to rank q and
+        receives rank q's [recv_off[q] .. + recv_cnt[q]) into recv[q*stride + recv_off[q] ..)"""
+        try:
+            torch, dist = self.torch, self.dist
+            nccl = dist.get_backend(self.group) == "nccl"
+            ops, staged = [], []
+            for d in range(1, self.world):
+                to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+                if send_cnt[to] > 0:
+                    t = self._view(send + 8 * send_off[to], send_cnt[to])
+                    ops.append(dist.P2POp(dist.isend, t if nccl else t.cpu(), to, self.group))
+                if recv_cnt[frm] > 0:
+                    dst = self._view(recv + 8 * (stride * frm + recv_off[frm]), recv_cnt[frm])
+                    if nccl:
+                        ops.append(dist.P2POp(dist.irecv, dst, frm, self.group))
+                    else:
+                        buf = torch.empty(recv_cnt[frm], dtype=torch.float64)
+                        staged.append((dst, buf))
+                        ops.append(dist.P2POp(dist.irecv, buf, frm, self.group))
+            if ops:
+                reqs = dist.batch_isend_irecv(ops)
+                if not nccl:
+                    for r in reqs:
+                        r.wait()
+                    for dst, buf in staged:
+                        dst.copy_(buf)
+            self.n_windows += 1
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self.error = e
+            return 1
 
     def _gather_part(self, user, send, recv, stride, offset, count):
         """rank q's send[offset, offset+count) -> recv[q*stride + offset, ...) on every other rank, on self.side.

@@ -476,3 +476,25 @@ def test_bench_two_gpus_over_rccl(cm):
         outs[form] = out
     assert outs["rccl:1"]["comm"]["form"]["gather"].startswith("in pieces")
     assert outs["rccl:1"]["config"]["gate_x_sha256"] == outs["rccl:0"]["config"]["gate_x_sha256"]
+
+
+def test_bench_two_processes_poisson_exchanges_a_halo():
+    """bench.py --workload poisson5 on two ranks (gloo rehearsal on one GPU): the ranks find that their rows reference
+    only a band of the other slice, exchange windows instead of gathering, pass the gate, and say so in the JSON"""
+    import json
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CUDAMAT_BENCH_ONE_DEVICE="1", CUDAMAT_BENCH_BACKEND="gloo", CUDAMAT_BENCH_FORMS="torch:0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--workload", "poisson5", "--rows", "400000", "--nx", "800", "--steps", "6", "--warmup", "1",
+                        "--cpu-baseline", "off"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["comm"]["gate"][-1]["failed_ranks"] == 0
+    assert out["comm"]["form"]["gather"].startswith("windows only"), out["comm"]["form"]
