@@ -442,6 +442,23 @@ def run_bench(args):
                 gbs = b_trsv / (out["trsv_ms_per_apply"] * 1e-3) / 1e9
                 out["trsv_roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_application": b_trsv}
+            # fabric bytes of the dependency-driven launches per application, from the committed counter passes of this
+            # workload (2 * FETCH_SIZE + WRITE_SIZE per launch: an UPPER bound here, the correction factor 2 holds for wide
+            # coalesced loads and these kernels gather 8 bytes per lane); launches per application = groups of L + groups of U
+            if world == 1 and args.workload == "rand50" and args.rows == 10_000_000 and args.per_row == 50 and precond == cm.PRECOND_ILU0:
+                import glob
+                for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*ilu0", "pmc_fetch_write.json")), reverse=True):
+                    pm = json.load(open(f))
+                    k = next((v for name, v in pm.items() if name.startswith("cm::k_trsv_syncfree") and isinstance(v, dict)
+                              and "hbm_bytes_per_launch_corrected" in v), None)
+                    if k is not None:
+                        groups = sum(max(2, min(16, nl // 24)) for nl in (st.n_levels_l, st.n_levels_u))
+                        out["trsv_traffic"] = {"kernel": "k_trsv_syncfree (near entries of every group)", "launches_per_application": groups,
+                                               "bytes_per_launch_upper_bound": k["hbm_bytes_per_launch_corrected"],
+                                               "bytes_per_application_upper_bound": groups * k["hbm_bytes_per_launch_corrected"],
+                                               "avg_launch_us": k["avg_us"], "source": os.path.relpath(f, ROOT),
+                                               "note": "the far entries go through 2 x (groups - 1) blocked SpMVs at 28 B per entry"}
+                        break
             out["levels"] = [st.n_levels_l, st.n_levels_u]
             # one-off setup (outside the timed region): level analysis of L and U; ILU(0) + factor layout + far/near split
             out["setup_s"] = {"analysis": st.t_analysis, "factor": st.t_factor}
