@@ -448,36 +448,6 @@ def test_block_jacobi_ilu0_sharded_vs_oracle(cm, oracle, golden_dir, world, name
     assert 2 + 3 * ran <= out[0][8] <= 2 + 3 * (ran + 3)             # (+1: the setup agreement of the solve)
 
 
-def test_bench_two_gpus_over_rccl(cm):
-    """two real GPUs (skipped on a one-GPU box): bench.py under torch.distributed.run with the library's RCCL
-    binding, the gather in pieces behind phase 1, and the same run with the plain all-gather -- both must pass
-    bench.py's own gate at the first form they are given and produce the same solution bit for bit"""
-    if cm.device_count() < 2:
-        pytest.skip("needs two GPUs")
-    import json
-    import socket
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = {}
-    for form in ("rccl:1", "rccl:0"):
-        sk = socket.socket()
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-        sk.close()
-        env = dict(os.environ, CUDAMAT_BENCH_FORMS=form, CUDAMAT_SPMV_MODE="pb")
-        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                            "--gpus", "2", "--rows", "2000000", "--steps", "10", "--warmup", "2", "--cpu-baseline", "off"],
-                           capture_output=True, text=True, timeout=600, env=env, cwd=root)
-        assert r.returncode == 0, r.stderr[-3000:]
-        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-        assert out["n_gpus"] == 2 and out["comm"]["gate"] == [{"form": {"comm": "rccl", "overlap": form.endswith("1")},
-                                                                 "failed_ranks": 0, "rank0_failure": None}]
-        outs[form] = out
-    assert outs["rccl:1"]["comm"]["form"]["gather"].startswith("in pieces")
-    assert outs["rccl:1"]["config"]["gate_x_sha256"] == outs["rccl:0"]["config"]["gate_x_sha256"]
-
-
 def test_bench_two_processes_poisson_exchanges_a_halo():
     """bench.py --workload poisson5 on two ranks (gloo rehearsal on one GPU): the ranks find that their rows reference
     only a band of the other slice, exchange windows instead of gathering, pass the gate, and say so in the JSON"""
