@@ -410,8 +410,8 @@ static int spmv_parts(const cudamat_solver *s)
 // Choose the SpMV implementation for this matrix (once), by TIMING the candidates on this device:
 //   0  the CSR forms (lanes per row / stream tiles / nnz-balanced tiles, plan_spmv_refine) -- always a candidate;
 //   1  the blocked two-phase kernels, when the columns are scattered over a vector far larger than L2 (pb_candidate);
-//   2  SELL-C-sigma, when row lengths vary (the lanes-per-row plan wastes lane-iterations) and the padded copy
-//      stays below 1.5 x the entries.
+//   2  SELL-C-sigma, for rows of 8 entries and more whose padded copy stays below 1.5 x the entries (banded
+//      matrices: 2-2.7 x the lanes-per-row kernel; short rows belong to the stream kernel).
 // CUDAMAT_SPMV_MODE=csr|pb|sell overrides.
 static int ensure_spmv_mode(cudamat_solver *s)
 {
@@ -493,11 +493,12 @@ static int ensure_spmv_mode(cudamat_solver *s)
             if (have[mode] && (!have[best] || ms[mode] < ms[best])) best = mode;
     s->spmv_mode = best;
     s->ms_spmv_alone = ms[best] / 2;
+    const double sell_fill = s->sell.fill;
     if (best != 1) pb_free(&s->pb);
     if (best != 2) sell_free(&s->sell);
     if (getenv("CUDAMAT_VERBOSE"))
         fprintf(stderr, "cudamat: SpMV auto-tune csr %.3f ms, blocked %s%.3f ms, sell %s%.3f ms (fill %.2f) -> %s\n", s->ms_csr,
-                have[1] ? "" : "(n/a) ", s->ms_pb, have[2] ? "" : "(n/a) ", s->ms_sell, s->sell.fill,
+                have[1] ? "" : "(n/a) ", s->ms_pb, have[2] ? "" : "(n/a) ", s->ms_sell, sell_fill,
                 best == 1 ? "blocked" : best == 2 ? "sell" : "csr");
     return CUDAMAT_OK;
 }
