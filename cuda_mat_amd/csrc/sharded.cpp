@@ -199,10 +199,11 @@ extern "C" int cudamat_solve_sharded(int ngpu, int n, int nnz, const double *A, 
                                      int maxit, double tol, int debug, double *x, cudamat_stats *out)
 {
     if (ngpu <= 1) return cudamat_solve(n, nnz, A, iA, jA, d, x0, b, precond, loop, maxit, tol, debug, x, out);
-    if (!(n > 0 && nnz >= 0 && A && iA && jA && b && x)) return CUDAMAT_ERR_ARG;
+    CM_ARG(n > 0 && nnz >= 0 && A && iA && jA && b && x, "null pointer or empty system");
     const int base = iA[0];
-    if (!((base == 0 || base == 1) && iA[n] - base == nnz)) return CUDAMAT_ERR_ARG;
-    if (precond == CUDAMAT_PRECOND_ILU0) return CUDAMAT_ERR_ARG;      // does not shard: CUDAMAT_PRECOND_BLOCK_ILU0 is the sharded form
+    CM_ARG((base == 0 || base == 1) && iA[n] - base == nnz, "iA[0] must be 0 or 1 and nnz == iA[n] - iA[0]");
+    CM_ARG(precond != CUDAMAT_PRECOND_ILU0, "ILU(0) of the whole matrix does not shard: use CUDAMAT_PRECOND_BLOCK_ILU0");
+    CM_ARG(ngpu <= n, "more ranks than rows");
     const double t0 = now_s();
     const char *emu = getenv("CUDAMAT_SHARDED_ONE_DEVICE");
     Shared sh;
@@ -210,7 +211,11 @@ extern "C" int cudamat_solve_sharded(int ngpu, int n, int nnz, const double *A, 
     sh.emulate = emu && emu[0] == '1';
     if (!sh.emulate) {
         int have = 0;
-        if (cudamat_device_count(&have) != CUDAMAT_OK || have < ngpu) return CUDAMAT_ERR_ARG;
+        CM_TRY(cudamat_device_count(&have));
+        if (have < ngpu) {
+            cm::set_error("%d GPUs requested, %d visible", ngpu, have);
+            return CUDAMAT_ERR_ARG;
+        }
     }
     sh.send.assign((size_t)ngpu, nullptr);
     sh.vals.assign((size_t)ngpu, std::vector<double>());
