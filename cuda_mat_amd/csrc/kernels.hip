@@ -113,6 +113,12 @@ __device__ __forceinline__ bool check_half(const LoopArgs &la, const ScalarSrc &
             if (leader()) st->state = 1;
             return true;
         }
+        // A NaN residual never passes a test: the reference would spin to maxit on NaNs (pbicgstab.cu:116 has no guard);
+        // here the loop stops and reports a breakdown, like the reference's own guard of the other loop (:735-742).
+        if (!la.no_exit && isnan(nrm)) {
+            if (leader()) st->state = 3;
+            return true;
+        }
     }
     return false;
 }
@@ -138,6 +144,10 @@ __device__ __forceinline__ bool check_full(const LoopArgs &la, const double (&sc
         return true;
     }
     if (la.loop == CUDAMAT_LOOP_PBICGSTAB2 && (fabs(omega) < 1e-5 || isnan(omega))) {
+        if (leader()) st->state = 3;
+        return true;
+    }
+    if (isnan(nrm)) {                       // (see check_half)
         if (leader()) st->state = 3;
         return true;
     }
@@ -1232,6 +1242,10 @@ __global__ __launch_bounds__(kBlock) void k_pipe_a(LoopArgs la, ScalarSrc B, int
             if (leader()) st->state = 2;
             return;
         }
+        if (!la.no_exit && isnan(nrm)) {                    // breakdown (0/0 somewhere): stop instead of spinning on NaNs
+            if (leader()) st->state = 3;
+            return;
+        }
     }
     const double rho = sc[0];
     double alpha, beta = 0.0, omega = 0.0;
@@ -1317,6 +1331,11 @@ __global__ __launch_bounds__(kBlock) void k_pipe_b(LoopArgs la, ScalarSrc A, int
     if (!la.no_exit && nrm < st->tolabs) {                  // :116 -- the iterate of this exit is xh
         if (leader()) st->state = 1;
         publish_progress(la, 1);
+        return;
+    }
+    if (!la.no_exit && isnan(nrm)) {
+        if (leader()) st->state = 3;
+        publish_progress(la, 3);
         return;
     }
     const double omega = sc[0] / sc[1];

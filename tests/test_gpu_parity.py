@@ -287,6 +287,13 @@ def test_pbicgstab2_breakdown_and_maxit(cm, ctx, oracle):
     # maxit = 0 leaves x = x0
     x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=0, tol=1e-8)
     assert st.iters == 0 and not st.converged and np.all(x == 1.0)
+    # the same skew-symmetric system through the loops WITHOUT a reference guard (pbicgstab.cu:45-154 would spin on
+    # NaNs up to maxit): t.t = ... / 0 somewhere => a NaN residual => the loop stops at once and reports a breakdown
+    for loop in (cm.LOOP_PBICGSTAB, cm.LOOP_PIPELINED):
+        x, st, h = _solve_dev(cm, ctx, Ask, np.array([1.0, 2.0]), loop=loop, maxit=500, tol=1e-12)
+        assert not st.converged and (st.breakdown or st.iters == 500)
+        if st.breakdown:
+            assert st.iters <= 3
 
 
 def test_drop_in_entry_points(cm, oracle, golden_dir):
