@@ -5,4 +5,4 @@ from ._lib import (FLAG_DEBUG, FLAG_NO_EXIT, FLAG_PROFILE, FLAG_X0_ONES, LOOP_PB
                    LOOP_PBICGSTAB2, LOOP_PIPELINED, PRECOND_BLOCK_ILU0, PRECOND_ILU0, PRECOND_NONE, Comm, CudamatError, Stats, build,
                    device_count, lib)
 from .api import (Context, DeviceArray, Solver, Timer, bicgstab, bicgstab_d,  # noqa: F401
-                  bicgstab_lu_precond, loadMMSparseMatrix, toDenseVector)
+                  bicgstab_lu_precond, loadMMSparseMatrix, toDenseVector, use_gpus)

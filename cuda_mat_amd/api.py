@@ -30,6 +30,17 @@ def _vp(a):
 
 
 # ----------------------------------------------------------------- drop-in functions
+_GPUS = 1
+
+
+def use_gpus(ngpu):
+    """spread the three drop-in solves below over `ngpu` GPUs of the node (uniform row blocks, one host thread and
+    one RCCL rank per device: cudamat_solve_sharded); the ILU(0) entry point then factors every GPU's diagonal block
+    (block-Jacobi).  Mirrors cudamat_use_gpus of include/pbicgstab.h.  Default 1 = the reference's behaviour."""
+    global _GPUS
+    _GPUS = max(1, int(ngpu))
+
+
 def _solve(n, nnz, A, iA, jA, d, x0, b, precond, loop, maxit, tol, debug):
     A, iA, jA, b = _np(A, np.float64), _np(iA, np.int32), _np(jA, np.int32), _np(b, np.float64)
     d = None if d is None else _np(d, np.float64)
@@ -38,8 +49,14 @@ def _solve(n, nnz, A, iA, jA, d, x0, b, precond, loop, maxit, tol, debug):
         raise ValueError("array sizes do not match n / nnz")
     x = np.zeros(n)
     st = Stats()
-    check(_lib.lib().cudamat_solve(n, nnz, _vp(A), _vp(iA), _vp(jA), _vp(d), _vp(x0), _vp(b), precond,
-                                   loop, maxit, tol, int(bool(debug)), _vp(x), C.byref(st)))
+    if _GPUS > 1:
+        if precond == PRECOND_ILU0:
+            precond = PRECOND_BLOCK_ILU0      # ILU(0) of the whole matrix does not shard
+        check(_lib.lib().cudamat_solve_sharded(_GPUS, n, nnz, _vp(A), _vp(iA), _vp(jA), _vp(d), _vp(x0), _vp(b), precond,
+                                               loop, maxit, tol, int(bool(debug)), _vp(x), C.byref(st)))
+    else:
+        check(_lib.lib().cudamat_solve(n, nnz, _vp(A), _vp(iA), _vp(jA), _vp(d), _vp(x0), _vp(b), precond,
+                                       loop, maxit, tol, int(bool(debug)), _vp(x), C.byref(st)))
     return x, st
 
 

@@ -1217,3 +1217,33 @@ def test_sell_in_the_solver_loop_and_auto_selection(cm, ctx, oracle, monkeypatch
         s.close()
     assert res["sell"][2] == 2 and res["csr"][2] == 0 and res[None][2] in (0, 2)
     assert np.linalg.norm(res["sell"][0] - res["csr"][0]) / np.linalg.norm(xo) <= 1e-10
+
+
+def test_drop_in_entry_points_over_several_ranks(cm, oracle, golden_dir, monkeypatch):
+    """cm.use_gpus(n) (= cudamat_use_gpus of pbicgstab.h): the three drop-in solves row-sharded by cudamat_solve_sharded.
+    On a one-GPU box the ranks share device 0 (CUDAMAT_SHARDED_ONE_DEVICE: host-synchronised copies stand in for RCCL)."""
+    if cm.device_count() < 3:
+        monkeypatch.setenv("CUDAMAT_SHARDED_ONE_DEVICE", "1")
+    A = _load(oracle, golden_dir, "mat10000")
+    xs = 1.0 + np.sin(np.arange(A.n))
+    b = oracle.spmv(A, xs)
+    ok1, x1, dt1, st1 = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 2000, 1e-8)
+    try:
+        cm.use_gpus(3)
+        ok3, x3, dt3, st3 = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 2000, 1e-8)
+        assert ok1 and ok3 and abs(st1.iters - st3.iters) <= max(2, st1.iters // 10)
+        assert np.linalg.norm(x3 - x1) / np.linalg.norm(x1) <= 1e-5
+        assert np.linalg.norm(b - oracle.spmv(A, x3)) <= 1e-7 * st3.nrm0
+        # the preconditioned entry point: block-Jacobi ILU(0) over 3 ranks, same solution
+        okp, xp, dtp, stp = cm.bicgstab_lu_precond(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 2000, 1e-8)
+        assert okp and stp.converged and stp.iters < st3.iters
+        assert np.linalg.norm(xp - x1) / np.linalg.norm(x1) <= 1e-5
+        # (A0 + I d) with a caller's x0
+        A0 = _load(oracle, golden_dir, "mat3_A0")
+        d = oracle.to_dense_vector(_load(oracle, golden_dir, "vec3_d"))
+        b3 = oracle.to_dense_vector(_load(oracle, golden_dir, "vec3"))
+        ok, x, dt, st = cm.bicgstab_d(3, A0.nnz, A0.val, A0.rowptr, A0.colidx, d, np.ones(3), b3, 2000, 1e-5)
+        assert ok
+        np.testing.assert_allclose(x, [7 / 6, 17 / 3, -23 / 6], rtol=1e-7)
+    finally:
+        cm.use_gpus(1)
