@@ -60,13 +60,42 @@ void orc_csrmv(int n, const int *rp, const int *ci, const double *v, double alph
     }
 }
 
-/* bicstab_omp/bicstab.cpp:83-91 */
+/* bicstab_omp/bicstab.cpp:83-91 (an `omp parallel for reduction(+)`, whose order of combination -- and so the
+ * last bits of the sum, and near a tolerance the iteration count -- changes with the thread count and from run to
+ * run).  A checker has to give the same answer every time: fixed blocks of ORC_DOT_BLOCK elements, each summed in
+ * index order, combined in block order -- identical for every thread count. */
+#define ORC_DOT_BLOCK 4096
 double orc_dot(int n, const double *a, const double *b)
 {
+    const int nb = (n + ORC_DOT_BLOCK - 1) / ORC_DOT_BLOCK;
     double sum = 0.0;
-#pragma omp parallel for reduction(+ : sum) schedule(static)
-    for (int i = 0; i < n; i++)
-        sum += a[i] * b[i];
+    if (nb <= 1) {
+        for (int i = 0; i < n; i++)
+            sum += a[i] * b[i];
+        return sum;
+    }
+    double *part = (double *)malloc((size_t)nb * sizeof(double));
+    if (!part) {                      /* out of memory: the same blocks, one after the other */
+        for (int k = 0; k < nb; k++) {
+            const int hi = (k + 1) * ORC_DOT_BLOCK < n ? (k + 1) * ORC_DOT_BLOCK : n;
+            double s = 0.0;
+            for (int i = k * ORC_DOT_BLOCK; i < hi; i++)
+                s += a[i] * b[i];
+            sum += s;
+        }
+        return sum;
+    }
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < nb; k++) {
+        const int hi = (k + 1) * ORC_DOT_BLOCK < n ? (k + 1) * ORC_DOT_BLOCK : n;
+        double s = 0.0;
+        for (int i = k * ORC_DOT_BLOCK; i < hi; i++)
+            s += a[i] * b[i];
+        part[k] = s;
+    }
+    for (int k = 0; k < nb; k++)
+        sum += part[k];
+    free(part);
     return sum;
 }
 
