@@ -257,7 +257,9 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     // Sub-blocks (one wave each): ~48 entries per (sub-block, column block) segment keeps a wave's
     // lanes busy, but never fewer than 4096 waves (16 per CU) -- a shard of a row-partitioned matrix
     // has few entries per column block and would otherwise be latency-bound.
-    double nsub_t = (double)nnz / ((double)p.NCB * 48.0);
+    double seg_target = 48.0;
+    if (const char *e = getenv("CUDAMAT_PB_SEG")) seg_target = atof(e);      // experiment
+    double nsub_t = (double)nnz / ((double)p.NCB * seg_target);
     if (nsub_t < 4096.0) nsub_t = 4096.0;
     if (nsub_t > (double)n / 16.0) nsub_t = (double)n / 16.0;
     if (nsub_t < 4.0) nsub_t = 4.0;

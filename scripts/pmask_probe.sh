@@ -2,13 +2,17 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmask
 rm -rf $O && mkdir -p $O
-for mb in 0 32 64 128 256 1024; do
+for seg in 48 24 12 6; do
+for mb in 0 64; do
+  export CUDAMAT_PB_SEG=$seg
   if [ $mb = 0 ]; then unset CUDAMAT_PB_PMASK_MB; else export CUDAMAT_PB_PMASK_MB=$mb; fi
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p$mb -- python3 $R/scripts/pmask_probe.py 2> $O/p$mb.err | grep PMASK
-  f=$(find $O/p$mb -name "*kernel_stats.csv" | head -1)
+  echo "seg $seg window $mb MB"
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p${seg}_$mb -- python3 $R/scripts/pmask_probe.py 2> $O/p${seg}_$mb.err | grep PMASK
+  f=$(find $O/p${seg}_$mb -name "*kernel_stats.csv" | head -1)
   python3 - $f <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'k_pb_phase' in r['Name']: print('   ', r['Name'][:26], r['Calls'], 'avg us', round(float(r['AverageNs'])/1e3,1))
+    if 'k_pb_phase' in r['Name']: print('   ', r['Name'][:32], r['Calls'], 'avg us', round(float(r['AverageNs'])/1e3,1))
 PY
+done
 done
