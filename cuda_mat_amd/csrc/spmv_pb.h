@@ -44,9 +44,6 @@ struct PbPlan {
     int *order = nullptr;          // NCB block ids, part after part
     int part_off[kPbMaxChunks + 2] = {0};
     double build_seconds = 0.0;
-    int slabs = 0, slab_order = 1;   // experiment: column slabs (CUDAMAT_PB_SLABS)
-    double *acc = nullptr;
-    int pmask = 0x7fffffff;          // experiment: products folded into a window of this many entries (timing only)
 };
 
 // decide whether the matrix is a candidate (large x, scattered columns) -- cheap estimate

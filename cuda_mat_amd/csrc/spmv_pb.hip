@@ -51,7 +51,7 @@ static int dalloc(T **p, size_t count)
 
 void pb_free(PbPlan *p)
 {
-    void *ptrs[] = {p->pv, p->pc, p->pr, p->P, p->cstart, p->col0, p->sstart, p->slen, p->order, p->acc};
+    void *ptrs[] = {p->pv, p->pc, p->pr, p->P, p->cstart, p->col0, p->sstart, p->slen, p->order};
     for (void *q : ptrs)
         if (q) hipFree(q);
     *p = PbPlan();
@@ -257,9 +257,7 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     // Sub-blocks (one wave each): ~48 entries per (sub-block, column block) segment keeps a wave's
     // lanes busy, but never fewer than 4096 waves (16 per CU) -- a shard of a row-partitioned matrix
     // has few entries per column block and would otherwise be latency-bound.
-    double seg_target = 48.0;
-    if (const char *e = getenv("CUDAMAT_PB_SEG")) seg_target = atof(e);      // experiment
-    double nsub_t = (double)nnz / ((double)p.NCB * seg_target);
+    double nsub_t = (double)nnz / ((double)p.NCB * 48.0);
     if (nsub_t < 4096.0) nsub_t = 4096.0;
     if (nsub_t > (double)n / 16.0) nsub_t = (double)n / 16.0;
     if (nsub_t < 4.0) nsub_t = 4.0;
@@ -295,12 +293,6 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
         if ((rc = dalloc(&p.cstart, (size_t)p.NCB + 1))) break;
         if ((rc = dalloc(&p.col0, (size_t)p.NCB + 1))) break;
         if ((rc = dalloc(&p.order, (size_t)p.NCB))) break;
-        if (const char *e = getenv("CUDAMAT_PB_PMASK_MB")) p.pmask = (int)((size_t)atoi(e) * (1 << 20) / 8) - 1;   // power of two MB
-        if (const char *e = getenv("CUDAMAT_PB_SLABS")) {
-            p.slabs = atoi(e);
-            if (const char *o = getenv("CUDAMAT_PB_SLAB_ORDER")) p.slab_order = atoi(o);
-            if (p.slabs > 1 && (rc = dalloc(&p.acc, (size_t)n))) break;
-        }
         {
             // first column of every block (blocks tile [0, n_cols) in order; blocks past the end are empty) and the
             // phase-1 launch parts: the local slice first, then piece after piece of the other slices
@@ -372,13 +364,13 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
 }
 
 // ------------------------------------------------------------------ phase 1
-__global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const int *col0, const int *list, int cb_first, int pmask,
+__global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const int *col0, const int *list,
                                                           const int *cstart, const double *pv, const u16 *pc,
                                                           double *P, const LoopState *st)
 {
     extern __shared__ __attribute__((aligned(16))) double xs[];
     if (st && st->state != 0) return;
-    const int cb = list ? list[blockIdx.x] : cb_first + (int)blockIdx.x;
+    const int cb = list ? list[blockIdx.x] : (int)blockIdx.x;
     const int s = cstart[cb], e = cstart[cb + 1];
     if (s == e) return;                                    // (block-uniform) nothing stored in this block
     const int c0 = col0[cb], cn = col0[cb + 1] - c0;
@@ -407,10 +399,10 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const
                 double2 o;
                 o.x = v[u].x * xs[c[u].x];
                 o.y = v[u].y * xs[c[u].y];
-                *(double2 *)(P + (kk & pmask)) = o;
+                *(double2 *)(P + kk) = o;
             } else {
-                if (kk >= s && kk < e) P[kk & pmask] = pv[kk] * xs[pc[kk]];
-                if (kk + 1 >= s && kk + 1 < e) P[(kk + 1) & pmask] = pv[kk + 1] * xs[pc[kk + 1]];
+                if (kk >= s && kk < e) P[kk] = pv[kk] * xs[pc[kk]];
+                if (kk + 1 >= s && kk + 1 < e) P[kk + 1] = pv[kk + 1] * xs[pc[kk + 1]];
             }
         }
     }
@@ -429,11 +421,6 @@ struct Pb2Args {
     const double *w;
     double *parts;
     const LoopState *st;
-    // column slabs (experiment, CUDAMAT_PB_SLABS): this launch adds the column blocks [cb_lo, cb_hi) only; the
-    // running sums of the rows travel through `acc` between the launches of one product
-    int cb_lo, cb_hi;
-    double *acc;
-    int pmask;
 };
 
 template <int NW, int LPS>
@@ -444,20 +431,16 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = blockIdx.x * NW + wave;
     double *my = yt + (size_t)wave * a.SR;
-    const long long row0 = (long long)sub * a.SR;
-    if (a.cb_lo == 0)
-        for (int i = lane; i < a.SR; i += 64) my[i] = 0.0;
-    else
-        for (int i = lane; i < a.SR; i += 64) my[i] = row0 + i < a.n ? a.acc[row0 + i] : 0.0;
+    for (int i = lane; i < a.SR; i += 64) my[i] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int *ss = a.sstart + (size_t)sub * a.NCB;
     const int *sl = a.slen + (size_t)sub * a.NCB;
-    for (int cb0 = a.cb_lo; cb0 < a.cb_hi; cb0 += 64) {
+    for (int cb0 = 0; cb0 < a.NCB; cb0 += 64) {
         const int c = cb0 + lane;
-        const int mys = c < a.cb_hi ? ss[c] : 0;
-        const int myl = c < a.cb_hi ? sl[c] : 0;
-        const int lim = a.cb_hi - cb0 < 64 ? a.cb_hi - cb0 : 64;
+        const int mys = c < a.NCB ? ss[c] : 0;
+        const int myl = c < a.NCB ? sl[c] : 0;
+        const int lim = a.NCB - cb0 < 64 ? a.NCB - cb0 : 64;
         // LPS < 64: 64/LPS segments share one wave instruction (lane group g takes column block j+g).
         // Groups are ordered by column block and ds_add_f64 serves equal addresses in lane order, so a
         // row still receives its products in increasing column order -- unless a segment is longer than
@@ -477,7 +460,7 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool on = lane < l[u];
-                    pv4[u] = on ? a.P[(s[u] + lane) & a.pmask] : 0.0;
+                    pv4[u] = on ? a.P[s[u] + lane] : 0.0;
                     r4[u] = on ? (int)a.pr[s[u] + lane] : 0;
                 }
 #pragma unroll
@@ -503,7 +486,7 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool on = li < l[u];
-                    pv4[u] = on ? a.P[(s[u] + li) & a.pmask] : 0.0;
+                    pv4[u] = on ? a.P[s[u] + li] : 0.0;
                     r4[u] = on ? (int)a.pr[s[u] + li] : 0;
                 }
 #pragma unroll
@@ -514,12 +497,9 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (a.cb_hi < a.NCB) {                 // (launch-uniform) more column slabs to come: park the running sums
-        for (int i = lane; i < a.SR && row0 + i < a.n; i += 64) a.acc[row0 + i] = my[i];
-        return;
-    }
     // epilogue: this wave's rows
     double acc0 = 0.0, acc1 = 0.0;
+    const long long row0 = (long long)sub * a.SR;
     for (int i = lane; i < a.SR && row0 + i < a.n; i += 64) {
 #pragma clang fp contract(off)   // one rounding per product and per sum, like cusparse's mult_spec + csrmv(beta=1)
         const int row = (int)(row0 + i);
@@ -576,46 +556,21 @@ int launch_pb_phase1(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int par
     const int first = part < 0 ? 0 : p.part_off[part], last = part < 0 ? p.NCB : p.part_off[part + 1];
     if (last <= first) return CUDAMAT_OK;
     hipLaunchKernelGGL(k_pb_phase1, dim3(last - first), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x, p.col0,
-                       part < 0 ? (const int *)nullptr : p.order + first, 0, p.pmask, p.cstart, p.pv, p.pc, p.P, a.loop.st);
+                       part < 0 ? (const int *)nullptr : p.order + first, p.cstart, p.pv, p.pc, p.P, a.loop.st);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }
 
-static int launch_pb_phase2_range(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int cb_lo, int cb_hi);
-
 int launch_spmv_pb(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
 {
     CM_TRY(launch_pb_check(st, a));
-    if (p.slabs > 1 && p.acc) {
-        // EXPERIMENT (CUDAMAT_PB_SLABS=S, CUDAMAT_PB_SLAB_ORDER=0|1): column slabs, the products of a slab consumed
-        // right after they were written (order 1) or after all of phase 1 (order 0) -- measures what Infinity-Cache
-        // residency of P is worth to the real phase 2
-        CM_TRY(set_max_lds((const void *)k_pb_phase1));
-        const int per = (p.NCB + p.slabs - 1) / p.slabs;
-        for (int pass = 0; pass < 2; pass++)
-            for (int lo = 0; lo < p.NCB; lo += per) {
-                const int hi = lo + per < p.NCB ? lo + per : p.NCB;
-                if (pass == 0 || p.slab_order == 1) {
-                    if (pass == 0)
-                        hipLaunchKernelGGL(k_pb_phase1, dim3(hi - lo), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x,
-                                           p.col0, (const int *)nullptr, lo, p.pmask, p.cstart, p.pv, p.pc, p.P, a.loop.st);
-                }
-                if ((pass == 0 && p.slab_order == 1) || (pass == 1 && p.slab_order == 0))
-                    CM_TRY(launch_pb_phase2_range(st, p, a, lo, hi));
-            }
-        CM_HIP(hipGetLastError());
-        return CUDAMAT_OK;
-    }
     CM_TRY(launch_pb_phase1(st, p, a, -1));
     return launch_pb_phase2(st, p, a);
 }
 
-int launch_pb_phase2(hipStream_t st, const PbPlan &p, const SpmvArgs &a) { return launch_pb_phase2_range(st, p, a, 0, p.NCB); }
-
-static int launch_pb_phase2_range(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int cb_lo, int cb_hi)
+int launch_pb_phase2(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
 {
     Pb2Args b;
-    b.cb_lo = cb_lo; b.cb_hi = cb_hi; b.acc = p.acc; b.pmask = p.pmask;
     b.n = p.n; b.NCB = p.NCB; b.SR = p.SR;
     b.sstart = p.sstart; b.slen = p.slen;
     b.P = p.P; b.pr = p.pr;

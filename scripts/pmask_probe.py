@@ -1,6 +1,7 @@
 """timing-only probe (results are wrong by construction): C4's blocked SpMV with the product stream folded into a
 window of CUDAMAT_PB_PMASK_MB megabytes -- the upper bound of what an Infinity-Cache-resident product ring could give
-the REAL phase-1 / phase-2 kernels (run under rocprofv3 --kernel-trace --stats for the per-kernel split)"""
+the REAL phase-1 / phase-2 kernels (run under rocprofv3 --kernel-trace --stats for the per-kernel split).
+The knob exists only in commits d474d75 / 7505629 (reverted); logs: profiles/r02_probes/pmask*_probe.log"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,3 +1,5 @@
+# NOTE: drives experiment knobs (CUDAMAT_PB_SLABS / _SLAB_ORDER / _PMASK_MB / _SEG) that exist only in commits d474d75 and
+# 7505629 (reverted afterwards); the logs of those runs are profiles/r02_probes/{slab,pmask,pmask_seg}_probe.log
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmask

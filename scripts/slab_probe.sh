@@ -1,3 +1,5 @@
+# NOTE: drives experiment knobs (CUDAMAT_PB_SLABS / _SLAB_ORDER / _PMASK_MB / _SEG) that exist only in commits d474d75 and
+# 7505629 (reverted afterwards); the logs of those runs are profiles/r02_probes/{slab,pmask,pmask_seg}_probe.log
 # run on the GPU box: what is Infinity-Cache residency of the product stream worth to the REAL phase 2?
 # column slabs (CUDAMAT_PB_SLABS=S): order 0 = all of phase 1, then phase 2 slab by slab (products cold, from HBM);
 # order 1 = phase 1 and phase 2 alternate per slab (products just written).  Per-kernel totals from rocprofv3.
