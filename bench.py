@@ -86,6 +86,9 @@ def cpu_baseline(args):
     iters_full = max(1, args.cpu_iters_full)
     x, it, t_tr, t_loop = O.bicg_timed(A, b, maxit=iters_full, eps=0.0, fast_transpose=True)
     it = max(it, 1)
+    # (ii) of SURVEY 8d: the same loop with its five vector loops parallel too (what a tuned host port would do)
+    _, it_p, _, t_loop_p = O.bicg_timed(A, b, maxit=iters_full, eps=0.0, parallel_vec=True, fast_transpose=True)
+    it_p = max(it_p, 1)
     # like for like: the oracle's restatement of the GPU loop (BiCGSTAB, pbicgstab.cu:581-754) on the
     # same matrix; tol = 0 never triggers, so exactly iters_full iterations run
     t1 = time.perf_counter()
@@ -101,6 +104,8 @@ def cpu_baseline(args):
         "threads": {"nproc": os.cpu_count(), "sched_affinity_at_start": HOST_CPUS,
                     "omp_threads_used": O.num_threads(), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
                     "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
+        "parallel_vector_loops": {"value": it_p / t_loop_p, "unit": "iter/s",
+                                  "sample": "the same BiCG loop with its five vector loops under OpenMP as well, %d iterations" % it_p},
         "bicgstab_port": {"value": max(st2.iters, 1) / dt2, "unit": "iter/s",
                           "sample": "oracle BiCGSTAB restatement (pbicgstab.cu:581-754), %d iterations on the same full matrix"
                                     % max(st2.iters, 1)},
