@@ -80,6 +80,18 @@ struct FuseArgs {
     ScalarSrc src;                         // mode 1: (rw.r, ||r||^2) partials;  mode 2: rw.v partials
     double *parts_half;                    // mode 2: ||s||^2 partial of every workgroup
 };
+// the whole loop in one launch (small systems; kernels.hip "resident loop")
+struct ResidentArgs {
+    int iters;                 // iterations this launch may run (it stops early when a test fires)
+    int first_count;           // partial sums behind parts_full at this launch's first iteration
+    unsigned spin_limit;       // polls a barrier wait may take (2^22 ~ seconds; CUDAMAT_RESIDENT_SPIN_LIMIT: tests)
+    unsigned *bar;             // [0] barrier arrivals, [1] set when a barrier wait ran into its bound; zeroed by the host
+    double *p_a, *p_b, *v_a, *v_b, *r, *s, *t, *x;
+    const double *rw;
+    double *parts_rv, *parts_tt, *parts_half, *parts_full;
+};
+bool resident_loop_supported(const SpmvPlan &plan, int n);
+int launch_resident_loop(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, const ResidentArgs &q);
 bool fused_spmv_supported(const SpmvPlan &plan);
 int launch_fused_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, const FuseArgs &f);
 // stream plans only: build the compressed index copy when every offset fits (no-op otherwise); rp/ci 0-based

@@ -1450,15 +1450,21 @@ struct FusedX {
     const double *r, *b1, *b2;     // FUSE_P: b1 = p, b2 = v;  FUSE_HALF: b1 = v
     double c1, c2;                 // FUSE_P: beta, -omega;    FUSE_HALF: -alpha
     bool first;                    // FUSE_P at iteration 0: p = r already (k_init)
-    __device__ __forceinline__ double operator()(int c) const
+    // the folded vector element from its already-fetched operands (rv = r, v1 = b1, v2 = b2 at the same index)
+    __device__ __forceinline__ double combine(double rv, double v1, double v2) const
     {
         if (MODE == FUSE_P) {
-            if (first) return b1[c];
-            double pp = fma(c2, b2[c], b1[c]);                 // pbicgstab.cu:86
+            if (first) return v1;
+            double pp = fma(c2, v2, v1);                       // pbicgstab.cu:86
             pp = c1 * pp;                                      // :87
-            return r[c] + pp;                                  // :88
+            return rv + pp;                                    // :88
         }
-        return fma(c1, b1[c], r[c]);                           // :109
+        return fma(c1, v1, rv);                                // :109
+    }
+    __device__ __forceinline__ double operator()(int c) const
+    {
+        if (MODE == FUSE_P) return first ? b1[c] : combine(r[c], b1[c], b2[c]);
+        return combine(r[c], b1[c], 0.0);
     }
 };
 
@@ -1522,10 +1528,21 @@ __device__ __forceinline__ FusedRowOps fused_row_ops(const SpmvArgs &a, const Fu
 }
 
 template <int MODE>
+__device__ __forceinline__ void fused_finish_row_x(const SpmvArgs &a, const FuseArgs &f, double alpha, int row, double sum,
+                                                   const FusedRowOps &o, double xr, double (&acc)[3]);
+
+template <int MODE>
 __device__ __forceinline__ void fused_finish_row(const SpmvArgs &a, const FuseArgs &f, const FusedX<MODE> &X, double alpha,
                                                  int row, double sum, const FusedRowOps &o, double (&acc)[3])
 {
-    const double xr = X(row);
+    fused_finish_row_x<MODE>(a, f, alpha, row, sum, o, X(row), acc);
+}
+
+// xr: the folded vector's element of this row
+template <int MODE>
+__device__ __forceinline__ void fused_finish_row_x(const SpmvArgs &a, const FuseArgs &f, double alpha, int row, double sum,
+                                                   const FusedRowOps &o, double xr, double (&acc)[3])
+{
     if (a.d) sum += o.d * xr;
     a.y[row] = sum;                                            // alpha = 1, beta = 0 inside the loop
     if (MODE == FUSE_P) {
@@ -1671,6 +1688,281 @@ int launch_fused_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, co
         }
     }
 #undef CM_FS
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// ---------------------------------------------------------------- resident loop (one launch, many iterations)
+// For systems of at most one stream tile per compute unit (<= 256 x 256 rows of <= 8 entries) even the three-launch
+// loop above is bound by launch boundaries: each of its kernels spends most of its 5-7 us being dispatched and
+// drained.  Here the SAME three phases run inside ONE launch: every workgroup owns one tile of R rows for the whole
+// solve -- its matrix entries, row ends and rw stay in registers / LDS -- and the phases are separated by a grid
+// barrier (release fence, one agent-scope atomic arrival, polling load, acquire fence) instead of a launch boundary.
+// Every scalar, stopping test and vector value is produced by the expressions of the fused loop (fused_prologue,
+// fused_finish_row, check_half, check_full); only the partial sums of the last phase are grouped per tile instead
+// of per vector chunk.  All workgroups take every exit decision from the same partial sums, so they leave the loop
+// in the same phase.  The grid is at most one workgroup per compute unit, all resident at once; should the GPU be
+// shared with something that keeps some of them from starting, the barrier's bounded wait raises a flag, every
+// workgroup leaves, and the host redoes the solve with the three-launch loop (cudamat_stats.loop_fallbacks).
+__device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned &epoch, int *s_ok, unsigned spin_limit)
+{
+    // Release side: everything other workgroups read is stored with agent-scope (write-through, sc1) stores, and the
+    // workgroup-scope release inside __syncthreads() has every wave wait for its stores -- so no L2 write-back here.
+    // Acquire side: buffer_inv sc1, after which plain (cached) loads of the others' data are served from memory.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        epoch += gridDim.x;
+        __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool good = true;
+        for (unsigned spins = 0; __hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch; spins++) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 255u) == 255u && __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                good = false;                                       // another workgroup gave up
+                break;
+            }
+            if (spins >= spin_limit) {                              // seconds: this launch is not making progress
+                __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = false;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *s_ok = good ? 1 : 0;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+// a store other workgroups (or the host) will read: agent scope = written through, never a dirty line in this XCD's L2
+// (the loop's acquire side invalidates that L2)
+template <typename T>
+__device__ __forceinline__ void st_shared(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_resident_loop(SpmvArgs a, ResidentArgs q)
+{
+    __shared__ double prod[kStreamNnz];
+    __shared__ int srp[R + 1];
+    __shared__ double lds[12];
+    __shared__ int s_ok;
+    constexpr int E = kStreamNnz / kBlock;
+    const int tid = threadIdx.x;
+    const int r0 = (int)blockIdx.x * R;                 // one tile per workgroup (launch_resident_loop checks)
+    const int nr = a.n - r0 < R ? a.n - r0 : R;
+    for (int i = tid; i <= nr; i += kBlock) srp[i] = a.rp[r0 + i];
+    __syncthreads();
+    const int base = srp[0], cnt = srp[nr] - base;
+    double v0[E];
+    int c0[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const int k = tid + j * kBlock;
+        v0[j] = k < cnt ? a.val[base + k] : 0.0;
+        c0[j] = k < cnt ? a.ci[base + k] : 0;
+    }
+    const bool own = tid < nr;
+    const int row = r0 + tid;
+    const int lo = own ? srp[tid] - base : 0, hi = own ? srp[tid + 1] - base : 0;
+    const double w_own = own ? q.rw[row] : 0.0;
+    const double d_own = own && a.d ? a.d[row] : 0.0;
+    double *p_a = q.p_a, *p_b = q.p_b, *v_a = q.v_a, *v_b = q.v_b, *r = q.r, *sv = q.s;
+    const LoopArgs la = a.loop;
+    LoopState *st = la.st;
+    const bool lead = leader();
+    const int G = (int)gridDim.x;
+    // The loop scalars live in registers: every workgroup derives them from the same partial sums in the same
+    // order, so all hold the same values and take the same decisions; the leader mirrors them into LoopState (for
+    // the host and for the launch that follows this one).
+    int it = st->it;
+    double rho_s[2] = {st->rho[0], st->rho[1]};
+    double alpha = st->alpha, omega = st->omega;
+    const double tolabs = st->tolabs;
+    if (st->state != 0) return;                        // (launch-uniform: nothing in this launch has written it yet)
+    double x_cur = own ? q.x[row] : 0.0;               // this row's x: a register for the whole launch
+    unsigned epoch = 0;
+    for (int k = 0; k < q.iters; k++) {
+        // ---- rho, beta, full-step test; p' = r + beta (p - omega v) on the fly; v' = A p'; rw.v'     :80-89, :104-106
+        double p_new = 0.0;
+        {
+            // the gathers do not depend on this phase's scalars: issue them first, combine once the scalars are known
+            double gr[E], gp[E], gv[E];
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int e = tid + j * kBlock;
+                gr[j] = 0.0; gp[j] = 0.0; gv[j] = 0.0;
+                if (e < cnt) {
+                    gp[j] = p_a[c0[j]];
+                    gr[j] = r[c0[j]];
+                    gv[j] = v_a[c0[j]];      // (unused at iteration 0, where p = r already)
+                }
+            }
+            const double r_own = own ? r[row] : 0.0, p_own = own ? p_a[row] : 0.0, v_own = own ? v_a[row] : 0.0;
+            double sc[2];
+            load_scalars<2>(ScalarSrc{q.parts_full, k == 0 ? q.first_count : G, 2}, sc, lds);
+            if (it != 0) {                                         // full-step test of iteration it-1 (check_full)
+                const double nrm = sqrt(sc[1]);
+                if (lead) {
+                    st_shared(&st->nrm, nrm);
+                    if (la.hist) {
+                        const int slot = (la.loop != CUDAMAT_LOOP_PBICGSTAB2) ? 2 * (it - 1) + 1 : it - 1;
+                        if (slot < la.hist_cap) st_shared(&la.hist[slot], nrm);
+                    }
+                }
+                if (!la.no_exit) {
+                    int stop = 0;
+                    if (nrm < tolabs) stop = 2;
+                    else if (la.loop == CUDAMAT_LOOP_PBICGSTAB2 && (fabs(omega) < 1e-5 || isnan(omega))) stop = 3;
+                    else if (isnan(nrm)) stop = 3;
+                    if (stop) {
+                        if (lead) st_shared(&st->state, stop);
+                        break;
+                    }
+                }
+            }
+            const double rho = sc[0], rhop = rho_s[(it + 1) & 1];
+            rho_s[it & 1] = rho;
+            if (lead) st_shared(&st->rho[it & 1], rho);
+            FusedX<FUSE_P> X;
+            X.first = it == 0;
+            X.c1 = (rho / rhop) * (alpha / omega);                 // :84 (unused at it == 0)
+            X.c2 = -omega;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int e = tid + j * kBlock;
+                if (e < cnt) prod[e] = v0[j] * X.combine(gr[j], gp[j], gv[j]);
+            }
+            __syncthreads();
+            double acc[1] = {0.0};
+            if (own) {
+                double sum = 0.0;
+                for (int j = lo; j < hi; j++) sum += prod[j];
+                p_new = X.combine(r_own, p_own, v_own);
+                if (a.d) sum += d_own * p_new;
+                st_shared(&v_b[row], sum);
+                st_shared(&p_b[row], p_new);
+                acc[0] = sum * w_own;                              // rw . v
+            }
+            block_sum<1>(acc, lds);
+            if (tid == 0) st_shared(&q.parts_rv[2 * blockIdx.x], acc[0]);
+        }
+        if (!grid_barrier(q.bar, epoch, &s_ok, q.spin_limit)) break;
+        // ---- alpha; s = r - alpha v' on the fly; x += alpha p'; t = A s; (t.s, t.t), ||s||^2          :107-111, :132-136
+        double s_new = 0.0, t_new = 0.0, x_half = 0.0;
+        {
+            double gr[E], gv[E];
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int e = tid + j * kBlock;
+                gr[j] = 0.0; gv[j] = 0.0;
+                if (e < cnt) {
+                    gr[j] = r[c0[j]];
+                    gv[j] = v_b[c0[j]];
+                }
+            }
+            const double r_own = own ? r[row] : 0.0, v_own = own ? v_b[row] : 0.0;
+            double sc[1];
+            load_scalars<1>(ScalarSrc{q.parts_rv, G, 2}, sc, lds);
+            alpha = rho_s[it & 1] / sc[0];                         // :107
+            if (lead) st_shared(&st->alpha, alpha);
+            FusedX<FUSE_HALF> X;
+            X.first = false;
+            X.c1 = -alpha;
+            X.c2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int e = tid + j * kBlock;
+                if (e < cnt) prod[e] = v0[j] * X.combine(gr[j], gv[j], 0.0);
+            }
+            __syncthreads();
+            double acc[3] = {0.0, 0.0, 0.0};
+            if (own) {
+                double sum = 0.0;
+                for (int j = lo; j < hi; j++) sum += prod[j];
+                s_new = X.combine(r_own, v_own, 0.0);
+                if (a.d) sum += d_own * s_new;
+                t_new = sum;
+                st_shared(&sv[row], s_new);
+                x_half = fma(alpha, p_new, x_cur);                 // :110
+                acc[0] = sum * s_new;                              // t . s
+                acc[1] = sum * sum;                                // t . t
+                acc[2] = s_new * s_new;                            // ||s||^2 (:111)
+            }
+            block_sum<3>(acc, lds);
+            if (tid == 0) {
+                st_shared(&q.parts_tt[2 * blockIdx.x], acc[0]);
+                st_shared(&q.parts_tt[2 * blockIdx.x + 1], acc[1]);
+                st_shared(&q.parts_half[blockIdx.x], acc[2]);
+            }
+        }
+        if (!grid_barrier(q.bar, epoch, &s_ok, q.spin_limit)) break;
+        // ---- half-step test, omega, x += omega s, r = s - omega t, (rw.r, ||r||^2), i++                :116, :137-151
+        {
+            double sc[3] = {0.0, 0.0, 0.0};                        // ||s||^2, t.s, t.t
+            for (int j = tid; j < G; j += kBlock) {
+                sc[0] += q.parts_half[j];
+                sc[1] += q.parts_tt[2 * j];
+                sc[2] += q.parts_tt[2 * j + 1];
+            }
+            block_sum<3>(sc, lds);
+            if (la.loop == CUDAMAT_LOOP_PBICGSTAB) {               // half-step test (check_half)
+                const double nrm = sqrt(sc[0]);
+                if (lead) {
+                    st_shared(&st->nrm, nrm);
+                    if (la.hist && 2 * it < la.hist_cap) st_shared(&la.hist[2 * it], nrm);
+                }
+                if (!la.no_exit && (nrm < tolabs || isnan(nrm))) {
+                    if (lead) st_shared(&st->state, nrm < tolabs ? 1 : 3);
+                    x_cur = x_half;                                // x += alpha p' belongs to the half step
+                    break;
+                }
+            }
+            omega = sc[1] / sc[2];                                 // :137
+            double acc[2] = {0.0, 0.0};
+            if (own) {
+                x_cur = fma(omega, s_new, x_half);                 // :139
+                const double rr = fma(-omega, t_new, s_new);       // :140
+                st_shared(&sv[row], rr);   // the new residual goes over s (as k_full does)
+                acc[0] = w_own * rr;                               // :81 of i+1
+                acc[1] = rr * rr;                                  // :142
+            }
+            block_sum<2>(acc, lds);
+            if (tid == 0) {
+                st_shared(&q.parts_full[2 * blockIdx.x], acc[0]);
+                st_shared(&q.parts_full[2 * blockIdx.x + 1], acc[1]);
+            }
+            it++;
+            if (lead) {
+                st_shared(&st->omega, omega);
+                st_shared(&st->it, it);                            // :148 / :151
+            }
+        }
+        if (!grid_barrier(q.bar, epoch, &s_ok, q.spin_limit)) break;
+        double *tp = p_a; p_a = p_b; p_b = tp;
+        tp = v_a; v_a = v_b; v_b = tp;
+        tp = r; r = sv; sv = tp;
+    }
+    if (own) q.x[row] = x_cur;
+}
+
+bool resident_loop_supported(const SpmvPlan &plan, int n)
+{
+    // one stream tile per workgroup, at most one workgroup per compute unit of an MI355X
+    return plan.tiles == 0 && plan.stream_rows > 0 && plan.rows_per_block == 1 && plan.grid >= 1 && plan.grid <= 256 &&
+           (long long)plan.grid * plan.stream_rows >= n;
+}
+
+int launch_resident_loop(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, const ResidentArgs &q)
+{
+    dim3 g(plan.grid), b(kBlock);
+    switch (plan.stream_rows) {
+    case 64:  hipLaunchKernelGGL(k_resident_loop<64>, g, b, 0, s, a, q); break;
+    case 128: hipLaunchKernelGGL(k_resident_loop<128>, g, b, 0, s, a, q); break;
+    default:  hipLaunchKernelGGL(k_resident_loop<256>, g, b, 0, s, a, q); break;
+    }
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }

@@ -112,6 +112,9 @@ struct cudamat_solver {
     void *ilu_plans = nullptr;  // launch plans owned by ilu.hip
     double t_analysis = 0.0, t_factor = 0.0, t_analysis_l = 0.0, t_analysis_u = 0.0;
     int trsv_fallbacks = 0;     // solves redone level by level after a dependency-driven wait timed out
+    unsigned *bar = nullptr;    // grid barrier words of the single-launch loop (device)
+    bool resident_off = false;  // a barrier wait ran into its bound once: keep to the three-launch loop
+    int loop_fallbacks = 0;     // solves redone with the three-launch loop for that reason
 };
 
 namespace cm {

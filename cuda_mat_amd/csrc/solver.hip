@@ -215,6 +215,7 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     for (hipEvent_t e : s->prof_ev) hipEventDestroy(e);
     for (hipEvent_t e : s->comm_ev) hipEventDestroy(e);
     if (s->need_dev) hipFree(s->need_dev);
+    if (s->bar) hipFree(s->bar);
     for (int e = 0; e < 2; e++) {
         if (s->ev_red[e]) hipEventDestroy(s->ev_red[e]);
         if (s->ev_red_done[e]) hipEventDestroy(s->ev_red_done[e]);
@@ -691,7 +692,7 @@ extern "C" int cudamat_solver_precond_apply(cudamat_solver *s, const double *in,
 }
 
 static int solve_once(cudamat_solver *s, const double *b, double *x, int precond, int loop, int maxit, double tol,
-                      int flags, cudamat_stats *out, bool *precond_gave_up)
+                      int flags, cudamat_stats *out, bool *precond_gave_up, bool *resident_gave_up)
 {
     CM_ARG(s && b && x, "null pointer");
     CM_ARG(precond == CUDAMAT_PRECOND_NONE || precond == CUDAMAT_PRECOND_ILU0 || precond == CUDAMAT_PRECOND_BLOCK_ILU0,
@@ -834,8 +835,56 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     }
     double *p_a = s->p, *p_b = s->pw, *v_a = s->v, *v_b = s->v2;
 
+    // Very small systems (one stream tile per workgroup, at most one workgroup per compute unit): the whole loop in ONE
+    // launch, grid barriers instead of launch boundaries (kernels.hip, "resident loop").  CUDAMAT_RESIDENT=0 disables.
+    *resident_gave_up = false;
+    int loop_form = fused ? 1 : 0;
+    bool resident = false;
+    {
+        const char *re = getenv("CUDAMAT_RESIDENT");
+        resident = fused && !profile && !s->resident_off && !(re && re[0] == '0') && resident_loop_supported(s->plan, n);
+    }
+    if (resident) {
+        loop_form = 2;
+        if (!s->bar) CM_TRY(dev_alloc((void **)&s->bar, 2 * sizeof(unsigned)));
+        SpmvArgs a{};
+        a.n = n; a.rp = s->rp; a.ci = s->ci; a.val = s->val; a.x = nullptr; a.d = s->d; a.xd = nullptr;
+        a.alpha = 1.0; a.beta = 0.0; a.check = CHECK_NONE; a.half = nosrc;
+        a.loop = la;
+        a.loop.snap = nullptr;               // no per-iteration progress words: the host waits for the launch
+        int done = 0;
+        while (done < maxit) {
+            const int c = maxit - done < 8192 ? maxit - done : 8192;      // ~0.1 s of iterations per launch
+            CM_HIP(hipMemsetAsync(s->bar, 0, 2 * sizeof(unsigned), st));
+            ResidentArgs q{};
+            q.iters = c; q.first_count = done == 0 ? np_full : s->plan.grid; q.bar = s->bar;
+            q.spin_limit = 1u << 22;
+            if (const char *lim = getenv("CUDAMAT_RESIDENT_SPIN_LIMIT")) q.spin_limit = (unsigned)atoi(lim);
+            q.p_a = p_a; q.p_b = p_b; q.v_a = v_a; q.v_b = v_b; q.r = s->r; q.s = s->s; q.t = s->t; q.x = x; q.rw = s->rw;
+            q.parts_rv = s->parts_rv; q.parts_tt = s->parts_tt; q.parts_half = s->parts_half; q.parts_full = s->parts_full;
+            CM_TRY(launch_resident_loop(st, s->plan, a, q));
+            unsigned bar_host[2] = {0u, 0u};
+            CM_HIP(hipMemcpyAsync(&s->st_ring[0], s->st, sizeof(LoopState), hipMemcpyDeviceToHost, st));
+            CM_HIP(hipMemcpyAsync(bar_host, s->bar, sizeof(bar_host), hipMemcpyDeviceToHost, st));
+            CM_HIP(hipStreamSynchronize(st));
+            if (bar_host[1] != 0u) {         // a barrier wait ran into its bound: this attempt is void
+                *resident_gave_up = true;
+                *precond_gave_up = false;
+                return CUDAMAT_OK;
+            }
+            full_src = ScalarSrc{s->parts_full, s->plan.grid, 2};
+            if (s->st_ring[0].state != 0) break;
+            if (c & 1) {
+                std::swap(p_a, p_b);
+                std::swap(v_a, v_b);
+                std::swap(s->r, s->s);
+            }
+            done += c;
+        }
+    }
+
     int k = 0;
-    for (; k < maxit; k++) {
+    for (; !resident && k < maxit; k++) {
         if (k >= kLag) {   // lagged, deterministic look at the device state: the progress word of
             const int j = k - kLag;   // iteration j, published by its k_full through pinned memory
             volatile unsigned long long *slot = &s->snap_host[j % kRing];
@@ -1028,6 +1077,8 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     stt.n_levels_u = s->U.nlevels;
     stt.trsv_form = precond ? trsv_form_code(s) : 0;
     stt.trsv_fallbacks = s->trsv_fallbacks;
+    stt.loop_form = loop_form;
+    stt.loop_fallbacks = s->loop_fallbacks;
     stt.overlapped = sharded && s->windowed ? 2 : (sharded && s->overlap && s->spmv_mode == 1) ? 1 : 0;
     stt.gather_fraction = sharded ? s->gather_fraction : 0.0;
     stt.ms_spmv_alone = s->ms_spmv_alone;
@@ -1093,14 +1144,28 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
     CM_ARG(s && b && x, "null pointer");
     // keep the caller's x0 while the dependency-driven preconditioner is in use: if one of its waits times
     // out, the solve is redone from x0 with the level-by-level kernels (same results, bit for bit)
-    const bool keep_x0 = precond != CUDAMAT_PRECOND_NONE && !(flags & CUDAMAT_FLAG_X0_ONES);
+    // (the single-launch loop of very small systems can be voided the same way: <= 65536 rows, the copy is nothing)
+    const bool keep_x0 = (precond != CUDAMAT_PRECOND_NONE || (!s->sharded && !s->resident_off && s->n <= 65536)) &&
+                         !(flags & CUDAMAT_FLAG_X0_ONES);
     if (keep_x0) {
         CM_HIP(hipSetDevice(s->ctx->device));
         if (!s->x0_save) CM_TRY(dev_alloc((void **)&s->x0_save, sizeof(double) * (size_t)(s->n > 0 ? s->n : 1)));
         CM_HIP(hipMemcpyAsync(s->x0_save, x, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
     }
-    bool gave_up = false;
-    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up));
+    bool gave_up = false, resident_gave_up = false;
+    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up));
+    if (resident_gave_up) {
+        // the grid barrier of the single-launch loop ran into its bound (its workgroups were not all resident: the GPU
+        // is shared): from now on this solver uses the three-launch loop; the solve is redone from x0
+        s->resident_off = true;
+        s->loop_fallbacks++;
+        if (getenv("CUDAMAT_VERBOSE"))
+            fprintf(stderr, "cudamat: the single-launch loop's grid barrier timed out (GPU shared?); redoing the solve with "
+                            "one launch per phase\n");
+        if (keep_x0)
+            CM_HIP(hipMemcpyAsync(x, s->x0_save, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
+        CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up));
+    }
     if (!gave_up) return CUDAMAT_OK;
     if (!trsv_syncfree_active(s)) {
         set_error("triangular solve reported a timeout although the level-by-level kernels were in use");
@@ -1113,7 +1178,7 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
                         "kernel?); redoing the solve with one launch per level\n");
     if (keep_x0)
         CM_HIP(hipMemcpyAsync(x, s->x0_save, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
-    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up));
+    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up));
     if (gave_up) {
         set_error("triangular solve timed out twice");
         return CUDAMAT_ERR_HIP;

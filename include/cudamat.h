@@ -112,11 +112,15 @@ typedef struct cudamat_stats {
     double ms_gather;   double ms_gather_exposed;   double ms_allreduce;
     int overlapped;     /* 1: the gather ran in pieces behind phase 1 of the blocked SpMV; 2: only the windows
                          * of the other slices that this rank's rows reference were exchanged (halo)            */
-    int reserved_;
+    int loop_form;      /* how the iterations were issued: 0 five launches each, 1 three (vector updates folded into the
+                         * SpMVs, small systems), 2 the whole loop in ONE launch with grid barriers (<= 65536 short rows) */
     double gather_fraction; /* doubles received per SpMV / doubles of a whole gather ((world-1) slices)        */
     double ms_spmv_alone;  /* the selected SpMV form with its input in place, as timed when it was selected
                             * (0: never timed); an overlapped gather's exposed part is what the SpMVs of the
                             * loop took beyond this                                                            */
+    int loop_fallbacks;    /* solves of this solver that were discarded and redone with the three-launch loop because a
+                            * grid barrier of the single-launch loop ran into its bound (GPU shared; 0 in a healthy run) */
+    int reserved_;
 } cudamat_stats;
 
 /* Collectives for a row-sharded solve.  Either supplied by the host program (e.g.

@@ -1037,13 +1037,14 @@ def test_fused_small_system_loop_equals_five_launch_loop(cm, ctx, oracle, golden
         kw = dict(loop=cm.LOOP_PBICGSTAB2, maxit=400, tol=1e-9)
     b = oracle.spmv(A, xs) + (d * xs if d is not None else 0.0)
     res = {}
+    monkeypatch.setenv("CUDAMAT_RESIDENT", "0")      # (the single-launch form of the same loop has its own test below)
     for fused in ("0", "1000000"):
         monkeypatch.setenv("CUDAMAT_FUSED", fused)
         monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
         x, st, h = _solve_dev(cm, ctx, A, b, d=d, **kw)
         res[fused] = (x, st, h)
     (x0, st0, h0), (x1, st1, h1) = res["0"], res["1000000"]
-    assert st0.converged and st1.converged
+    assert st0.converged and st1.converged and (st0.loop_form, st1.loop_form) == (0, 1)
     # the summation order of ||s||^2 differs in the last bit; BiCGSTAB amplifies that over hundreds of iterations,
     # so: the first 20 residuals agree to 1e-9, short solves agree throughout, long ones within 10 % of iterations
     k = min(20, len(h0), len(h1))
@@ -1247,3 +1248,87 @@ def test_drop_in_entry_points_over_several_ranks(cm, oracle, golden_dir, monkeyp
         np.testing.assert_allclose(x, [7 / 6, 17 / 3, -23 / 6], rtol=1e-7)
     finally:
         cm.use_gpus(1)
+
+
+def test_single_launch_loop_matches_the_three_launch_loop(cm, ctx, oracle, golden_dir, monkeypatch):
+    """systems of at most one stream tile per compute unit run the whole loop in ONE launch (grid barriers between
+    the phases, cudamat_stats.loop_form == 2): same stopping decisions and iterates as one launch per phase"""
+    for name, loop, tol in (("mat10000", cm.LOOP_PBICGSTAB, 1e-8), ("mat900", cm.LOOP_PBICGSTAB, 1e-8),
+                            ("mat10000", cm.LOOP_PBICGSTAB2, 1e-8)):
+        A = _load(oracle, golden_dir, name)
+        xs = 1.0 + np.sin(np.arange(A.n))
+        b = oracle.spmv(A, xs)
+        res = {}
+        for resident in ("1", "0"):
+            monkeypatch.setenv("CUDAMAT_RESIDENT", resident)
+            s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+            db, dx = ctx.array(b), ctx.empty(A.n)
+            st = s.solve(db, dx, loop=loop, maxit=2000, tol=tol, flags=cm.FLAG_X0_ONES)
+            res[resident] = (dx.download(), st, s.history())
+            for a in (db, dx):
+                a.free()
+            s.close()
+        (x1, st1, h1), (x0, st0, h0) = res["1"], res["0"]
+        assert st1.loop_form == 2 and st0.loop_form == 1 and st1.loop_fallbacks == 0
+        assert st1.converged and st0.converged
+        # the only difference is the grouping of the last phase's partial sums (per tile / per vector chunk): the
+        # residual histories start out equal to rounding and then drift apart as any two BiCGSTAB runs with different
+        # summation orders do (an un-preconditioned 70-iteration run amplifies 1e-16 to tens of percent)
+        assert abs(st1.iters - st0.iters) <= max(2, st0.iters // 10)
+        np.testing.assert_allclose(h1[:8], h0[:8], rtol=1e-12)
+        assert np.linalg.norm(x1 - x0) <= 1e-5 * np.linalg.norm(x0)
+        assert np.linalg.norm(x1 - xs) <= 1e-5 * np.linalg.norm(xs)
+        assert np.linalg.norm(b - oracle.spmv(A, x1)) <= 1.5 * tol * st1.nrm0
+    # the (A0 + I d) variant with a caller's x0
+    A = _load(oracle, golden_dir, "mat900")
+    rng = np.random.default_rng(5)
+    d = 0.5 + rng.random(A.n)
+    xs = 1.0 + rng.random(A.n)
+    b = oracle.spmv(A, xs) + d * xs
+    out = {}
+    for resident in ("1", "0"):
+        monkeypatch.setenv("CUDAMAT_RESIDENT", resident)
+        x, st, h = _solve_dev(cm, ctx, A, b, d=d, loop=cm.LOOP_PBICGSTAB2, maxit=400, tol=1e-9)
+        out[resident] = (x, st, h)
+    assert (out["1"][1].loop_form, out["0"][1].loop_form) == (2, 1)
+    assert out["1"][1].converged and abs(out["1"][1].iters - out["0"][1].iters) <= 2
+    np.testing.assert_allclose(out["1"][2][:8], out["0"][2][:8], rtol=1e-12)
+    np.testing.assert_allclose(out["1"][0], xs, rtol=1e-6)
+    # fixed iteration windows (the bench's mode): exactly maxit iterations, odd and even, also across launch chunks
+    A = _load(oracle, golden_dir, "mat10000")
+    b = oracle.spmv(A, 1.0 + np.sin(np.arange(A.n)))
+    monkeypatch.setenv("CUDAMAT_RESIDENT", "1")
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+    db, dx = ctx.array(b), ctx.empty(A.n)
+    for maxit in (1, 2, 7, 8193):
+        st = s.solve(db, dx, maxit=maxit, tol=1e-8, flags=cm.FLAG_X0_ONES | cm.FLAG_NO_EXIT)
+        assert st.iters == maxit and st.loop_form == 2
+    s.close()
+
+
+def test_single_launch_loop_timeout_redoes_the_solve(cm, ctx, oracle, golden_dir, monkeypatch):
+    """a grid barrier whose wait runs into its bound (forced here: a bound of one poll) voids the attempt: the solve
+    is redone from the caller's x0 with one launch per phase, the solver stays with that form, the stats say so"""
+    A = _load(oracle, golden_dir, "mat10000")
+    xs = 1.0 + np.sin(np.arange(A.n))
+    b = oracle.spmv(A, xs)
+    x0 = np.full(A.n, 0.25)
+    monkeypatch.setenv("CUDAMAT_RESIDENT", "0")
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+    db, dx = ctx.array(b), ctx.array(x0)
+    ref = s.solve(db, dx, maxit=2000, tol=1e-8)
+    xref = dx.download()
+    s.close()
+    monkeypatch.setenv("CUDAMAT_RESIDENT", "1")
+    monkeypatch.setenv("CUDAMAT_RESIDENT_SPIN_LIMIT", "0")
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+    dx2 = ctx.array(x0)
+    st = s.solve(db, dx2, maxit=2000, tol=1e-8)
+    assert st.loop_fallbacks == 1 and st.loop_form == 1 and st.converged and st.iters == ref.iters
+    np.testing.assert_array_equal(dx2.download(), xref)
+    monkeypatch.delenv("CUDAMAT_RESIDENT_SPIN_LIMIT")
+    dx3 = ctx.array(x0)
+    st = s.solve(db, dx3, maxit=2000, tol=1e-8)          # the solver keeps to the three-launch loop
+    assert st.loop_fallbacks == 1 and st.loop_form == 1
+    np.testing.assert_array_equal(dx3.download(), xref)
+    s.close()
