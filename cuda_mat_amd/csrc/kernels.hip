@@ -1693,7 +1693,7 @@ int launch_fused_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, co
 }
 
 // ---------------------------------------------------------------- resident loop (one launch, many iterations)
-// For systems of at most one stream tile per compute unit (<= 256 x 256 rows of <= 8 entries) even the three-launch
+// For systems of at most 128 stream tiles (<= 128 x 256 rows of <= 8 entries) even the three-launch
 // loop above is bound by launch boundaries: each of its kernels spends most of its 5-7 us being dispatched and
 // drained.  Here the SAME three phases run inside ONE launch: every workgroup owns one tile of R rows for the whole
 // solve -- its matrix entries, row ends and rw stay in registers / LDS -- and the phases are separated by a grid
@@ -1701,7 +1701,7 @@ int launch_fused_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, co
 // Every scalar, stopping test and vector value is produced by the expressions of the fused loop (fused_prologue,
 // fused_finish_row, check_half, check_full); only the partial sums of the last phase are grouped per tile instead
 // of per vector chunk.  All workgroups take every exit decision from the same partial sums, so they leave the loop
-// in the same phase.  The grid is at most one workgroup per compute unit, all resident at once; should the GPU be
+// in the same phase.  The grid is at most one workgroup per two compute units, all resident at once; should the GPU be
 // shared with something that keeps some of them from starting, the barrier's bounded wait raises a flag, every
 // workgroup leaves, and the host redoes the solve with the three-launch loop (cudamat_stats.loop_fallbacks).
 __device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned &epoch, int *s_ok, unsigned spin_limit)
@@ -1950,8 +1950,11 @@ __global__ __launch_bounds__(kBlock) void k_resident_loop(SpmvArgs a, ResidentAr
 
 bool resident_loop_supported(const SpmvPlan &plan, int n)
 {
-    // one stream tile per workgroup, at most one workgroup per compute unit of an MI355X
-    return plan.tiles == 0 && plan.stream_rows > 0 && plan.rows_per_block == 1 && plan.grid >= 1 && plan.grid <= 256 &&
+    // one stream tile per workgroup; up to 128 workgroups (half the compute units of an MI355X): a grid barrier costs
+    // 1.1 us with 8 workgroups, 1.4 us with 40, 2.5 us with 128 and 4.3 us with 256 (scripts/probe_barrier.hip: the
+    // arrivals serialise on one counter), and beyond ~150 tiles three barriers cost more than three launch boundaries
+    // (scripts/resident_sizes.sh: 1.56x at 10 tiles, 1.38x at 40, 1.29x at 78, 1.09x at 127, 1.0x at 157, 0.76x at 255)
+    return plan.tiles == 0 && plan.stream_rows > 0 && plan.rows_per_block == 1 && plan.grid >= 1 && plan.grid <= 128 &&
            (long long)plan.grid * plan.stream_rows >= n;
 }
 

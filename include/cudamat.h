@@ -113,7 +113,7 @@ typedef struct cudamat_stats {
     int overlapped;     /* 1: the gather ran in pieces behind phase 1 of the blocked SpMV; 2: only the windows
                          * of the other slices that this rank's rows reference were exchanged (halo)            */
     int loop_form;      /* how the iterations were issued: 0 five launches each, 1 three (vector updates folded into the
-                         * SpMVs, small systems), 2 the whole loop in ONE launch with grid barriers (<= 65536 short rows) */
+                         * SpMVs, small systems), 2 the whole loop in ONE launch with grid barriers (<= 32768 short rows) */
     double gather_fraction; /* doubles received per SpMV / doubles of a whole gather ((world-1) slices)        */
     double ms_spmv_alone;  /* the selected SpMV form with its input in place, as timed when it was selected
                             * (0: never timed); an overlapped gather's exposed part is what the SpMVs of the

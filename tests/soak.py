@@ -10,6 +10,7 @@ ctx = cm.Context(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = 0
+forms = {}
 for case in range(ncase):
     n = int(rng.integers(1, 40000))
     per = float(rng.choice([1.5, 4, 9, 30, 80]))
@@ -55,6 +56,7 @@ for case in range(ncase):
             except cm.CudamatError as e:
                 msgs.append("solve error %s" % e); s.close(); continue
             xg = dxx.download()
+            forms[st.loop_form] = forms.get(st.loop_form, 0) + 1
             if loop == 0: xo, so = O.pbicgstab(A, b, vm=O.ilu0(A) if precond else None, maxit=500, tol=1e-9)
             elif loop == 2: xo, so = O.pipelined_bicgstab(A, b, maxit=500, tol=1e-9)
             else: ok, xo, so = O.pbicgstab2(A, b, maxit=500, tol=1e-9)
@@ -93,4 +95,4 @@ for case in range(ncase):
     if msgs:
         bad += 1
         print("case %d n=%d per=%g base=%d: %s" % (case, n, per, base, "; ".join(msgs)), flush=True)
-print("soak: %d cases, %d with findings" % (ncase, bad))
+print("soak: %d cases, %d with findings; solves by loop form (0 five launches, 1 three, 2 one): %s" % (ncase, bad, sorted(forms.items())))
