@@ -114,6 +114,7 @@ struct cudamat_solver {
     int trsv_fallbacks = 0;     // solves redone level by level after a dependency-driven wait timed out
     unsigned *bar = nullptr;    // grid barrier words of the single-launch loop (device)
     bool resident_off = false;  // a barrier wait ran into its bound once: keep to the three-launch loop
+    int device_cus = 0;         // compute units of the device (0: not asked yet)
     int loop_fallbacks = 0;     // solves redone with the three-launch loop for that reason
 };
 

@@ -843,6 +843,12 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     {
         const char *re = getenv("CUDAMAT_RESIDENT");
         resident = fused && !profile && !s->resident_off && !(re && re[0] == '0') && resident_loop_supported(s->plan, n);
+        if (resident) {      // all workgroups must be resident at once: at most one per two compute units of THIS device
+            if (s->device_cus == 0 &&
+                hipDeviceGetAttribute(&s->device_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device) != hipSuccess)
+                s->device_cus = -1;
+            resident = s->device_cus > 0 && 2 * s->plan.grid <= s->device_cus;
+        }
     }
     if (resident) {
         loop_form = 2;
