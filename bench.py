@@ -424,6 +424,10 @@ def run_bench(args):
                          "iteration_bytes": 2 * b_spmv + vec_bytes,
                          "iteration_frac": (2 * b_spmv + vec_bytes) * (args.steps / dt) / 1e9 / HBM_PEAK_GBS},
             "spmv_gbs": achieved, "spmv_form": "blocked two-phase" if blocked else "csr (lanes-per-row / stream tiles)",
+            # > 0: the matrix has that many distinct fp64 values (<= 256) and the SpMV reads 8-bit indices into a dictionary
+            # of them instead of the values (bit-identical products, 7 bytes per entry less traffic; csrc/valdict.hip).
+            # `roofline.achieved` stays ALGORITHMIC bytes (12 B per entry) over time; CUDAMAT_VALUE_DICT=0 switches it off
+            "value_dictionary": solver.value_dict(),
         }
         if comm is not None:
             # rank 0's exchanges inside the timed region (HIP events recorded by the C++ loop, cudamat_stats): the

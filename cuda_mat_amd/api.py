@@ -323,6 +323,12 @@ class Solver:
         check(_lib.lib().cudamat_solver_spmv_mode(self.h, C.byref(m)))
         return m.value
 
+    def value_dict(self):
+        """distinct values when the selected SpMV form reads 8-bit indices into a value dictionary, else 0"""
+        m = C.c_int()
+        check(_lib.lib().cudamat_solver_value_dict(self.h, C.byref(m)))
+        return m.value
+
     def solve(self, b, x, precond=PRECOND_NONE, loop=LOOP_PBICGSTAB, maxit=2000, tol=1e-8, flags=0):
         st = Stats()
         check(_lib.lib().cudamat_solver_solve(self.h, _ptr(b), _ptr(x), precond, loop, maxit, tol, flags,

@@ -34,6 +34,14 @@ struct SpmvPlan {
     short *c_off16 = nullptr;
     unsigned char *c_len8 = nullptr;
     int *c_tile_base = nullptr;
+    // the matrix's value dictionary (valdict.h; 256 doubles on the device, not owned) when the copies below exist
+    const double *c_dict = nullptr;
+    // dictionary form of the compressed stream kernel (plan_spmv_dict): per tile, the entries' 16-bit offsets and 8-bit
+    // value indices padded to a multiple of 8 entries, so that a thread fetches its 8 entries with one 16-byte and one
+    // 8-byte load (owned by the plan)
+    int *d_pbase = nullptr;             // ntiles + 1: first padded entry of every tile
+    short *d_off16 = nullptr;
+    unsigned char *d_val8 = nullptr;
 };
 SpmvPlan plan_spmv(int n_rows, int64_t nnz);
 void plan_spmv_free(SpmvPlan *plan);
@@ -96,6 +104,10 @@ bool fused_spmv_supported(const SpmvPlan &plan);
 int launch_fused_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, const FuseArgs &f);
 // stream plans only: build the compressed index copy when every offset fits (no-op otherwise); rp/ci 0-based
 int plan_spmv_compress(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const int *ci, SpmvPlan *plan);
+// compressed stream plans of a matrix with a value dictionary (valdict.h): vidx = 8-bit value index per entry in CSR
+// order, dict = 256 doubles on the device (not owned); no-op when the plan has no compressed copy
+int plan_spmv_dict(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const unsigned char *vidx, const double *dict,
+                   SpmvPlan *plan);
 
 int vec_grid(int64_t n);
 

@@ -486,6 +486,90 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream_c(SpmvArgs a, int tiles_
     }
 }
 
+// The same kernel for a matrix with a VALUE DICTIONARY (valdict.h; at most 256 distinct fp64 bit patterns): the plan
+// holds per-tile copies of the 16-bit offsets and of 8-bit value indices, each tile padded to a multiple of 8 entries
+// (plan_spmv_dict), so a thread fetches its 8 consecutive entries with one 16-byte and one 8-byte load -- 3 bytes per
+// entry instead of 10 -- and multiplies dict[index], the very same double, by x: bit-identical results.  (Requesting
+// the next tile's operands while this one is summed was tried: 0.159 ms against 0.118 ms for this plain loop.)
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_spmv_stream_d(SpmvArgs a, int tiles_per_block, const int *pbase,
+                                                          const short *off16p, const unsigned char *val8p,
+                                                          const unsigned char *len8, const double *dict)
+{
+    __shared__ double prod[kStreamNnz];
+    __shared__ int srp[R + 1];
+    __shared__ int scan_w[kBlock / 64];
+    __shared__ double lds[8];
+    __shared__ double dv[kBlock];                     // the dictionary, one entry per thread (kBlock == 256)
+    dv[threadIdx.x] = dict[threadIdx.x];              // (visible after the first __syncthreads below)
+    if (a.loop.st) {
+        if (a.check == CHECK_HALF) {
+            if (check_half(a.loop, a.half, lds)) return;
+        } else if (a.loop.st->state != 0) {
+            return;
+        }
+    }
+    const int tid = threadIdx.x;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const bool xcd_split = (nb & 7) == 0;
+    const int wg_per_set = xcd_split ? nb >> 3 : nb;
+    const int set = xcd_split ? (b & 7) : 0;
+    const int w = xcd_split ? (b >> 3) : b;
+    const long long set_tile0 = (long long)set * wg_per_set * tiles_per_block;
+    double acc[2] = {0.0, 0.0};
+    for (int t = 0; t < tiles_per_block; t++) {
+        const long long tile = set_tile0 + (long long)t * wg_per_set + w;
+        const long long r0l = tile * R;
+        if (r0l >= a.n) continue;
+        const int r0 = (int)r0l;
+        const int nr = a.n - r0 < R ? a.n - r0 : R;
+        const int base = pbase[tile], cnt = pbase[tile + 1] - base;    // a multiple of 8, at most kStreamNnz = 8 * kBlock
+        const int len = tid < nr ? (int)len8[r0 + tid] : 0;
+        const bool mine = 8 * tid < cnt;
+        double xv[8];
+        unsigned iw[2] = {0u, 0u};
+        if (mine) {
+            const uint2 iv = *(const uint2 *)(val8p + base + 8 * tid);
+            const uint4 ov = *(const uint4 *)(off16p + base + 8 * tid);
+            const unsigned ow[4] = {ov.x, ov.y, ov.z, ov.w};
+            iw[0] = iv.x; iw[1] = iv.y;
+#pragma unroll
+            for (int q = 0; q < 8; q++) xv[q] = a.x[r0 + (int)(short)((ow[q >> 1] >> (16 * (q & 1))) & 0xffffu)];
+        }
+        int total;
+        const int start = block_scan_int(len, scan_w, &total);
+        if (tid < nr) srp[tid] = start;
+        if (tid == 0) srp[nr] = total;
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) prod[8 * tid + q] = dv[(iw[q >> 2] >> (8 * (q & 3))) & 0xffu] * xv[q];
+        }
+        __syncthreads();
+        if (tid < nr) {
+            const int row = r0 + tid;
+            const int s = srp[tid], e = srp[tid + 1];
+            double sum = 0.0;
+            for (int j = s; j < e; j++) sum += prod[j];
+            if (a.d) sum += a.d[row] * a.xd[row];
+            double out = a.alpha * sum;
+            if (a.beta != 0.0) out += a.beta * a.y[row];
+            a.y[row] = out;
+            if (a.dot) {
+                acc[0] += out * a.w[row];
+                acc[1] += out * out;
+            }
+        }
+        __syncthreads();
+    }
+    if (a.dot) {
+        block_sum<2>(acc, lds);
+        if (tid == 0) {
+            a.parts[2 * b] = acc[0];
+            a.parts[2 * b + 1] = acc[1];
+        }
+    }
+}
+
 // one 8-lane team per row: 8-bit length, 16-bit offsets from the first row of the row's tile; flags[0] = does not fit
 __global__ __launch_bounds__(kBlock) void k_stream_compress(int n, int R, const int *rp, const int *ci, short *off16,
                                                             unsigned char *len8, int *tile_base, int *flags)
@@ -541,6 +625,81 @@ int plan_spmv_compress(hipStream_t s, int n_rows, int64_t nnz, const int *rp, co
         plan->c_len8 = nullptr;
         plan->c_tile_base = nullptr;
         if (rc == CUDAMAT_ERR_HIP) return fail_hip(hipGetLastError(), "index compression", __FILE__, __LINE__);
+    }
+    return CUDAMAT_OK;
+}
+
+// ---- padded per-tile copies for the dictionary form
+// one workgroup: exclusive scan of the tiles' entry counts rounded up to 8 -> pbase[0..ntiles]
+__global__ __launch_bounds__(kBlock) void k_tile_pad_scan(int n, int R, int ntiles, const int *rp, int *pbase)
+{
+    __shared__ int scan_w[kBlock / 64];
+    int run = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += kBlock) {
+        const int t = t0 + threadIdx.x;
+        int padded = 0;
+        if (t < ntiles) {
+            const long long r1 = (long long)(t + 1) * R;
+            const int cnt = rp[r1 < n ? r1 : n] - rp[(long long)t * R];
+            padded = (cnt + 7) & ~7;
+        }
+        int total;
+        const int ex = block_scan_int(padded, scan_w, &total);
+        if (t < ntiles) pbase[t] = run + ex;
+        run += total;
+    }
+    if (threadIdx.x == 0) pbase[ntiles] = run;
+}
+
+// an 8-lane team per row copies the row's offsets and value indices to their padded places
+__global__ __launch_bounds__(kBlock) void k_tile_pad_fill(int n, int R, const int *rp, const short *off16, const unsigned char *vidx,
+                                                          const int *pbase, short *off16p, unsigned char *val8p)
+{
+    constexpr int L = 8;
+    const long long row = ((long long)blockIdx.x * kBlock + threadIdx.x) / L;
+    if (row >= n) return;
+    const int lane = threadIdx.x & (L - 1);
+    const int t = (int)(row / R);
+    const int s = rp[row], e = rp[row + 1], first = rp[(long long)t * R];
+    const int dst = pbase[t] + (s - first);
+    for (int k = s + lane; k < e; k += L) {
+        off16p[dst + (k - s)] = off16[k - rp[0]];
+        val8p[dst + (k - s)] = vidx[k - rp[0]];
+    }
+}
+
+int plan_spmv_dict(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const unsigned char *vidx, const double *dict,
+                   SpmvPlan *plan)
+{
+    if (!plan->stream_rows || !plan->c_off16 || !vidx || !dict || nnz <= 0) return CUDAMAT_OK;
+    const int R = plan->stream_rows;
+    const int ntiles = (int)(((long long)n_rows + R - 1) / R);
+    int total = 0, rc = CUDAMAT_OK;
+    do {
+        if (hipMalloc((void **)&plan->d_pbase, sizeof(int) * ((size_t)ntiles + 1)) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
+        hipLaunchKernelGGL(k_tile_pad_scan, dim3(1), dim3(kBlock), 0, s, n_rows, R, ntiles, rp, plan->d_pbase);
+        if (hipMemcpyAsync(&total, plan->d_pbase + ntiles, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        if (total < nnz || (int64_t)total > nnz + 8LL * ntiles) { rc = CUDAMAT_ERR_HIP; break; }
+        if (hipMalloc((void **)&plan->d_off16, sizeof(short) * (size_t)total + 16) != hipSuccess ||
+            hipMalloc((void **)&plan->d_val8, (size_t)total + 16) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
+        hipMemsetAsync(plan->d_off16, 0, sizeof(short) * (size_t)total + 16, s);      // padding: offset 0, value index 0
+        hipMemsetAsync(plan->d_val8, 0, (size_t)total + 16, s);
+        const long long threads = (long long)n_rows * 8;
+        hipLaunchKernelGGL(k_tile_pad_fill, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, R, rp,
+                           plan->c_off16, vidx, plan->d_pbase, plan->d_off16, plan->d_val8);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        plan->c_dict = dict;
+    } while (0);
+    if (rc) {                                         // no memory / failure: the plain compressed kernel stays
+        void *ptrs[] = {plan->d_pbase, plan->d_off16, plan->d_val8};
+        for (void *q : ptrs)
+            if (q) hipFree(q);
+        plan->d_pbase = nullptr;
+        plan->d_off16 = nullptr;
+        plan->d_val8 = nullptr;
+        plan->c_dict = nullptr;
+        if (rc == CUDAMAT_ERR_HIP) return fail_hip(hipGetLastError(), "dictionary tiles", __FILE__, __LINE__);
     }
     return CUDAMAT_OK;
 }
@@ -768,7 +927,10 @@ __global__ __launch_bounds__(kBlock) void k_lane_cost(int n, const int *rp, int 
 void plan_spmv_free(SpmvPlan *plan)
 {
     void *ptrs[] = {plan->tile_S, plan->tile_span, plan->tile_heads, plan->tile_tails, plan->c_off16, plan->c_len8,
-                    plan->c_tile_base};
+                    plan->c_tile_base, plan->d_pbase, plan->d_off16, plan->d_val8};
+    plan->d_pbase = nullptr;
+    plan->d_off16 = nullptr;
+    plan->d_val8 = nullptr;
     for (void *q : ptrs)
         if (q) hipFree(q);
     plan->c_off16 = nullptr;
@@ -913,10 +1075,20 @@ int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a)
     }
     if (plan.stream_rows && plan.c_off16) {
         switch (plan.stream_rows) {
-        case 64:  hipLaunchKernelGGL(k_spmv_stream_c<64>, g, b, 0, s, a, plan.rows_per_block, plan.c_tile_base, plan.c_off16, plan.c_len8); break;
-        case 128: hipLaunchKernelGGL(k_spmv_stream_c<128>, g, b, 0, s, a, plan.rows_per_block, plan.c_tile_base, plan.c_off16, plan.c_len8); break;
-        default:  hipLaunchKernelGGL(k_spmv_stream_c<256>, g, b, 0, s, a, plan.rows_per_block, plan.c_tile_base, plan.c_off16, plan.c_len8); break;
+#define CM_SC(RV)                                                                                                          \
+    do {                                                                                                                   \
+        if (plan.d_pbase)                                                                                                  \
+            hipLaunchKernelGGL(k_spmv_stream_d<RV>, g, b, 0, s, a, plan.rows_per_block, plan.d_pbase, plan.d_off16, plan.d_val8, \
+                               plan.c_len8, plan.c_dict);                                                                 \
+        else                                                                                                               \
+            hipLaunchKernelGGL(k_spmv_stream_c<RV>, g, b, 0, s, a, plan.rows_per_block, plan.c_tile_base, plan.c_off16,   \
+                               plan.c_len8);                                                                               \
+    } while (0)
+        case 64:  CM_SC(64); break;
+        case 128: CM_SC(128); break;
+        default:  CM_SC(256); break;
         }
+#undef CM_SC
         CM_HIP(hipGetLastError());
         return CUDAMAT_OK;
     }

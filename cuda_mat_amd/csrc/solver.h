@@ -4,6 +4,7 @@
 
 #include "kernels.h"
 #include "spmv_pb.h"
+#include "valdict.h"
 #include "spmv_sell.h"
 
 namespace cm {
@@ -112,6 +113,8 @@ struct cudamat_solver {
     void *ilu_plans = nullptr;  // launch plans owned by ilu.hip
     double t_analysis = 0.0, t_factor = 0.0, t_analysis_l = 0.0, t_analysis_u = 0.0;
     int trsv_fallbacks = 0;     // solves redone level by level after a dependency-driven wait timed out
+    cm::ValDict vd;             // value dictionary of the matrix (n == 0: more than 256 distinct values, or not looked yet)
+    bool vd_tried = false;
     unsigned *bar = nullptr;    // grid barrier words of the single-launch loop (device)
     bool resident_off = false;  // a barrier wait ran into its bound once: keep to the three-launch loop
     int device_cus = 0;         // compute units of the device (0: not asked yet)

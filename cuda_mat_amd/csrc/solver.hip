@@ -127,6 +127,8 @@ static int validate_csr(cudamat_solver *s)
     return CUDAMAT_OK;
 }
 
+static int ensure_valdict(cudamat_solver *s);
+
 extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz,
                                      const int *rowptr, const int *colidx, const double *val,
                                      int base, cudamat_solver **out)
@@ -190,6 +192,18 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
         cudamat_solver_destroy(s);
         return rc3;
     }
+    if (s->plan.c_off16) {          // compressed stream kernel: 8-bit value indices too when the matrix has a dictionary
+        if (int rc4 = ensure_valdict(s)) {
+            cudamat_solver_destroy(s);
+            return rc4;
+        }
+        if (s->vd.n > 0) {
+            if (int rc5 = plan_spmv_dict(st, n_local, nnz, s->rp, s->vd.idx, s->vd.dict, &s->plan)) {
+                cudamat_solver_destroy(s);
+                return rc5;
+            }
+        }
+    }
     *out = s;
     return CUDAMAT_OK;
 }
@@ -216,6 +230,7 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     for (hipEvent_t e : s->comm_ev) hipEventDestroy(e);
     if (s->need_dev) hipFree(s->need_dev);
     if (s->bar) hipFree(s->bar);
+    valdict_free(&s->vd);
     for (int e = 0; e < 2; e++) {
         if (s->ev_red[e]) hipEventDestroy(s->ev_red[e]);
         if (s->ev_red_done[e]) hipEventDestroy(s->ev_red_done[e]);
@@ -402,6 +417,16 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
     return launch_spmv(s->ctx->stream, s->plan, a);
 }
 
+// the matrix's value dictionary (valdict.hip), looked for once: large systems only (small ones live in caches and the
+// small-system loops keep their values in registers)
+static int ensure_valdict(cudamat_solver *s)
+{
+    if (s->vd_tried) return CUDAMAT_OK;
+    s->vd_tried = true;
+    if (s->nnz < (1 << 20)) return CUDAMAT_OK;
+    return valdict_build(s->ctx->stream, s->nnz, s->val, &s->vd);
+}
+
 // number of per-workgroup partial sums an SpMV launch leaves in `parts`
 static int spmv_parts(const cudamat_solver *s)
 {
@@ -439,7 +464,8 @@ static int ensure_spmv_mode(cudamat_solver *s)
                 cols.rank = s->comm.rank;
                 cols.chunks = can_overlap ? s->overlap_chunks : 1;
             }
-            const int rc = pb_build(st, s->n, s->n_cols, s->nnz, s->rp, s->ci, s->val, &s->pb, &cols);
+            CM_TRY(ensure_valdict(s));
+            const int rc = pb_build(st, s->n, s->n_cols, s->nnz, s->rp, s->ci, s->val, &s->pb, &cols, &s->vd);
             if (rc != CUDAMAT_OK && force_pb) return rc;
             have[1] = rc == CUDAMAT_OK;          // e.g. out of memory for the blocked copy: keep the others
         }
@@ -642,6 +668,18 @@ extern "C" int cudamat_solver_spmv_mode(cudamat_solver *s, int *mode)
     CM_TRY(ensure_work(s));
     CM_TRY(ensure_spmv_mode(s));
     *mode = s->spmv_mode;
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_solver_value_dict(cudamat_solver *s, int *distinct)
+{
+    CM_ARG(s && distinct, "null pointer");
+    CM_HIP(hipSetDevice(s->ctx->device));
+    CM_TRY(ensure_work(s));
+    CM_TRY(ensure_spmv_mode(s));
+    *distinct = 0;
+    if (s->spmv_mode == 1 && s->pb.pvi) *distinct = s->pb.ndict;
+    else if (s->spmv_mode == 0 && s->plan.d_pbase) *distinct = s->vd.n;
     return CUDAMAT_OK;
 }
 

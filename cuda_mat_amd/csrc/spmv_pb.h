@@ -2,6 +2,7 @@
 // over a vector much larger than an XCD's 4 MiB L2 (internal API; see spmv_pb.hip).
 #pragma once
 #include "kernels.h"
+#include "valdict.h"
 
 namespace cm {
 
@@ -32,7 +33,10 @@ struct PbPlan {
     int LPS = 64;         // lanes per (sub-block, column block) segment in phase 2
     int NSUB = 0;         // NRB * NW
     // entries in (column block, row block, row, column) order
-    double *pv = nullptr;          // values
+    double *pv = nullptr;          // values (nullptr when the matrix has a value dictionary:)
+    unsigned char *pvi = nullptr;  // ... then one 8-bit index per entry into `dict` (valdict.h; not owned, <= 256 doubles)
+    const double *dict = nullptr;
+    int ndict = 0;
     unsigned short *pc = nullptr;  // column - first column of its block
     unsigned short *pr = nullptr;  // row - sub*SR
     double *P = nullptr;           // products val * x[col], same order (phase 1 -> phase 2)
@@ -49,8 +53,9 @@ struct PbPlan {
 // decide whether the matrix is a candidate (large x, scattered columns) -- cheap estimate
 bool pb_candidate(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci);
 // build the blocked copy from 0-based CSR on the device
+// vd (optional): the value dictionary of `val` (indices in the same CSR order) -- the copy then stores 1 byte per value
 int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
-             const double *val, PbPlan *out, const PbCols *cols = nullptr);
+             const double *val, PbPlan *out, const PbCols *cols = nullptr, const ValDict *vd = nullptr);
 void pb_free(PbPlan *p);
 // y = alpha*(A x + d.*xd) + beta*y with the same fused dot / prologue options as launch_spmv;
 // args.rp/ci/val are ignored (the plan holds the matrix)

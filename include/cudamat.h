@@ -263,6 +263,11 @@ int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *comm);
 /* which SpMV implementation the analysis chose for this matrix: 0 = one group of lanes per row on
  * the CSR arrays, 1 = blocked two-phase kernels (x / y tiles in LDS); decided at the first use.   */
 int cudamat_solver_spmv_mode(cudamat_solver *s, int *mode);
+/* Value dictionary: *distinct = number of distinct fp64 bit patterns among the matrix values when the SELECTED SpMV form
+ * reads 8-bit indices into a dictionary of them instead of the 8-byte values (large matrices with at most 256 distinct
+ * values; results are bit-identical, HBM traffic drops by 7 bytes per entry), 0 when it reads the values themselves.
+ * CUDAMAT_VALUE_DICT=0 in the environment disables the dictionary.                                                  */
+int cudamat_solver_value_dict(cudamat_solver *s, int *distinct);
 /* y_local = (A + diag(d)) x ; x is the LOCAL slice, gathered through comm if sharded  */
 int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, double *y_local);
 /* Solve.  b, x: device vectors of n_local doubles; x holds the initial guess on entry

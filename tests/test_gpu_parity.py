@@ -1332,3 +1332,49 @@ def test_single_launch_loop_timeout_redoes_the_solve(cm, ctx, oracle, golden_dir
     assert st.loop_fallbacks == 1 and st.loop_form == 1
     np.testing.assert_array_equal(dx3.download(), xref)
     s.close()
+
+
+def test_value_dictionary_is_bit_exact(cm, ctx, oracle, monkeypatch):
+    """matrices with at most 256 distinct values: the blocked kernels and the compressed stream kernel read 8-bit
+    indices into a dictionary of the distinct bit patterns (csrc/valdict.hip) -- same doubles, same order, so the
+    products are bit-identical to the run on the fp64 values and to the oracle; 257 distinct values: no dictionary"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(17)
+    n = 300_000
+    cases = []
+    # scattered columns, 12 per row, values from a small set with -0.0 and a denormal among them -> blocked kernels
+    nnz = n * 12
+    S = sp.csr_matrix((np.ones(nnz), (np.repeat(np.arange(n), 12), rng.integers(0, n, nnz))), shape=(n, n))
+    S.sum_duplicates(); S.sort_indices()
+    few = np.array([-2.0, -1.0, 1.0, 2.0, 0.5, -0.0, 5e-324, 1e300, np.pi])
+    cases.append(("pb", S, few))
+    # banded short rows -> compressed stream kernel
+    B = sp.diags([1.0, 1.0, 1.0, 1.0, 1.0], [-700, -1, 0, 1, 700], shape=(n, n), format="csr")
+    B.sort_indices()
+    cases.append(("csr", B, np.array([4.0, -1.0, -1.0000000000000002])))
+    cases.append(("pb", S, rng.standard_normal(257)))              # one value too many
+    for k, (mode, M, vals) in enumerate(cases):
+        data = vals[rng.integers(0, len(vals), M.nnz)]
+        data[:len(vals)] = vals                                    # every value occurs
+        A = oracle.Csr(n, (M.indptr + 1).astype(np.int32), (M.indices + 1).astype(np.int32), data, n)
+        x = rng.standard_normal(n)
+        want = oracle.spmv(A, x)
+        got = {}
+        for vd in ("1", "0"):
+            monkeypatch.setenv("CUDAMAT_VALUE_DICT", vd)
+            monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
+            s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+            dx, dy = ctx.array(x), ctx.empty(n)
+            s.spmv(dx, dy)
+            got[vd] = (dy.download(), s.value_dict(), s.spmv_mode())
+            for a in (dx, dy):
+                a.free()
+            s.close()
+        assert got["0"][1] == 0
+        assert got["1"][1] == (len(np.unique(vals.view(np.uint64))) if len(vals) <= 256 else 0), (k, got["1"][1])
+        assert got["1"][2] == (1 if mode == "pb" else 0)
+        np.testing.assert_array_equal(got["1"][0].view(np.uint64), got["0"][0].view(np.uint64))
+        if mode == "pb":
+            np.testing.assert_array_equal(got["1"][0], want)       # the blocked form is bit-exact against the oracle
+        else:
+            np.testing.assert_allclose(got["1"][0], want, rtol=1e-13, atol=1e-300)
