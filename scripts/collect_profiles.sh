@@ -15,4 +15,4 @@ run() { # name, bench args...
 run rand50 --steps 10 --warmup 2
 run poisson5 --workload poisson5 --steps 20 --warmup 2
 run ilu0 --precond ilu0 --steps 4 --warmup 1
-run mat10000 --workload mat10000 --steps 200 --warmup 20
+run mat10000 --workload mat10000 --steps 2000 --warmup 200

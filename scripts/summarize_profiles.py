@@ -1,9 +1,15 @@
 """turn gpurun_out/prof_<name> + pmcf_/pmcw_<name> (scripts/collect_profiles.sh) into profiles/<dir>/"""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: take the most recent match"""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+
 def main(tag):
     for name in ("rand50", "poisson5", "ilu0", "mat10000"):
-        src = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s" % name, "*", "*_kernel_stats.csv"))
+        src = newest(os.path.join(ROOT, "gpurun_out", "prof_%s" % name, "*", "*_kernel_stats.csv"))
         if not src:
             continue
         dst = os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
@@ -11,7 +17,7 @@ def main(tag):
         shutil.copy(src[0], os.path.join(dst, "kernel_stats.csv"))
         shutil.copy(os.path.join(ROOT, "gpurun_out", "prof_%s.json" % name), os.path.join(dst, "bench_line.json"))
         # real (non-frozen) launch durations from the kernel trace
-        tr = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s" % name, "*", "*_kernel_trace.csv"))[0]
+        tr = newest(os.path.join(ROOT, "gpurun_out", "prof_%s" % name, "*", "*_kernel_trace.csv"))[0]
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(tr)):
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -25,7 +31,7 @@ def main(tag):
         for k, v in dur.items():
             out[k] = {"launches": len(v), "avg_us": sum(v) / len(v) / 1e3, "min_us": min(v) / 1e3, "max_us": max(v) / 1e3}
         for pre, cn in (("pmcf", "FETCH_SIZE"), ("pmcw", "WRITE_SIZE")):
-            fs = glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (pre, name), "*", "*_counter_collection.csv"))
+            fs = newest(os.path.join(ROOT, "gpurun_out", "%s_%s" % (pre, name), "*", "*_counter_collection.csv"))
             if not fs:
                 continue
             acc = collections.defaultdict(list)
