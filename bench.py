@@ -419,8 +419,10 @@ def run_bench(args):
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_fetch_write.json")), reverse=True):
             pm = json.load(open(f))
-            want = ["cm::k_pb_phase1", "cm::k_pb_phase2"] if blocked else ["cm::k_spmv<"]
-            got = [next((v for k, v in pm.items() if k.startswith(w) and isinstance(v, dict)
+            # (kernel names as the trace prints them, without argument lists; phase 1 has a dictionary form)
+            p1 = "cm::k_pb_phase1_dict" if solver.value_dict() > 0 else "cm::k_pb_phase1"
+            want = [p1, "cm::k_pb_phase2<"] if blocked else ["cm::k_spmv<"]
+            got = [next((v for k, v in pm.items() if (k == w or (w.endswith("<") and k.startswith(w))) and isinstance(v, dict)
                          and "hbm_bytes_per_launch_corrected" in v), None) for w in want]
             if all(g is not None for g in got):
                 traffic = sum(g["hbm_bytes_per_launch_corrected"] for g in got)

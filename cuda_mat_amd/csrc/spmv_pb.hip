@@ -30,6 +30,7 @@ namespace cm {
 typedef unsigned short u16;
 constexpr int kPbBuildWaves = 4;
 constexpr int kP1Threads = 1024;
+constexpr int kP1Unroll = 8;          // steps of phase 1 whose loads are in flight together (k_pb_phase1_dict)
 constexpr int kTileMax = 13312;        // doubles per LDS tile (104 KB)
 
 static double now_s()
@@ -415,10 +416,20 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const
 }
 
 // phase 1 for a matrix with a value dictionary: 8-bit value indices (1 byte per entry instead of 8), the dictionary
-// beside the x tile in LDS.  Same entry-to-lane mapping as k_pb_phase1 (two entries per lane per step, four steps in
-// flight), so every store instruction of a wave still writes one contiguous kilobyte of products -- the launch is
-// bound by its 8 B/nnz of product WRITES (measured: 1.44 ms with 3 B/nnz of reads, 1.58 ms with 10).
-// Same products bit for bit: dict[idx] IS the stored value.
+// beside the x tile in LDS; same products bit for bit: dict[idx] IS the stored value.
+//
+// Shape of the streaming loop (round 2, from the ISA of its predecessor): on gfx9-family parts loads and stores share
+// ONE counter (vmcnt) and complete out of order with respect to each other, so the compiler waits for vmcnt(0) -- all of
+// a wave's earlier stores included -- before it uses any loaded value while stores are pending, and a loop whose steps
+// sit behind per-step bounds checks is compiled into load / wait / load / wait.  With one 1024-thread workgroup per
+// compute unit (the x tile fills the LDS) that left every wave with ~0.5 KB of loads and 4 KB of stores in flight per
+// memory round trip, and the launch bound by LATENCY (1.45-1.8 ms with 5.5 GB to move; stores removed: 0.6 ms).  So:
+// a branch-free body over whole chunks of U = 8 steps -- 2U loads issued back to back, ONE wait (which the previous
+// chunk's stores overlap), U product pairs, U 16-byte stores per lane -- and the bounds checks confined to the head and
+// the tail: 1.20-1.29 ms (U = 4 / 8 / 16 within 5 %), i.e. 5.5 GB at the 4.3-4.6 TB/s a write-heavy mix reaches.
+// (The same loop shape makes k_pb_phase1, which reads 10 B per entry, 10 % SLOWER -- 2.05 ms against 1.87 on one box
+// for U = 2, 4, 8 alike: bursts of reads followed by bursts of writes suit the memory system less than its
+// interleaved steps -- so that kernel keeps its loop.)
 __global__ __launch_bounds__(kP1Threads) void k_pb_phase1_dict(const double *x, const int *col0, const int *list,
                                                                const int *cstart, const unsigned char *pvi, const u16 *pc,
                                                                const double *dict, int cb_doubles, double *P,
@@ -434,33 +445,36 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1_dict(const double *x, 
     for (int i = threadIdx.x; i < cn; i += kP1Threads) xs[i] = x[c0 + i];
     if (threadIdx.x < kDictMax) dv[threadIdx.x] = dict[threadIdx.x];
     __syncthreads();
-    const int k0 = (s & ~1) + 2 * (int)threadIdx.x;
-    constexpr int STEP = 2 * kP1Threads;
-    for (int k = k0; k < e; k += 4 * STEP) {
-        u16 iv[4];
-        ushort2 c[4];
-        bool full[4];
+    constexpr int U = kP1Unroll, STEP = 2 * kP1Threads, CH = U * STEP;
+    const int a0 = (s + 1) & ~1;                           // pairs start at an even entry (16-byte aligned products)
+    if (threadIdx.x == 0 && s < a0) P[s] = dv[pvi[s]] * xs[pc[s]];
+    int k = a0 + 2 * (int)threadIdx.x;
+    for (int left = e > a0 ? (e - a0) / CH : 0; left > 0; left--, k += CH) {      // whole chunks: no bounds checks
+        u16 iv[U];
+        unsigned cv[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int kk = k + u * STEP;
-            full[u] = kk >= s && kk + 1 < e;
-            if (full[u]) {
-                iv[u] = *(const u16 *)(pvi + kk);
-                c[u] = *(const ushort2 *)(pc + kk);
-            }
+        for (int u = 0; u < U; u++) {
+            iv[u] = *(const u16 *)(pvi + k + u * STEP);
+            cv[u] = *(const unsigned *)(pc + k + u * STEP);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int kk = k + u * STEP;
-            if (full[u]) {
-                double2 o;
-                o.x = dv[iv[u] & 0xffu] * xs[c[u].x];
-                o.y = dv[iv[u] >> 8] * xs[c[u].y];
-                *(double2 *)(P + kk) = o;
-            } else {
-                if (kk >= s && kk < e) P[kk] = dv[pvi[kk]] * xs[pc[kk]];
-                if (kk + 1 >= s && kk + 1 < e) P[kk + 1] = dv[pvi[kk + 1]] * xs[pc[kk + 1]];
-            }
+        for (int u = 0; u < U; u++) {
+            double2 o;
+            o.x = dv[iv[u] & 0xffu] * xs[cv[u] & 0xffffu];
+            o.y = dv[iv[u] >> 8] * xs[cv[u] >> 16];
+            *(double2 *)(P + k + u * STEP) = o;
+        }
+    }
+    for (; k < e; k += STEP) {                             // less than one chunk is left: pair by pair
+        if (k + 1 < e) {
+            const u16 iv = *(const u16 *)(pvi + k);
+            const unsigned cv = *(const unsigned *)(pc + k);
+            double2 o;
+            o.x = dv[iv & 0xffu] * xs[cv & 0xffffu];
+            o.y = dv[iv >> 8] * xs[cv >> 16];
+            *(double2 *)(P + k) = o;
+        } else {
+            P[k] = dv[pvi[k]] * xs[pc[k]];
         }
     }
 }
@@ -608,7 +622,6 @@ int launch_pb_check(hipStream_t st, const SpmvArgs &a)
 
 int launch_pb_phase1(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int part)
 {
-    CM_TRY(set_max_lds((const void *)k_pb_phase1));
     // part < 0: every block in index order; otherwise the blocks of one launch part (PbPlan::order)
     const int first = part < 0 ? 0 : p.part_off[part], last = part < 0 ? p.NCB : p.part_off[part + 1];
     if (last <= first) return CUDAMAT_OK;
@@ -621,6 +634,7 @@ int launch_pb_phase1(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int par
         CM_HIP(hipGetLastError());
         return CUDAMAT_OK;
     }
+    CM_TRY(set_max_lds((const void *)k_pb_phase1));
     hipLaunchKernelGGL(k_pb_phase1, dim3(last - first), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x, p.col0,
                        part < 0 ? (const int *)nullptr : p.order + first, p.cstart, p.pv, p.pc, p.P, a.loop.st);
     CM_HIP(hipGetLastError());
