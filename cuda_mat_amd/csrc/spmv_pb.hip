@@ -448,8 +448,10 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1_dict(const double *x, 
     constexpr int U = kP1Unroll, STEP = 2 * kP1Threads, CH = U * STEP;
     const int a0 = (s + 1) & ~1;                           // pairs start at an even entry (16-byte aligned products)
     if (threadIdx.x == 0 && s < a0) P[s] = dv[pvi[s]] * xs[pc[s]];
-    int k = a0 + 2 * (int)threadIdx.x;
-    for (int left = e > a0 ? (e - a0) / CH : 0; left > 0; left--, k += CH) {      // whole chunks: no bounds checks
+    int kb = a0;                                           // (workgroup-uniform) first entry of the current chunk
+    const int t2 = 2 * (int)threadIdx.x;
+    for (; kb + CH <= e; kb += CH) {                       // whole chunks: no bounds checks
+        const int k = kb + t2;
         u16 iv[U];
         unsigned cv[U];
 #pragma unroll
@@ -465,16 +467,37 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1_dict(const double *x, 
             *(double2 *)(P + k + u * STEP) = o;
         }
     }
-    for (; k < e; k += STEP) {                             // less than one chunk is left: pair by pair
-        if (k + 1 < e) {
-            const u16 iv = *(const u16 *)(pvi + k);
-            const unsigned cv = *(const unsigned *)(pc + k);
+    {                                                      // the last, partial chunk: m whole steps (uniform) ...
+        const int m = e > kb ? (e - kb) / STEP : 0;
+        const int k = kb + t2;
+        u16 iv[U - 1];
+        unsigned cv[U - 1];
+#pragma unroll
+        for (int u = 0; u < U - 1; u++) {
+            if (u < m) {
+                iv[u] = *(const u16 *)(pvi + k + u * STEP);
+                cv[u] = *(const unsigned *)(pc + k + u * STEP);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U - 1; u++) {
+            if (u < m) {
+                double2 o;
+                o.x = dv[iv[u] & 0xffu] * xs[cv[u] & 0xffffu];
+                o.y = dv[iv[u] >> 8] * xs[cv[u] >> 16];
+                *(double2 *)(P + k + u * STEP) = o;
+            }
+        }
+        const int kr = k + m * STEP;                       // ... and less than one step, checked per lane
+        if (kr + 1 < e) {
+            const u16 iw = *(const u16 *)(pvi + kr);
+            const unsigned cw = *(const unsigned *)(pc + kr);
             double2 o;
-            o.x = dv[iv & 0xffu] * xs[cv & 0xffffu];
-            o.y = dv[iv >> 8] * xs[cv >> 16];
-            *(double2 *)(P + k) = o;
-        } else {
-            P[k] = dv[pvi[k]] * xs[pc[k]];
+            o.x = dv[iw & 0xffu] * xs[cw & 0xffffu];
+            o.y = dv[iw >> 8] * xs[cw >> 16];
+            *(double2 *)(P + kr) = o;
+        } else if (kr < e) {
+            P[kr] = dv[pvi[kr]] * xs[pc[kr]];
         }
     }
 }
