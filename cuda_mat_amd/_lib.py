@@ -34,7 +34,7 @@ class Stats(C.Structure):
                 ("n_gather", C.c_int), ("n_allreduce", C.c_int), ("ms_gather", C.c_double),
                 ("ms_gather_exposed", C.c_double), ("ms_allreduce", C.c_double), ("overlapped", C.c_int),
                 ("loop_form", C.c_int), ("gather_fraction", C.c_double), ("ms_spmv_alone", C.c_double),
-                ("loop_fallbacks", C.c_int), ("reserved_", C.c_int)]
+                ("loop_fallbacks", C.c_int), ("restarts", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

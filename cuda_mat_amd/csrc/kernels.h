@@ -115,7 +115,9 @@ int vec_grid(int64_t n);
 int launch_init(hipStream_t s, int64_t n, const double *b, double *r, double *rw, double *p,
                 double *parts, int *nparts);
 // one workgroup: set up LoopState from the initial reduction
-int launch_init_finish(hipStream_t s, LoopState *st, ScalarSrc init, double tol);
+// abs_tol > 0: the loop stops at this absolute residual norm (tol is ignored) and starts out 'converged' when the
+// initial residual is within twice of it
+int launch_init_finish(hipStream_t s, LoopState *st, ScalarSrc init, double tol, double abs_tol = 0.0);
 // p = r + beta (p - omega v), preceded by the full-step test of the previous iteration
 int launch_update_p(hipStream_t s, LoopArgs la, ScalarSrc full, int64_t n, const double *r,
                     double *p, const double *v);

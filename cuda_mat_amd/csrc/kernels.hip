@@ -1175,7 +1175,7 @@ int launch_init(hipStream_t s, int64_t n, const double *b, double *r, double *rw
     return CUDAMAT_OK;
 }
 
-__global__ __launch_bounds__(kBlock) void k_init_finish(LoopState *st, ScalarSrc init, double tol)
+__global__ __launch_bounds__(kBlock) void k_init_finish(LoopState *st, ScalarSrc init, double tol, double abs_tol)
 {
     __shared__ double lds[8];
     double sc[2];
@@ -1184,21 +1184,23 @@ __global__ __launch_bounds__(kBlock) void k_init_finish(LoopState *st, ScalarSrc
         const double nrm0 = sqrt(sc[1]);           // pbicgstab.cu:74 / :655
         // x0 already solves the system exactly (r0 = 0): the reference's loop would divide 0 by 0 and hand back NaNs;
         // here the loop starts frozen in the 'converged' state and x0 is returned untouched
-        st->state = nrm0 == 0.0 ? 2 : 0;
+        // abs_tol > 0 (a restart that verifies an iterate): stop at that ABSOLUTE residual, and if the residual of the
+        // initial guess is already within twice of it (a recursive residual drifts by about that much) there is nothing to do
+        st->state = (nrm0 == 0.0 || (abs_tol > 0.0 && nrm0 <= 2.0 * abs_tol)) ? 2 : 0;
         st->it = 0;
         st->rho[0] = 1.0;                          // pbicgstab.cu:617 (rho = 1)
         st->rho[1] = 1.0;
         st->alpha = 1.0;                           // :615
         st->omega = 1.0;                           // :614
         st->nrm0 = nrm0;
-        st->tolabs = tol * nrm0;
+        st->tolabs = abs_tol > 0.0 ? abs_tol : tol * nrm0;
         st->nrm = nrm0;
     }
 }
 
-int launch_init_finish(hipStream_t s, LoopState *st, ScalarSrc init, double tol)
+int launch_init_finish(hipStream_t s, LoopState *st, ScalarSrc init, double tol, double abs_tol)
 {
-    hipLaunchKernelGGL(k_init_finish, dim3(1), dim3(kBlock), 0, s, st, init, tol);
+    hipLaunchKernelGGL(k_init_finish, dim3(1), dim3(kBlock), 0, s, st, init, tol, abs_tol);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }

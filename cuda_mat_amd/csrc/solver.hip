@@ -730,7 +730,7 @@ extern "C" int cudamat_solver_precond_apply(cudamat_solver *s, const double *in,
 }
 
 static int solve_once(cudamat_solver *s, const double *b, double *x, int precond, int loop, int maxit, double tol,
-                      int flags, cudamat_stats *out, bool *precond_gave_up, bool *resident_gave_up)
+                      int flags, cudamat_stats *out, bool *precond_gave_up, bool *resident_gave_up, double abs_tol)
 {
     CM_ARG(s && b && x, "null pointer");
     CM_ARG(precond == CUDAMAT_PRECOND_NONE || precond == CUDAMAT_PRECOND_ILU0 || precond == CUDAMAT_PRECOND_BLOCK_ILU0,
@@ -756,17 +756,20 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     // with a larger maxit keeps the first 2^20 (the kernels check the capacity)
     const long long want_hist = (long long)(loop != CUDAMAT_LOOP_PBICGSTAB2 ? 2 : 1) * (maxit > 0 ? maxit : 1);
     const int need_hist = (int)(want_hist < (1LL << 20) ? want_hist : (1LL << 20));
-    if (need_hist > s->hist_cap) {
+    // a restart segment (abs_tol > 0) appends to the history of the segments before it (the kernels check the capacity)
+    const int hist_base = abs_tol > 0.0 ? (s->hist_count < s->hist_cap ? s->hist_count : s->hist_cap) : 0;
+    if (hist_base == 0 && need_hist > s->hist_cap) {
         if (s->hist) { CM_HIP(hipStreamSynchronize(st)); hipFree(s->hist); s->hist = nullptr; }
         CM_TRY(dev_alloc((void **)&s->hist, sizeof(double) * (size_t)need_hist));
         s->hist_cap = need_hist;
     }
-    CM_HIP(hipMemsetAsync(s->hist, 0xFF, sizeof(double) * (size_t)s->hist_cap, st));  // NaN fill
+    if (s->hist_cap > hist_base)
+        CM_HIP(hipMemsetAsync(s->hist + hist_base, 0xFF, sizeof(double) * (size_t)(s->hist_cap - hist_base), st));  // NaN fill
     s->last_loop = loop;
     const bool profile = (flags & CUDAMAT_FLAG_PROFILE) != 0;
     const bool sharded = s->sharded;
     const int n = s->n;
-    LoopArgs la{s->st, s->hist, s->hist_cap, loop, (flags & CUDAMAT_FLAG_NO_EXIT) ? 1 : 0, s->snap_dev, kRing, 0};
+    LoopArgs la{s->st, s->hist + hist_base, s->hist_cap - hist_base, loop, (flags & CUDAMAT_FLAG_NO_EXIT) ? 1 : 0, s->snap_dev, kRing, 0};
     for (int i = 0; i < kRing; i++) s->snap_host[i] = 0ULL;
     const LoopArgs la_none{nullptr, nullptr, 0, 0, 0};
     const ScalarSrc nosrc{nullptr, 0, 1};
@@ -789,7 +792,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
         CM_TRY(allreduce(s, s->red + 4, 2));
         full_src = ScalarSrc{s->red + 4, 0, 1};
     }
-    CM_TRY(launch_init_finish(st, s->st, full_src, tol));
+    CM_TRY(launch_init_finish(st, s->st, full_src, tol, abs_tol));
 
     // Pipelined BiCGStab (kernels.hip): extra vectors, w0 = A r0 (with rw.w0), t0 = A w0, and the seed
     // [rw.r0, rw.w0, 0, 0, r0.r0] of the first k_pipe_a.  A reduction phase = the per-workgroup partials of a
@@ -817,14 +820,15 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
                 if (!s->ev_red_done[e]) CM_HIP(hipEventCreateWithFlags(&s->ev_red_done[e], hipEventDisableTiming));
             }
         }
-        CM_TRY(spmv_local(s, s->r, s->pww, 1, s->rw, s->parts_rv, la_none, CHECK_NONE, nosrc));     // w0 = A r0, rw.w0
+        const LoopArgs la_freeze{s->st, nullptr, 0, loop, 0};      // (returns at once when the initial guess already passes: restarts)
+        CM_TRY(spmv_local(s, s->r, s->pww, 1, s->rw, s->parts_rv, la_freeze, CHECK_NONE, nosrc));     // w0 = A r0, rw.w0
         ScalarSrc rww{s->parts_rv, spmv_parts(s), 2};
         if (sharded) {
             CM_TRY(launch_reduce_parts(st, rww, 1, s->red + 0, 0));
             CM_TRY(allreduce(s, s->red + 0, 1));
             rww = ScalarSrc{s->red + 0, 0, 1};
         }
-        CM_TRY(spmv_local(s, s->pww, s->t, 0, nullptr, nullptr, la_none, CHECK_NONE, nosrc));       // t0 = A w0
+        CM_TRY(spmv_local(s, s->pww, s->t, 0, nullptr, nullptr, la_freeze, CHECK_NONE, nosrc));       // t0 = A w0
         CM_TRY(launch_pipe_seed(st, full_src, rww, s->red_pipe + 8));
         pipeB_src = ScalarSrc{s->red_pipe + 8, 0, 1};
     }
@@ -1103,7 +1107,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
         CM_HIP(hipMemcpyAsync(x, s->pxh, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
         CM_HIP(hipStreamSynchronize(st));
     }
-    s->hist_count = (loop != CUDAMAT_LOOP_PBICGSTAB2) ? 2 * fin.it + (fin.state == 1 ? 1 : 0) : fin.it;
+    s->hist_count = hist_base + ((loop != CUDAMAT_LOOP_PBICGSTAB2) ? 2 * fin.it + (fin.state == 1 ? 1 : 0) : fin.it);
     if (s->hist_count > s->hist_cap) s->hist_count = s->hist_cap;
 
     cudamat_stats stt;
@@ -1165,7 +1169,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             hipMemcpy(h.data(), s->hist, sizeof(double) * (size_t)s->hist_count, hipMemcpyDeviceToHost);
         if (loop != CUDAMAT_LOOP_PBICGSTAB2) {
             printf("gpu, init residual:norm %20.16f\n", fin.nrm0);            // :77
-            for (int i = 0; i < s->hist_count; i++) {
+            for (int i = hist_base; i < s->hist_count; i++) {                  // (a restart segment prints its own part)
                 if ((i & 1) == 0) printf("i = %d, residual norm (before precond) = %g\n", i / 2, h[i]);  // :114
                 else printf("i = %d, residual norm = %g\n", i / 2, h[i]);      // :145
             }
@@ -1182,8 +1186,8 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     return CUDAMAT_OK;
 }
 
-extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *x, int precond,
-                                    int loop, int maxit, double tol, int flags, cudamat_stats *out)
+static int solve_guarded(cudamat_solver *s, const double *b, double *x, int precond, int loop, int maxit, double tol,
+                         int flags, cudamat_stats *out, double abs_tol)
 {
     CM_ARG(s && b && x, "null pointer");
     // keep the caller's x0 while the dependency-driven preconditioner is in use: if one of its waits times
@@ -1197,7 +1201,7 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
         CM_HIP(hipMemcpyAsync(s->x0_save, x, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
     }
     bool gave_up = false, resident_gave_up = false;
-    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up));
+    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up, abs_tol));
     if (resident_gave_up) {
         // the grid barrier of the single-launch loop ran into its bound (its workgroups were not all resident: the GPU
         // is shared): from now on this solver uses the three-launch loop; the solve is redone from x0
@@ -1208,7 +1212,7 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
                             "one launch per phase\n");
         if (keep_x0)
             CM_HIP(hipMemcpyAsync(x, s->x0_save, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
-        CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up));
+        CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up, abs_tol));
     }
     if (!gave_up) return CUDAMAT_OK;
     if (!trsv_syncfree_active(s)) {
@@ -1222,11 +1226,41 @@ extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *
                         "kernel?); redoing the solve with one launch per level\n");
     if (keep_x0)
         CM_HIP(hipMemcpyAsync(x, s->x0_save, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
-    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up));
+    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up, abs_tol));
     if (gave_up) {
         set_error("triangular solve timed out twice");
         return CUDAMAT_ERR_HIP;
     }
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *x, int precond,
+                                    int loop, int maxit, double tol, int flags, cudamat_stats *out)
+{
+    cudamat_stats st0;
+    CM_TRY(solve_guarded(s, b, x, precond, loop, maxit, tol, flags, &st0, 0.0));
+    // The pipelined loop carries r, w = A r, s = A p, z = A s by recurrences; over a few hundred iterations their rounding
+    // errors can let the recursive residual pass the test while the true one is orders of magnitude away (seen: 5e-3
+    // against a tolerance of 1e-9).  So an iterate that this loop calls converged is VERIFIED: a restart from it computes
+    // the true residual b - A x (one SpMV); within twice the target it is accepted, otherwise the loop goes on from
+    // there towards the same absolute target -- at most three times, within the caller's maxit.
+    if (loop == CUDAMAT_LOOP_PIPELINED && st0.converged && !(flags & CUDAMAT_FLAG_NO_EXIT) && st0.nrm0 > 0.0) {
+        const double target = tol * st0.nrm0;
+        for (int r = 0; r < 3 && st0.converged && st0.iters < maxit; r++) {
+            cudamat_stats st2;
+            CM_TRY(solve_guarded(s, b, x, precond, loop, maxit - st0.iters, tol, flags & ~CUDAMAT_FLAG_X0_ONES, &st2, target));
+            st0.t_solve += st2.t_solve;
+            st0.t_total += st2.t_total;
+            st0.nrm = st2.nrm;                       // the true residual of the verified iterate (st2.nrm0) or the loop's last
+            if (st2.iters == 0 && st2.converged) break;
+            st0.restarts++;
+            st0.iters += st2.iters;
+            st0.converged = st2.converged;
+            st0.half_exit = st2.half_exit;
+            st0.breakdown = st2.breakdown;
+        }
+    }
+    if (out) *out = st0;
     return CUDAMAT_OK;
 }
 

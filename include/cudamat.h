@@ -120,7 +120,8 @@ typedef struct cudamat_stats {
                             * loop took beyond this                                                            */
     int loop_fallbacks;    /* solves of this solver that were discarded and redone with the three-launch loop because a
                             * grid barrier of the single-launch loop ran into its bound (GPU shared; 0 in a healthy run) */
-    int reserved_;
+    int restarts;          /* pipelined loop only: how often an iterate it called converged failed the check of its TRUE
+                            * residual (one SpMV) and the loop was restarted from it (0 in most solves, at most 3)       */
 } cudamat_stats;
 
 /* Collectives for a row-sharded solve.  Either supplied by the host program (e.g.
@@ -275,7 +276,9 @@ int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, double *y_loca
 int cudamat_solver_solve(cudamat_solver *s, const double *b, double *x, int precond,
                          int loop, int maxit, double tol, int flags, cudamat_stats *st);
 /* residual-norm history of the last solve: LOOP_PBICGSTAB: hist[2i], hist[2i+1] =
- * norm after the half / full step of iteration i; LOOP_PBICGSTAB2: hist[i].
+ * norm after the half / full step of iteration i; LOOP_PBICGSTAB2: hist[i].  (LOOP_PIPELINED
+ * as LOOP_PBICGSTAB; when that loop was restarted after the check of its true residual --
+ * cudamat_stats.restarts -- the segments follow one another.)
  * Copies min(cap, available) doubles to the HOST buffer, returns the count in *count. */
 int cudamat_solver_history(cudamat_solver *s, double *hist_host, int cap, int *count);
 

@@ -202,14 +202,34 @@ def pbicgstab(A, f, x0=None, vm=None, maxit=2000, tol=1e-6, want_hist=False):
     return (x, st, hist) if want_hist else (x, st)
 
 
-def pipelined_bicgstab(A, f, x0=None, maxit=2000, tol=1e-6, want_hist=False):
-    """pipelined BiCGStab (Cools & Vanroose 2017, Alg. 4), stopping rules of pbicgstab.cu:116,147; x0 defaults to ones"""
+def pipelined_bicgstab(A, f, x0=None, maxit=2000, tol=1e-6, want_hist=False, verify=True):
+    """pipelined BiCGStab (Cools & Vanroose 2017, Alg. 4), stopping rules of pbicgstab.cu:116,147; x0 defaults to ones.
+    verify (the product's rule, csrc/solver.hip cudamat_solver_solve): an iterate the loop calls converged is checked
+    against its TRUE residual; beyond twice the target the loop is restarted from it towards the same absolute target,
+    at most three times within maxit.  st.iters is the total; the history is that of the first segment."""
     x = np.ones(A.n) if x0 is None else _f(x0).copy()
     st = Stats()
     hist = np.full(2 * maxit, np.nan) if want_hist else None
-    lib().orc_pipelined_bicgstab(A.n, A.rowptr, A.colidx, A.val, _f(f), x, maxit, tol,
+    fb = _f(f)
+    lib().orc_pipelined_bicgstab(A.n, A.rowptr, A.colidx, A.val, fb, x, maxit, tol,
                                  None if hist is None else hist.ctypes.data_as(C.c_void_p),
                                  0 if hist is None else len(hist), C.byref(st))
+    st.restarts = 0
+    if verify and st.converged and st.nrm0 > 0.0:
+        target = tol * st.nrm0
+        for _ in range(3):
+            if not st.converged or st.iters >= maxit:
+                break
+            true = float(np.linalg.norm(fb - spmv(A, x)))
+            if true <= 2.0 * target:
+                st.nrm = true
+                break
+            st2 = Stats()
+            lib().orc_pipelined_bicgstab(A.n, A.rowptr, A.colidx, A.val, fb, x, maxit - st.iters, target / true, None, 0,
+                                         C.byref(st2))
+            st.restarts += 1
+            st.iters += st2.iters
+            st.converged, st.half_exit, st.nrm = st2.converged, st2.half_exit, st2.nrm
     return (x, st, hist) if want_hist else (x, st)
 
 
