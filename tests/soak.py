@@ -29,9 +29,12 @@ for case in range(ncase):
         vals = rng.choice(np.array([-1.0, -0.5, 0.25, 2.0]), nnz_t)      # ... of bit patterns): the value-dictionary forms
     S = sp.csr_matrix((vals, (ri, cj)), shape=(n, n)); S.sum_duplicates()
     S.setdiag(0); S.eliminate_zeros()
-    dshift = np.full(n, 1.5) if case % 4 == 1 else 1.0 + rng.random(n)
-    S = (S + sp.diags(dshift + np.asarray(abs(S).sum(axis=1)).ravel())).tocsr(); S.sort_indices()
-    # (seed 21 case 41 of this generator is the drifting system of test_pipelined_loop_verifies_its_iterate: keep the draws)
+    rowsum = np.asarray(abs(S).sum(axis=1)).ravel()
+    # few-valued cases: a diagonal from a small set as well (multiples of 8 above the row sum), so that the matrix keeps
+    # <= 256 distinct values and the value-dictionary kernels run.  (test_pipelined_loop_verifies_its_iterate replays this
+    # generator's DRAWS for seed 21 case 41 with its own diagonal rule: keep the order of the rng calls.)
+    diag = 8.0 * np.ceil((rowsum + 1.5) / 8.0) if case % 4 == 1 else 1.0 + rng.random(n) + rowsum
+    S = (S + sp.diags(diag)).tocsr(); S.sort_indices()
     base = int(rng.integers(0, 2))
     A = O.Csr(n, (S.indptr + base).astype(np.int32), (S.indices + base).astype(np.int32), S.data.copy(), n)
     x = rng.standard_normal(n); want = O.spmv(A, x)
