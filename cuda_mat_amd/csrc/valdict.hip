@@ -46,15 +46,17 @@ __global__ __launch_bounds__(kBlock) void k_dict_probe(int64_t first, int64_t co
             since_check = 0;
             if (__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         }
-        if (bits == kEmpty) { flags[1] = 1; return; }
+        if (bits == kEmpty) { __hip_atomic_store(&flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
         unsigned h = slot_of(bits);
         for (int probe = 0; probe < kTableSlots; probe++) {
+            // plain (cached) load on purpose: a slot only ever goes EMPTY -> key, so a stale EMPTY merely sends this
+            // thread into the compare-and-swap below, which returns the key that is really there
             unsigned long long key = table[h];
             if (key == bits) break;
             if (key == kEmpty) {
                 key = atomicCAS(&table[h], kEmpty, bits);
                 if (key == kEmpty) {                                   // a new distinct value
-                    if (atomicAdd(&flags[0], 1) + 1 > kDictMax) flags[1] = 1;
+                    if (atomicAdd(&flags[0], 1) + 1 > kDictMax) __hip_atomic_store(&flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
                 if (key == bits) break;
