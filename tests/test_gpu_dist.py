@@ -339,6 +339,31 @@ def test_bench_two_processes_share_the_gpu_over_gloo():
     assert outs["torch:1"]["config"]["converges_in_iters"] == outs["torch:0"]["config"]["converges_in_iters"]
 
 
+def test_bench_plain_command_launches_its_ranks_and_survives_a_hanging_form():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver produced BENCH): bench.py starts the ranks itself
+    as child processes, prints one line with n_gpus = 2 -- and when the first exchange form never completes (forced: the
+    workers sleep in front of its gate) the supervisors end that set of workers at the time limit and the second form is
+    timed by fresh processes.  Two ranks on this box's one GPU, gloo exchanges (RCCL refuses two ranks per device)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CUDAMAT_BENCH_ONE_DEVICE="1", CUDAMAT_BENCH_BACKEND="gloo", CUDAMAT_SPMV_MODE="pb",
+               CUDAMAT_BENCH_TEST_HANG="torch:1", CUDAMAT_BENCH_FORM_TIMEOUT="90")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CUDAMAT_BENCH_FORMS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "600000", "--steps", "6",
+                        "--warmup", "1", "--cpu-baseline", "off"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    log = out["comm"]["launcher"]
+    assert [e["form"] for e in log] == ["torch:1", "torch:0"] and [e["ok"] for e in log] == [False, True]
+    assert "time limit" in log[0]["ranks"]
+    assert out["comm"]["form"]["gather"] == "plain all-gather" and out["comm"]["gate"][-1]["failed_ranks"] == 0
+
+
 def _block_jacobi_vm(oracle, A, world):
     """ILU(0) of every rank's diagonal block, written on A's pattern with zeros outside the blocks: with these
     values the oracle's triangular solves over A's pattern ARE the block-Jacobi preconditioner"""
