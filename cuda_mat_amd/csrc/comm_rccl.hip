@@ -21,7 +21,10 @@
 #include <rccl/rccl.h>          // types and enums only: every entry point is resolved with dlsym
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <mutex>
+#include <thread>
 
 #include "common.h"
 
@@ -32,6 +35,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -64,6 +68,7 @@ static int load_rccl()
     CM_SYM(GetUniqueId, "ncclGetUniqueId")
     CM_SYM(CommInitRank, "ncclCommInitRank")
     CM_SYM(CommDestroy, "ncclCommDestroy")
+    CM_SYM(CommAbort, "ncclCommAbort")
     CM_SYM(AllGather, "ncclAllGather")
     CM_SYM(AllReduce, "ncclAllReduce")
     CM_SYM(Send, "ncclSend")
@@ -93,11 +98,25 @@ struct RcclComm {
     hipStream_t main = nullptr;      // the context's stream (not owned)
     hipStream_t side = nullptr;      // owned
     hipStream_t rstream = nullptr;   // owned
+    std::mutex mu;                   // abort may come from another thread than the rank's (sharded.cpp)
+    std::atomic<bool> aborted{false};
 };
+
+// a group that met an error must still be closed: an open group would swallow every later call of this thread
+#define CM_NCCL_IN_GROUP(expr)                                                              \
+    do {                                                                                    \
+        ncclResult_t r__ = (expr);                                                          \
+        if (r__ != ncclSuccess) {                                                           \
+            g_api.GroupEnd();                                                               \
+            set_error("RCCL error %d (%s): %s", (int)r__, g_api.GetErrorString(r__), #expr); \
+            return CUDAMAT_ERR_COMM;                                                        \
+        }                                                                                   \
+    } while (0)
 
 static int rccl_allgather(void *user, const double *send, double *recv, int64_t count)
 {
     RcclComm *c = (RcclComm *)user;
+    if (c->aborted) { set_error("the communicator was aborted"); return CUDAMAT_ERR_COMM; }
     CM_NCCL(g_api.AllGather(send, recv, (size_t)count, ncclDouble, c->coll, c->main));
     return 0;
 }
@@ -105,6 +124,7 @@ static int rccl_allgather(void *user, const double *send, double *recv, int64_t 
 static int rccl_allreduce(void *user, double *buf, int count)
 {
     RcclComm *c = (RcclComm *)user;
+    if (c->aborted) { set_error("the communicator was aborted"); return CUDAMAT_ERR_COMM; }
     CM_NCCL(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->coll, c->main));
     return 0;
 }
@@ -112,6 +132,7 @@ static int rccl_allreduce(void *user, double *buf, int count)
 static int rccl_allreduce_side(void *user, double *buf, int count)
 {
     RcclComm *c = (RcclComm *)user;
+    if (c->aborted) { set_error("the communicator was aborted"); return CUDAMAT_ERR_COMM; }
     CM_NCCL(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->red, c->rstream));
     return 0;
 }
@@ -120,13 +141,14 @@ static int rccl_allreduce_side(void *user, double *buf, int count)
 static int rccl_gather_part(void *user, const double *send, double *recv, int64_t stride, int64_t offset, int64_t count)
 {
     RcclComm *c = (RcclComm *)user;
+    if (c->aborted) { set_error("the communicator was aborted"); return CUDAMAT_ERR_COMM; }
     if (c->world <= 1 || count <= 0) return 0;
     CM_NCCL(g_api.GroupStart());
     for (int d = 1; d < c->world; d++) {
         // peer order rotated by rank: at every position of the group the world's sends hit distinct receivers
         const int to = (c->rank + d) % c->world, from = (c->rank - d + c->world) % c->world;
-        CM_NCCL(g_api.Send(send + offset, (size_t)count, ncclDouble, to, c->p2p, c->side));
-        CM_NCCL(g_api.Recv(recv + (size_t)from * (size_t)stride + (size_t)offset, (size_t)count, ncclDouble, from, c->p2p, c->side));
+        CM_NCCL_IN_GROUP(g_api.Send(send + offset, (size_t)count, ncclDouble, to, c->p2p, c->side));
+        CM_NCCL_IN_GROUP(g_api.Recv(recv + (size_t)from * (size_t)stride + (size_t)offset, (size_t)count, ncclDouble, from, c->p2p, c->side));
     }
     CM_NCCL(g_api.GroupEnd());
     return 0;
@@ -137,15 +159,16 @@ static int rccl_gather_window(void *user, const double *send, double *recv, int6
                               const int64_t *send_cnt, const int64_t *recv_off, const int64_t *recv_cnt)
 {
     RcclComm *c = (RcclComm *)user;
+    if (c->aborted) { set_error("the communicator was aborted"); return CUDAMAT_ERR_COMM; }
     if (c->world <= 1) return 0;
     CM_NCCL(g_api.GroupStart());
     for (int d = 1; d < c->world; d++) {
         const int to = (c->rank + d) % c->world, from = (c->rank - d + c->world) % c->world;
         if (send_cnt[to] > 0)
-            CM_NCCL(g_api.Send(send + send_off[to], (size_t)send_cnt[to], ncclDouble, to, c->coll, c->main));
+            CM_NCCL_IN_GROUP(g_api.Send(send + send_off[to], (size_t)send_cnt[to], ncclDouble, to, c->coll, c->main));
         if (recv_cnt[from] > 0)
-            CM_NCCL(g_api.Recv(recv + (size_t)from * (size_t)stride + (size_t)recv_off[from], (size_t)recv_cnt[from], ncclDouble,
-                               from, c->coll, c->main));
+            CM_NCCL_IN_GROUP(g_api.Recv(recv + (size_t)from * (size_t)stride + (size_t)recv_off[from], (size_t)recv_cnt[from], ncclDouble,
+                                        from, c->coll, c->main));
     }
     CM_NCCL(g_api.GroupEnd());
     return 0;
@@ -224,15 +247,51 @@ extern "C" int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int ra
     return CUDAMAT_OK;
 }
 
+// wait for a stream for at most `seconds` (after an abort its kernels are told to leave; a wedged device must not
+// turn a reported failure into a hang)
+static bool bounded_sync(hipStream_t st, double seconds)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(st) == hipErrorNotReady) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    return true;
+}
+
+// Abort: tear the three communicators down WITHOUT waiting for their streams -- collectives already enqueued (here or,
+// once every rank of the job has aborted, on the peers) stop waiting for this rank and return.  For a rank that
+// failed while its peers sit inside a collective (csrc/sharded.cpp); callable from any thread; idempotent.
+extern "C" int cudamat_rccl_comm_abort(cudamat_comm *comm)
+{
+    if (!comm || !comm->user) return CUDAMAT_OK;
+    CM_ARG(comm->allgather == rccl_allgather, "not a communicator made by cudamat_rccl_comm_create");
+    RcclComm *c = (RcclComm *)comm->user;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->aborted) return CUDAMAT_OK;
+    c->aborted = true;
+    hipSetDevice(c->device);
+    ncclComm_t *all[] = {&c->coll, &c->p2p, &c->red};
+    for (ncclComm_t *q : all)
+        if (*q) { g_api.CommAbort(*q); *q = nullptr; }
+    return CUDAMAT_OK;
+}
+
 extern "C" int cudamat_rccl_comm_destroy(cudamat_comm *comm)
 {
     if (!comm || !comm->user) return CUDAMAT_OK;
     CM_ARG(comm->allgather == rccl_allgather, "not a communicator made by cudamat_rccl_comm_create");
     RcclComm *c = (RcclComm *)comm->user;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->main);
-    hipStreamSynchronize(c->side);
-    hipStreamSynchronize(c->rstream);
+    if (c->aborted) {               // (the communicators are gone; their kernels were told to leave)
+        bounded_sync(c->main, 5.0);
+        bounded_sync(c->side, 5.0);
+        bounded_sync(c->rstream, 5.0);
+    } else {
+        hipStreamSynchronize(c->main);
+        hipStreamSynchronize(c->side);
+        hipStreamSynchronize(c->rstream);
+    }
     if (c->coll) g_api.CommDestroy(c->coll);
     if (c->p2p) g_api.CommDestroy(c->p2p);
     if (c->red) g_api.CommDestroy(c->red);

@@ -10,13 +10,14 @@
 // CUDAMAT_SHARDED_ONE_DEVICE=1 (debugging aid for machines with fewer GPUs than ranks): every rank uses
 // device 0 and the collectives are host-synchronised device copies between the ranks' buffers (RCCL refuses
 // two ranks on one device).  Same loop, same kernels, same results; no overlap, no speed.
-#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -29,16 +30,60 @@ double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// A barrier a failed rank can BREAK: every thread waiting in it, or arriving later, returns false.  (With a
+// pthread barrier a rank thread that left after an error would leave its peers waiting for ever.)
+struct Barrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 1, count = 0;
+    unsigned gen = 0;
+    bool broken = false;
+    bool wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (broken) return false;
+        const unsigned g = gen;
+        if (++count == n) {
+            count = 0;
+            gen++;
+            cv.notify_all();
+            return true;
+        }
+        cv.wait(lk, [&] { return gen != g || broken; });
+        return gen != g;
+    }
+    void break_all()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        broken = true;
+        cv.notify_all();
+    }
+};
+
 struct Shared {
     int world = 1;
-    pthread_barrier_t bar;
+    Barrier bar;
     std::atomic<int> failed{0};
     char id[CUDAMAT_RCCL_ID_BYTES];
+    // the ranks' RCCL communicators, so that a rank that fails in the solve can abort EVERY rank's (its peers may be
+    // inside a collective that waits for it)
+    std::mutex comms_mu;
+    std::vector<cudamat_comm *> comms;
     // one-device emulation
     bool emulate = false;
     std::vector<const double *> send;
     std::vector<std::vector<double>> vals;
 };
+
+// a rank's solve failed: nobody may be left waiting for it
+void fail_everyone(Shared *sh)
+{
+    sh->failed.store(1);
+    sh->bar.break_all();
+    std::lock_guard<std::mutex> lk(sh->comms_mu);
+    for (cudamat_comm *c : sh->comms)
+        if (c) cudamat_rccl_comm_abort(c);
+}
 
 struct EmuComm {                 // `user` of the emulated collectives
     Shared *sh;
@@ -51,11 +96,11 @@ int emu_allgather(void *user, const double *send, double *recv, int64_t count)
     EmuComm *c = (EmuComm *)user;
     if (cudamat_ctx_sync(c->ctx)) return 1;                       // my producer kernels are done
     c->sh->send[(size_t)c->rank] = send;
-    pthread_barrier_wait(&c->sh->bar);
+    if (!c->sh->bar.wait()) return 1;
     for (int r = 0; r < c->sh->world; r++)
         if (cudamat_d2d(c->ctx, recv + (size_t)count * (size_t)r, c->sh->send[(size_t)r], sizeof(double) * (size_t)count)) return 1;
     if (cudamat_ctx_sync(c->ctx)) return 1;
-    pthread_barrier_wait(&c->sh->bar);                            // nobody overwrites a send buffer early
+    if (!c->sh->bar.wait()) return 1;                             // nobody overwrites a send buffer early
     return 0;
 }
 
@@ -65,11 +110,11 @@ int emu_allreduce(void *user, double *buf, int count)
     std::vector<double> &mine = c->sh->vals[(size_t)c->rank];
     mine.assign((size_t)count, 0.0);
     if (cudamat_d2h(c->ctx, mine.data(), buf, sizeof(double) * (size_t)count)) return 1;
-    pthread_barrier_wait(&c->sh->bar);
+    if (!c->sh->bar.wait()) return 1;
     std::vector<double> tot((size_t)count, 0.0);
     for (int r = 0; r < c->sh->world; r++)                        // fixed order: identical on every rank
         for (int k = 0; k < count; k++) tot[(size_t)k] += c->sh->vals[(size_t)r][(size_t)k];
-    pthread_barrier_wait(&c->sh->bar);
+    if (!c->sh->bar.wait()) return 1;
     return cudamat_h2d(c->ctx, buf, tot.data(), sizeof(double) * (size_t)count) ? 1 : 0;
 }
 
@@ -100,9 +145,9 @@ bool all_ok(Job *j, int rc)
         }
         j->sh->failed.store(1);
     }
-    pthread_barrier_wait(&j->sh->bar);
-    const bool ok = j->sh->failed.load() == 0;
-    pthread_barrier_wait(&j->sh->bar);
+    bool ok = j->sh->bar.wait();
+    ok = ok && j->sh->failed.load() == 0;
+    ok = j->sh->bar.wait() && ok;
     if (!ok && j->rc == CUDAMAT_OK) {
         j->rc = CUDAMAT_ERR_COMM;
         snprintf(j->err, sizeof(j->err), "another rank of the sharded solve failed");
@@ -171,6 +216,10 @@ void rank_main(Job *j)
             if (!all_ok(j, rc)) break;                           // (also publishes the id to the other threads)
             rc = cudamat_rccl_comm_create(ctx, sh->id, rank, world, &comm);
             native = rc == CUDAMAT_OK;
+            if (native) {
+                std::lock_guard<std::mutex> lk(sh->comms_mu);
+                sh->comms[(size_t)rank] = &comm;
+            }
         }
         if (!all_ok(j, rc)) break;
         rc = cudamat_solver_set_comm(s, &comm);
@@ -179,11 +228,22 @@ void rank_main(Job *j)
         const int flags = (j->debug && rank == 0 ? CUDAMAT_FLAG_DEBUG : 0) | (j->x0 ? 0 : CUDAMAT_FLAG_X0_ONES);
         rc = cudamat_solver_solve(s, d_b, d_x, j->precond, j->loop, j->maxit, j->tol, flags, &j->st);
         if (rc == CUDAMAT_OK && nloc > 0) rc = cudamat_d2h(ctx, j->x + row0, d_x, sizeof(double) * (size_t)nloc);
-        if (rc != CUDAMAT_OK && j->rc == CUDAMAT_OK) {
-            j->rc = rc;
-            snprintf(j->err, sizeof(j->err), "%s", cudamat_last_error());
+        if (rc != CUDAMAT_OK) {
+            // No barrier follows a failed solve, and the peers may be inside a collective that waits for this rank
+            // (or, having timed out on it, about to synchronise streams that hold one): break the emulated
+            // barriers and abort EVERY rank's communicators before anything here waits for a stream.
+            if (j->rc == CUDAMAT_OK) {
+                j->rc = rc;
+                snprintf(j->err, sizeof(j->err), "%s", cudamat_last_error());
+            }
+            fail_everyone(sh);
         }
     } while (0);
+    if (native) {                        // (from here on nobody aborts through a pointer into this frame)
+        std::lock_guard<std::mutex> lk(sh->comms_mu);
+        sh->comms[(size_t)rank] = nullptr;
+    }
+    if (sh->failed.load() && native) cudamat_rccl_comm_abort(&comm);
     if (s) cudamat_solver_destroy(s);
     if (native) cudamat_rccl_comm_destroy(&comm);
     void *ptrs[] = {d_rp, d_ci, d_val, d_b, d_x, d_d};
@@ -219,7 +279,8 @@ extern "C" int cudamat_solve_sharded(int ngpu, int n, int nnz, const double *A, 
     }
     sh.send.assign((size_t)ngpu, nullptr);
     sh.vals.assign((size_t)ngpu, std::vector<double>());
-    pthread_barrier_init(&sh.bar, nullptr, (unsigned)ngpu);
+    sh.comms.assign((size_t)ngpu, nullptr);
+    sh.bar.n = ngpu;
     std::vector<Job> jobs((size_t)ngpu);
     std::vector<std::thread> th;
     for (int r = 0; r < ngpu; r++) {
@@ -229,7 +290,6 @@ extern "C" int cudamat_solve_sharded(int ngpu, int n, int nnz, const double *A, 
         th.emplace_back(rank_main, &j);
     }
     for (std::thread &t : th) t.join();
-    pthread_barrier_destroy(&sh.bar);
     int rc = CUDAMAT_OK;
     for (Job &j : jobs)
         if (j.rc != CUDAMAT_OK && rc == CUDAMAT_OK) {

@@ -116,6 +116,7 @@ struct cudamat_solver {
     cm::ValDict vd;             // value dictionary of the matrix (n == 0: more than 256 distinct values, or not looked yet)
     bool vd_tried = false;
     unsigned *bar = nullptr;    // grid barrier words of the single-launch loop (device)
+    int test_allreduces = 0;    // fault injection (CUDAMAT_TEST_COMM_FAIL)
     bool resident_off = false;  // a barrier wait ran into its bound once: keep to the three-launch loop
     int device_cus = 0;         // compute units of the device (0: not asked yet)
     int loop_fallbacks = 0;     // solves redone with the three-launch loop for that reason

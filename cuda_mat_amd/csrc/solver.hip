@@ -288,6 +288,8 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     s->comm = *comm;
     s->sharded = true;
     s->n_pad = (int)per;
+    if (comm->gather_window && comm->world > 1 && comm->world <= 4096)      // compute_windows' exchange buffer: allocated
+        CM_TRY(dev_alloc((void **)&s->need_dev, sizeof(double) * ((size_t)2 * comm->world + (size_t)2 * comm->world * comm->world)));  // here, where a failure is still rank-local
     if (comm->gather_part && comm->comm_stream && !s->ev_x) {
         CM_HIP(hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming));
         for (int c = 0; c < kPbMaxChunks; c++) {
@@ -532,6 +534,15 @@ static int ensure_spmv_mode(cudamat_solver *s)
 
 static int allreduce(cudamat_solver *s, double *buf, int count)
 {
+    // fault injection for the tests of the failure paths: CUDAMAT_TEST_COMM_FAIL="rank:k" makes the k-th all-reduce
+    // of that rank's solver report an error (tests/test_gpu_dist.py: a failing rank must not strand its peers)
+    if (const char *inj = getenv("CUDAMAT_TEST_COMM_FAIL")) {
+        int r = -1, k = -1;
+        if (sscanf(inj, "%d:%d", &r, &k) == 2 && r == s->comm.rank && ++s->test_allreduces == k) {
+            set_error("injected all-reduce failure (CUDAMAT_TEST_COMM_FAIL=%s)", inj);
+            return CUDAMAT_ERR_COMM;
+        }
+    }
     comm_mark_begin(s, 3, s->ctx->stream);
     if (s->comm.allreduce(s->comm.user, buf, count) != 0) {
         set_error("allreduce callback failed");
@@ -570,7 +581,9 @@ __global__ __launch_bounds__(kBlock) void k_col_windows(long long nnz, const int
 }
 
 // collective: every rank learns what every rank needs from every slice; decides (identically everywhere) whether
-// the windows replace the whole gather
+// the windows replace the whole gather.  Every rank-local step comes BEFORE the all-gather and its outcome travels IN
+// the payload (a negative entry = "this rank failed"), so a rank whose local work failed still enters the collective
+// and every rank returns an error afterwards -- nobody is left alone inside it.
 static int compute_windows(cudamat_solver *s)
 {
     s->windows_known = true;
@@ -580,25 +593,34 @@ static int compute_windows(cudamat_solver *s)
     if (!s->comm.gather_window || W <= 1 || W > 4096) return CUDAMAT_OK;
     hipStream_t st = s->ctx->stream;
     const int per = s->n_pad;
-    int *d_lohi = nullptr;
     std::vector<int> h((size_t)2 * W);
-    CM_HIP(hipMalloc((void **)&d_lohi, sizeof(int) * 2 * (size_t)W));
-    for (int q = 0; q < W; q++) { h[(size_t)q] = per; h[(size_t)W + q] = 0; }
-    CM_HIP(hipMemcpyAsync(d_lohi, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, st));
-    if (s->nnz > 0) {
-        int grid = (int)((s->nnz + 4096LL * kBlock - 1) / (4096LL * kBlock));
-        grid = grid < 1 ? 1 : grid > 4096 ? 4096 : grid;
-        hipLaunchKernelGGL(k_col_windows, dim3(grid), dim3(kBlock), sizeof(int) * 2 * (size_t)W, st, (long long)s->nnz, s->ci, per, W,
-                           d_lohi, d_lohi + W);
-    }
-    hipError_t e = hipMemcpyAsync(h.data(), d_lohi, sizeof(int) * h.size(), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(d_lohi);
-    CM_HIP(e);
     std::vector<double> mine((size_t)2 * W, 0.0), all((size_t)2 * W * W, 0.0);
-    for (int q = 0; q < W; q++)
-        if (q != me && h[(size_t)W + q] > h[(size_t)q]) { mine[(size_t)2 * q] = h[(size_t)q]; mine[(size_t)2 * q + 1] = h[(size_t)W + q]; }
-    if (!s->need_dev) CM_TRY(dev_alloc((void **)&s->need_dev, sizeof(double) * ((size_t)2 * W + (size_t)2 * W * W)));
+    char saved[512] = "";
+    auto local = [&]() -> int {
+        int *d_lohi = nullptr;
+        CM_HIP(hipMalloc((void **)&d_lohi, sizeof(int) * 2 * (size_t)W));
+        for (int q = 0; q < W; q++) { h[(size_t)q] = per; h[(size_t)W + q] = 0; }
+        hipError_t e = hipMemcpyAsync(d_lohi, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && s->nnz > 0) {
+            int grid = (int)((s->nnz + 4096LL * kBlock - 1) / (4096LL * kBlock));
+            grid = grid < 1 ? 1 : grid > 4096 ? 4096 : grid;
+            hipLaunchKernelGGL(k_col_windows, dim3(grid), dim3(kBlock), sizeof(int) * 2 * (size_t)W, st, (long long)s->nnz, s->ci, per, W,
+                               d_lohi, d_lohi + W);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_lohi, sizeof(int) * h.size(), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        hipFree(d_lohi);
+        CM_HIP(e);
+        for (int q = 0; q < W; q++)
+            if (q != me && h[(size_t)W + q] > h[(size_t)q]) { mine[(size_t)2 * q] = h[(size_t)q]; mine[(size_t)2 * q + 1] = h[(size_t)W + q]; }
+        return CUDAMAT_OK;
+    };
+    const int rc_local = local();
+    if (rc_local != CUDAMAT_OK) {
+        snprintf(saved, sizeof(saved), "%s", cudamat_last_error());
+        mine.assign((size_t)2 * W, -1.0);
+    }
+    // (need_dev was allocated by cudamat_solver_set_comm: no allocation can fail between here and the collective)
     CM_HIP(hipMemcpyAsync(s->need_dev, mine.data(), sizeof(double) * mine.size(), hipMemcpyHostToDevice, st));
     CM_HIP(hipStreamSynchronize(st));
     if (s->comm.allgather(s->comm.user, s->need_dev, s->need_dev + 2 * W, (int64_t)2 * W) != 0) {
@@ -607,6 +629,9 @@ static int compute_windows(cudamat_solver *s)
     }
     CM_HIP(hipMemcpyAsync(all.data(), s->need_dev + 2 * W, sizeof(double) * all.size(), hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
+    if (rc_local != CUDAMAT_OK) { set_error("%s", saved); return rc_local; }
+    for (double v : all)
+        if (v < 0.0) { set_error("another rank failed while it looked for its column windows"); return CUDAMAT_ERR_COMM; }
     s->w_send_off.assign((size_t)W, 0); s->w_send_cnt.assign((size_t)W, 0);
     s->w_recv_off.assign((size_t)W, 0); s->w_recv_cnt.assign((size_t)W, 0);
     double worst = 0.0;
@@ -643,6 +668,9 @@ static int setup_agree(cudamat_solver *s, int rc_local)
     snprintf(saved, sizeof(saved), "%s", cudamat_last_error());
     hipStream_t st = s->ctx->stream;
     double h[2] = {rc_local != CUDAMAT_OK ? 1.0 : 0.0, s->spmv_mode == 1 ? 1.0 : 0.0};
+    // (the only rank-local step in front of the collective is this 16-byte upload; if it fails the device itself is
+    // gone and the all-reduce below could not run either -- the host must then abort the communicator,
+    // cudamat_rccl_comm_abort, as csrc/sharded.cpp does for every failed rank)
     CM_HIP(hipMemcpyAsync(s->red + 10, h, sizeof(h), hipMemcpyHostToDevice, st));
     CM_HIP(hipStreamSynchronize(st));                       // (h is a stack buffer)
     CM_TRY(allreduce(s, s->red + 10, 2));

@@ -177,6 +177,9 @@ int cudamat_rccl_available(void);                  /* 1 when librccl could be lo
 int cudamat_rccl_unique_id(void *id);              /* fills CUDAMAT_RCCL_ID_BYTES bytes */
 int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int rank, int world, cudamat_comm *out);
 int cudamat_rccl_comm_destroy(cudamat_comm *comm);
+/* Tear the communicator down without waiting for its streams: for a rank that failed while its peers wait inside a
+ * collective (every rank of the job aborts, then destroys).  Any thread; idempotent; destroy must still follow.      */
+int cudamat_rccl_comm_abort(cudamat_comm *comm);
 
 /* A communicator whose exchanges are SKIPPED (streams and call sequence are real): times one rank's share of a
  * sharded solve on a single GPU (scripts/rank_probe.py).  The iterates of such a solve are meaningless.        */

@@ -1250,6 +1250,38 @@ def test_drop_in_entry_points_over_several_ranks(cm, oracle, golden_dir, monkeyp
         cm.use_gpus(1)
 
 
+def test_a_failing_rank_does_not_strand_its_peers(cm, oracle, golden_dir, monkeypatch):
+    """cudamat_solve_sharded with one rank whose k-th all-reduce fails (injected): that rank leaves the solve while its
+    peers are inside the next collective -- the call must RETURN (an error naming the rank), not hang: the failing rank
+    breaks the emulated barriers / aborts every rank's RCCL communicator before anything waits for a stream."""
+    import threading
+    if cm.device_count() < 3:
+        monkeypatch.setenv("CUDAMAT_SHARDED_ONE_DEVICE", "1")
+    A = _load(oracle, golden_dir, "mat10000")
+    b = oracle.spmv(A, 1.0 + np.sin(np.arange(A.n)))
+    for inj in ("1:7", "0:3", "2:12"):           # in the loop, right after the setup agreement, some iterations in
+        monkeypatch.setenv("CUDAMAT_TEST_COMM_FAIL", inj)
+        box = {}
+
+        def call():
+            try:
+                cm.use_gpus(3)
+                box["res"] = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 2000, 1e-8)
+            except Exception as e:  # noqa: BLE001
+                box["err"] = e
+            finally:
+                cm.use_gpus(1)
+
+        t = threading.Thread(target=call, daemon=True)
+        t.start()
+        t.join(120)
+        assert not t.is_alive(), "cudamat_solve_sharded did not return after rank %s failed" % inj.split(":")[0]
+        assert "err" in box and "rank %s of 3" % inj.split(":")[0] in str(box["err"]) and "injected" in str(box["err"]), box
+    monkeypatch.delenv("CUDAMAT_TEST_COMM_FAIL")
+    ok, x, dt, st = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 2000, 1e-8)      # and the library still works
+    assert ok
+
+
 def test_single_launch_loop_matches_the_three_launch_loop(cm, ctx, oracle, golden_dir, monkeypatch):
     """systems of at most one stream tile per compute unit run the whole loop in ONE launch (grid barriers between
     the phases, cudamat_stats.loop_form == 2): same stopping decisions and iterates as one launch per phase"""

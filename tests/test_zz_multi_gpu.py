@@ -61,3 +61,33 @@ def test_cli_row_shards_over_two_gpus(cm):
     x0 = [float(v) for v in re.search(r"result:\s*\(([^)]*)\)", ref.stdout).group(1).split()]
     x1 = [float(v) for v in re.search(r"result:\s*\(([^)]*)\)", r.stdout).group(1).split()]
     assert len(x0) == len(x1) == 10000 and max(abs(a - b) for a, b in zip(x0, x1)) <= 2e-5
+
+
+def test_a_failing_rank_aborts_the_rccl_communicators(cm):
+    """two real GPUs, in-process RCCL ranks (cudamat_solve_sharded): rank 1's 7th all-reduce fails (injected) while rank 0
+    sits in the matching collective -- ncclCommAbort on every rank's communicators must bring the call back with an error"""
+    import threading
+    import numpy as np
+    from oracle import oracle as O
+    A = O.mtx_load(os.path.join(GOLD, "mat10000.mtx"))
+    b = O.spmv(A, 1.0 + np.sin(np.arange(A.n)))
+    os.environ["CUDAMAT_TEST_COMM_FAIL"] = "1:7"
+    box = {}
+
+    def call():
+        try:
+            cm.use_gpus(2)
+            box["res"] = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 2000, 1e-8)
+        except Exception as e:  # noqa: BLE001
+            box["err"] = e
+        finally:
+            cm.use_gpus(1)
+
+    try:
+        t = threading.Thread(target=call, daemon=True)
+        t.start()
+        t.join(180)
+    finally:
+        del os.environ["CUDAMAT_TEST_COMM_FAIL"]
+    assert not t.is_alive(), "cudamat_solve_sharded did not return after rank 1 failed"
+    assert "err" in box and "rank 1 of 2" in str(box["err"]), box
