@@ -53,7 +53,7 @@ def parse():
                          "ILU(0) of each rank's diagonal block, row-sharded (different maths for N > 1, SURVEY 8 f4)")
     ap.add_argument("--loop", default="pbicgstab", choices=["pbicgstab", "pipelined"],
                     help="pbicgstab: the reference's loop (pbicgstab.cu:45-154), the headline; pipelined: the same "
-                         "recurrences re-arranged so that the reductions run beside the SpMVs (SURVEY 8 f4; no preconditioner)")
+                         "recurrences re-arranged so that the reductions run beside the SpMVs (SURVEY 8 f4; with --precond: its preconditioned form)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-iters-full", type=int, default=3, help="iterations of the CPU baseline on the full matrix")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)

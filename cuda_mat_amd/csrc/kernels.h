@@ -131,12 +131,19 @@ int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, 
                 ScalarSrc half = ScalarSrc{nullptr, 0, 1});
 // pipelined BiCGStab (kernels.hip, "pipelined BiCGStab"): partials of k_pipe_a have stride 3, of k_pipe_b stride 5
 int launch_pipe_seed(hipStream_t s, ScalarSrc init, ScalarSrc rww, double *out5);
+// the hatted (M^-1-applied) vectors of the preconditioned form; all NULL without a preconditioner
+struct PipeHatA { const double *rh, *wh, *zh; double *sh, *qh; };
+struct PipeHatB { const double *qh, *wh, *zh; double *rh; };
 int launch_pipe_a(hipStream_t s, LoopArgs la, ScalarSrc B, int64_t n, const double *r, const double *w, const double *t,
                   const double *v, double *p, double *sv, double *z, double *q, double *y, const double *x, double *xh,
-                  double *parts, int *nparts);
+                  double *parts, int *nparts, PipeHatA hat);
 int launch_pipe_b(hipStream_t s, LoopArgs la, ScalarSrc A, int64_t n, const double *q, const double *y, const double *t,
                   const double *v, const double *rw, const double *sv, const double *z, const double *xh, double *x, double *r,
-                  double *w, double *parts, int *nparts);
+                  double *w, double *parts, int *nparts, PipeHatB hat);
+// residual replacement: r = f - ax; the five dots of k_pipe_b recomputed (stride 5 partials)
+int launch_residual(hipStream_t s, int64_t n, const double *f, const double *ax, double *r);
+int launch_pipe_dots(hipStream_t s, int64_t n, const double *rw, const double *r, const double *w, const double *sv,
+                     const double *z, double *parts, int *nparts);
 // standalone stopping tests (one workgroup)
 int launch_check(hipStream_t s, LoopArgs la, ScalarSrc src, int which);
 // out[k] = sum of partials, k < K (one workgroup)

@@ -1392,11 +1392,14 @@ int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, 
 // what a late workgroup of the same launch still reads).  Same stopping rules as LOOP_PBICGSTAB (:116, :147).
 constexpr int kPipeA = 3, kPipeB = 5;
 
-template <int VEC>
+// PC = 1: the preconditioned form (M^-1 where pbicgstab.cu:92-98,121-127 apply it).  Hatted vectors are M^-1 times the
+// plain ones: rh, wh, zh come in, p carries ph = M^-1 p, sh = M^-1 s is carried by its own recurrence, qh = rh - alpha sh
+// goes out for k_pipe_b; x advances along the hatted directions.  With PC = 0 hatted and plain vectors coincide.
+template <int VEC, int PC>
 __global__ __launch_bounds__(kBlock) void k_pipe_a(LoopArgs la, ScalarSrc B, int64_t n, const double *r,
                                                    const double *w, const double *t, const double *v, double *p,
                                                    double *s, double *z, double *q, double *y, const double *x,
-                                                   double *xh, double *parts)
+                                                   double *xh, double *parts, PipeHatA hat)
 {
 #pragma clang fp contract(off)      // one rounding per operation, like the oracle's restatement
     __shared__ double lds[4 * kPipeB];
@@ -1438,15 +1441,18 @@ __global__ __launch_bounds__(kBlock) void k_pipe_a(LoopArgs la, ScalarSrc B, int
     }
     double acc[kPipeA] = {0.0, 0.0, 0.0};
     const bool first = k == 0;
+    // (rh, wh, zh, sh, qh are only touched when PC = 1: without a preconditioner they ARE r, w, z, s, q)
     auto elem = [&](double rr, double ww, double tt, double vv, double &pp, double &ss, double &zz, double xx,
-                    double &qq, double &yy, double &xo) {
-        if (first) { pp = rr; ss = ww; zz = tt; }
+                    double &qq, double &yy, double &xo, double rrh, double wwh, double zzh, double &ssh, double &qqh) {
+        if (first) { pp = PC ? rrh : rr; ss = ww; zz = tt; if (PC) ssh = wwh; }
         else {
-            pp = rr + beta * (pp - omega * ss);
+            pp = (PC ? rrh : rr) + beta * (pp - omega * (PC ? ssh : ss));
+            if (PC) ssh = wwh + beta * (ssh - omega * zzh);
             ss = ww + beta * (ss - omega * zz);
             zz = tt + beta * (zz - omega * vv);
         }
         qq = rr - alpha * ss;
+        if (PC) qqh = rrh - alpha * ssh;
         yy = ww - alpha * zz;
         xo = xx + alpha * pp;
         acc[0] += qq * yy;
@@ -1464,27 +1470,40 @@ __global__ __launch_bounds__(kBlock) void k_pipe_a(LoopArgs la, ScalarSrc B, int
             double2 pp = ((double2 *)p)[i];
             double2 ss = ((double2 *)s)[i];
             double2 zz = ((double2 *)z)[i];
+            double2 rrh = {0.0 COMMA 0.0}; double2 wwh = {0.0 COMMA 0.0}; double2 zzh = {0.0 COMMA 0.0};
+            double2 ssh = {0.0 COMMA 0.0}; double2 qqh = {0.0 COMMA 0.0};
+            if (PC) {
+                rrh = ((const double2 *)hat.rh)[i]; wwh = ((const double2 *)hat.wh)[i];
+                if (!first) { zzh = ((const double2 *)hat.zh)[i]; ssh = ((double2 *)hat.sh)[i]; }
+            }
             double2 qq; double2 yy; double2 xo;
-            elem(rr.x, ww.x, tt.x, vv.x, pp.x, ss.x, zz.x, xx.x, qq.x, yy.x, xo.x);
-            elem(rr.y, ww.y, tt.y, vv.y, pp.y, ss.y, zz.y, xx.y, qq.y, yy.y, xo.y);
+            elem(rr.x, ww.x, tt.x, vv.x, pp.x, ss.x, zz.x, xx.x, qq.x, yy.x, xo.x, rrh.x, wwh.x, zzh.x, ssh.x, qqh.x);
+            elem(rr.y, ww.y, tt.y, vv.y, pp.y, ss.y, zz.y, xx.y, qq.y, yy.y, xo.y, rrh.y, wwh.y, zzh.y, ssh.y, qqh.y);
             ((double2 *)p)[i] = pp; ((double2 *)s)[i] = ss; ((double2 *)z)[i] = zz;
             ((double2 *)q)[i] = qq; ((double2 *)y)[i] = yy; ((double2 *)xh)[i] = xo;
+            if (PC) { ((double2 *)hat.sh)[i] = ssh; ((double2 *)hat.qh)[i] = qqh; }
         },
         {
             double pp = p[i]; double ss = s[i]; double zz = z[i]; double qq; double yy; double xo;
-            elem(r[i], w[i], t[i], first ? 0.0 : v[i], pp, ss, zz, x[i], qq, yy, xo);
+            double ssh = 0.0; double qqh = 0.0;
+            if (PC && !first) ssh = hat.sh[i];
+            elem(r[i], w[i], t[i], first ? 0.0 : v[i], pp, ss, zz, x[i], qq, yy, xo, PC ? hat.rh[i] : 0.0, PC ? hat.wh[i] : 0.0,
+                 (PC && !first) ? hat.zh[i] : 0.0, ssh, qqh);
             p[i] = pp; s[i] = ss; z[i] = zz; q[i] = qq; y[i] = yy; xh[i] = xo;
+            if (PC) { hat.sh[i] = ssh; hat.qh[i] = qqh; }
         })
     block_sum<kPipeA>(acc, lds);
     if (threadIdx.x == 0)
         for (int j = 0; j < kPipeA; j++) parts[kPipeA * blockIdx.x + j] = acc[j];
 }
 
-template <int VEC>
+// PC = 1: x advances along qh = M^-1 q, and rh' = qh - omega (wh - alpha zh) = M^-1 r' is carried along
+template <int VEC, int PC>
 __global__ __launch_bounds__(kBlock) void k_pipe_b(LoopArgs la, ScalarSrc A, int64_t n, const double *q,
                                                    const double *y, const double *t, const double *v,
                                                    const double *rw, const double *s, const double *z,
-                                                   const double *xh, double *x, double *r, double *w, double *parts)
+                                                   const double *xh, double *x, double *r, double *w, double *parts,
+                                                   PipeHatB hat)
 {
 #pragma clang fp contract(off)
     __shared__ double lds[4 * kPipeB];
@@ -1516,9 +1535,10 @@ __global__ __launch_bounds__(kBlock) void k_pipe_b(LoopArgs la, ScalarSrc A, int
     const double alpha = st->alpha2[la.k & 1];
     double acc[kPipeB] = {0.0, 0.0, 0.0, 0.0, 0.0};
     auto elem = [&](double qq, double yy, double tt, double vv, double ww_, double ss, double zz, double xo,
-                    double &xx, double &rr, double &wn) {
-        xx = xo + omega * qq;
+                    double &xx, double &rr, double &wn, double qqh, double wwh, double zzh, double &rrh) {
+        xx = xo + omega * (PC ? qqh : qq);
         rr = qq - omega * yy;
+        if (PC) rrh = qqh - omega * (wwh - alpha * zzh);
         wn = yy - omega * (tt - alpha * vv);
         acc[0] += ww_ * rr;
         acc[1] += ww_ * wn;
@@ -1536,15 +1556,20 @@ __global__ __launch_bounds__(kBlock) void k_pipe_b(LoopArgs la, ScalarSrc A, int
             const double2 ss = ((const double2 *)s)[i];
             const double2 zz = ((const double2 *)z)[i];
             const double2 xo = ((const double2 *)xh)[i];
+            double2 qqh = {0.0 COMMA 0.0}; double2 wwh = {0.0 COMMA 0.0}; double2 zzh = {0.0 COMMA 0.0}; double2 rrh = {0.0 COMMA 0.0};
+            if (PC) { qqh = ((const double2 *)hat.qh)[i]; wwh = ((const double2 *)hat.wh)[i]; zzh = ((const double2 *)hat.zh)[i]; }
             double2 xx; double2 rr; double2 wn;
-            elem(qq.x, yy.x, tt.x, vv.x, ww_.x, ss.x, zz.x, xo.x, xx.x, rr.x, wn.x);
-            elem(qq.y, yy.y, tt.y, vv.y, ww_.y, ss.y, zz.y, xo.y, xx.y, rr.y, wn.y);
+            elem(qq.x, yy.x, tt.x, vv.x, ww_.x, ss.x, zz.x, xo.x, xx.x, rr.x, wn.x, qqh.x, wwh.x, zzh.x, rrh.x);
+            elem(qq.y, yy.y, tt.y, vv.y, ww_.y, ss.y, zz.y, xo.y, xx.y, rr.y, wn.y, qqh.y, wwh.y, zzh.y, rrh.y);
             ((double2 *)x)[i] = xx; ((double2 *)r)[i] = rr; ((double2 *)w)[i] = wn;
+            if (PC) ((double2 *)hat.rh)[i] = rrh;
         },
         {
-            double xx; double rr; double wn;
-            elem(q[i], y[i], t[i], v[i], rw[i], s[i], z[i], xh[i], xx, rr, wn);
+            double xx; double rr; double wn; double rrh = 0.0;
+            elem(q[i], y[i], t[i], v[i], rw[i], s[i], z[i], xh[i], xx, rr, wn, PC ? hat.qh[i] : 0.0, PC ? hat.wh[i] : 0.0,
+                 PC ? hat.zh[i] : 0.0, rrh);
             x[i] = xx; r[i] = rr; w[i] = wn;
+            if (PC) hat.rh[i] = rrh;
         })
     block_sum<kPipeB>(acc, lds);
     if (threadIdx.x == 0)
@@ -1578,30 +1603,107 @@ int launch_pipe_seed(hipStream_t s, ScalarSrc init, ScalarSrc rww, double *out)
 
 int launch_pipe_a(hipStream_t s, LoopArgs la, ScalarSrc B, int64_t n, const double *r, const double *w, const double *t,
                   const double *v, double *p, double *sv, double *z, double *q, double *y, const double *x, double *xh,
-                  double *parts, int *nparts)
+                  double *parts, int *nparts, PipeHatA hat)
 {
     const int g = vec_grid(n);
     *nparts = g;
-    if (aligned16(r) && aligned16(w) && aligned16(t) && aligned16(v) && aligned16(p) && aligned16(sv) && aligned16(z) &&
-        aligned16(q) && aligned16(y) && aligned16(x) && aligned16(xh))
-        hipLaunchKernelGGL(k_pipe_a<1>, dim3(g), dim3(kBlock), 0, s, la, B, n, r, w, t, v, p, sv, z, q, y, x, xh, parts);
-    else
-        hipLaunchKernelGGL(k_pipe_a<0>, dim3(g), dim3(kBlock), 0, s, la, B, n, r, w, t, v, p, sv, z, q, y, x, xh, parts);
+    const bool pc = hat.rh != nullptr;
+    const bool al = aligned16(r) && aligned16(w) && aligned16(t) && aligned16(v) && aligned16(p) && aligned16(sv) && aligned16(z) &&
+                    aligned16(q) && aligned16(y) && aligned16(x) && aligned16(xh) &&
+                    (!pc || (aligned16(hat.rh) && aligned16(hat.wh) && aligned16(hat.zh) && aligned16(hat.sh) && aligned16(hat.qh)));
+#define CM_PIPE_A(V, P) hipLaunchKernelGGL((k_pipe_a<V, P>), dim3(g), dim3(kBlock), 0, s, la, B, n, r, w, t, v, p, sv, z, q, y, x, xh, parts, hat)
+    if (al && pc) CM_PIPE_A(1, 1);
+    else if (al) CM_PIPE_A(1, 0);
+    else if (pc) CM_PIPE_A(0, 1);
+    else CM_PIPE_A(0, 0);
+#undef CM_PIPE_A
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }
 
 int launch_pipe_b(hipStream_t s, LoopArgs la, ScalarSrc A, int64_t n, const double *q, const double *y, const double *t,
                   const double *v, const double *rw, const double *sv, const double *z, const double *xh, double *x, double *r,
-                  double *w, double *parts, int *nparts)
+                  double *w, double *parts, int *nparts, PipeHatB hat)
 {
     const int g = vec_grid(n);
     *nparts = g;
-    if (aligned16(q) && aligned16(y) && aligned16(t) && aligned16(v) && aligned16(rw) && aligned16(sv) && aligned16(z) &&
-        aligned16(xh) && aligned16(x) && aligned16(r) && aligned16(w))
-        hipLaunchKernelGGL(k_pipe_b<1>, dim3(g), dim3(kBlock), 0, s, la, A, n, q, y, t, v, rw, sv, z, xh, x, r, w, parts);
+    const bool pc = hat.rh != nullptr;
+    const bool al = aligned16(q) && aligned16(y) && aligned16(t) && aligned16(v) && aligned16(rw) && aligned16(sv) && aligned16(z) &&
+                    aligned16(xh) && aligned16(x) && aligned16(r) && aligned16(w) &&
+                    (!pc || (aligned16(hat.qh) && aligned16(hat.wh) && aligned16(hat.zh) && aligned16(hat.rh)));
+#define CM_PIPE_B(V, P) hipLaunchKernelGGL((k_pipe_b<V, P>), dim3(g), dim3(kBlock), 0, s, la, A, n, q, y, t, v, rw, sv, z, xh, x, r, w, parts, hat)
+    if (al && pc) CM_PIPE_B(1, 1);
+    else if (al) CM_PIPE_B(1, 0);
+    else if (pc) CM_PIPE_B(0, 1);
+    else CM_PIPE_B(0, 0);
+#undef CM_PIPE_B
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// ---- residual replacement of the pipelined loop (solver.hip): r = f - ax, and the five dots k_pipe_b would have left
+// (rw.r, rw.w, rw.s, rw.z, r.r) recomputed from the replaced vectors (same layout: stride kPipeB per workgroup)
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_residual(int64_t n, const double *f, const double *ax, double *r)
+{
+    CM_VEC_LOOP(n,
+        {
+            const double2 ff = ((const double2 *)f)[i];
+            const double2 aa = ((const double2 *)ax)[i];
+            double2 rr; rr.x = ff.x - aa.x; rr.y = ff.y - aa.y;
+            ((double2 *)r)[i] = rr;
+        },
+        { r[i] = f[i] - ax[i]; })
+}
+
+int launch_residual(hipStream_t s, int64_t n, const double *f, const double *ax, double *r)
+{
+    const int g = vec_grid(n);
+    if (aligned16(f) && aligned16(ax) && aligned16(r)) hipLaunchKernelGGL(k_residual<1>, dim3(g), dim3(kBlock), 0, s, n, f, ax, r);
+    else hipLaunchKernelGGL(k_residual<0>, dim3(g), dim3(kBlock), 0, s, n, f, ax, r);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_pipe_dots(int64_t n, const double *rw, const double *r, const double *w,
+                                                      const double *s, const double *z, double *parts)
+{
+#pragma clang fp contract(off)
+    __shared__ double lds[4 * kPipeB];
+    double acc[kPipeB] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    auto elem = [&](double ww_, double rr, double wn, double ss, double zz) {
+        acc[0] += ww_ * rr;
+        acc[1] += ww_ * wn;
+        acc[2] += ww_ * ss;
+        acc[3] += ww_ * zz;
+        acc[4] += rr * rr;
+    };
+    CM_VEC_LOOP(n,
+        {
+            const double2 a = ((const double2 *)rw)[i];
+            const double2 b = ((const double2 *)r)[i];
+            const double2 c = ((const double2 *)w)[i];
+            const double2 d = ((const double2 *)s)[i];
+            const double2 e = ((const double2 *)z)[i];
+            elem(a.x, b.x, c.x, d.x, e.x);
+            elem(a.y, b.y, c.y, d.y, e.y);
+        },
+        { elem(rw[i], r[i], w[i], s[i], z[i]); })
+    block_sum<kPipeB>(acc, lds);
+    if (threadIdx.x == 0)
+        for (int j = 0; j < kPipeB; j++) parts[kPipeB * blockIdx.x + j] = acc[j];
+}
+
+int launch_pipe_dots(hipStream_t s, int64_t n, const double *rw, const double *r, const double *w, const double *sv,
+                     const double *z, double *parts, int *nparts)
+{
+    const int g = vec_grid(n);
+    *nparts = g;
+    if (aligned16(rw) && aligned16(r) && aligned16(w) && aligned16(sv) && aligned16(z))
+        hipLaunchKernelGGL(k_pipe_dots<1>, dim3(g), dim3(kBlock), 0, s, n, rw, r, w, sv, z, parts);
     else
-        hipLaunchKernelGGL(k_pipe_b<0>, dim3(g), dim3(kBlock), 0, s, la, A, n, q, y, t, v, rw, sv, z, xh, x, r, w, parts);
+        hipLaunchKernelGGL(k_pipe_dots<0>, dim3(g), dim3(kBlock), 0, s, n, rw, r, w, sv, z, parts);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }

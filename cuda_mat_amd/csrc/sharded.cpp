@@ -64,6 +64,7 @@ struct Shared {
     int world = 1;
     Barrier bar;
     std::atomic<int> failed{0};
+    std::atomic<int> first_bad{-1};       // the rank whose failure came first: its message is the one reported
     char id[CUDAMAT_RCCL_ID_BYTES];
     // the ranks' RCCL communicators, so that a rank that fails in the solve can abort EVERY rank's (its peers may be
     // inside a collective that waits for it)
@@ -76,8 +77,10 @@ struct Shared {
 };
 
 // a rank's solve failed: nobody may be left waiting for it
-void fail_everyone(Shared *sh)
+void fail_everyone(Shared *sh, int rank)
 {
+    int none = -1;
+    sh->first_bad.compare_exchange_strong(none, rank);
     sh->failed.store(1);
     sh->bar.break_all();
     std::lock_guard<std::mutex> lk(sh->comms_mu);
@@ -143,6 +146,8 @@ bool all_ok(Job *j, int rc)
             j->rc = rc;
             snprintf(j->err, sizeof(j->err), "%s", cudamat_last_error());
         }
+        int none = -1;
+        j->sh->first_bad.compare_exchange_strong(none, j->rank);
         j->sh->failed.store(1);
     }
     bool ok = j->sh->bar.wait();
@@ -236,7 +241,7 @@ void rank_main(Job *j)
                 j->rc = rc;
                 snprintf(j->err, sizeof(j->err), "%s", cudamat_last_error());
             }
-            fail_everyone(sh);
+            fail_everyone(sh, rank);
         }
     } while (0);
     if (native) {                        // (from here on nobody aborts through a pointer into this frame)
@@ -291,6 +296,11 @@ extern "C" int cudamat_solve_sharded(int ngpu, int n, int nnz, const double *A, 
     }
     for (std::thread &t : th) t.join();
     int rc = CUDAMAT_OK;
+    const int fb = sh.first_bad.load();          // the root cause first; the others failed because of it
+    if (fb >= 0 && jobs[(size_t)fb].rc != CUDAMAT_OK) {
+        rc = jobs[(size_t)fb].rc;
+        cm::set_error("rank %d of %d: %s", fb, ngpu, jobs[(size_t)fb].err);
+    }
     for (Job &j : jobs)
         if (j.rc != CUDAMAT_OK && rc == CUDAMAT_OK) {
             rc = j.rc;

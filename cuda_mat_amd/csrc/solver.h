@@ -11,6 +11,7 @@ namespace cm {
 
 constexpr int kLag = 2;            // host looks at the state written kLag iterations ago
 constexpr int kRing = kLag + 2;
+constexpr int kPipeRR = 32;         // residual replacement period of the pipelined loop (oracle.py PIPE_RR)
 
 struct TriFactor {                 // one triangular factor in level-major storage
     int nlevels = 0;
@@ -50,6 +51,7 @@ struct cudamat_solver {
     // CUDAMAT_LOOP_PIPELINED: z = A s, w = A r, q, y = A q, xh = x + alpha p (n_pad each), partials of k_pipe_a / k_pipe_b,
     // reduced scalars ([0..2] phase A, [8..12] phase B), events ordering the side-stream reductions
     double *pz = nullptr, *pww = nullptr, *pq = nullptr, *py = nullptr, *pxh = nullptr;
+    double *prh = nullptr, *pwh = nullptr, *psh = nullptr, *pzh = nullptr, *pqh = nullptr, *ptmp = nullptr;   // preconditioned pipelined loop: M^-1 r, w, s, z, q; scratch
     double *pipeA = nullptr, *pipeB = nullptr, *red_pipe = nullptr;
     hipEvent_t ev_red[2] = {}, ev_red_done[2] = {};
 

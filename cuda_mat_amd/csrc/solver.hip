@@ -45,7 +45,8 @@ static int dev_alloc(void **p, size_t bytes)
 static void free_work(cudamat_solver *s)
 {
     double **vs[] = {&s->r, &s->rw, &s->p, &s->pw, &s->s, &s->t, &s->v, &s->gather, &s->x0_save, &s->v2,
-                     &s->pz, &s->pww, &s->pq, &s->py, &s->pxh, &s->pipeA, &s->pipeB, &s->red_pipe};
+                     &s->pz, &s->pww, &s->pq, &s->py, &s->pxh, &s->pipeA, &s->pipeB, &s->red_pipe,
+                     &s->prh, &s->pwh, &s->psh, &s->pzh, &s->pqh, &s->ptmp};
     for (double **q : vs) {
         if (*q) hipFree(*q);
         *q = nullptr;
@@ -764,7 +765,6 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     CM_ARG(precond == CUDAMAT_PRECOND_NONE || precond == CUDAMAT_PRECOND_ILU0 || precond == CUDAMAT_PRECOND_BLOCK_ILU0,
            "precond");
     CM_ARG(loop == CUDAMAT_LOOP_PBICGSTAB || loop == CUDAMAT_LOOP_PBICGSTAB2 || loop == CUDAMAT_LOOP_PIPELINED, "loop");
-    CM_ARG(!(loop == CUDAMAT_LOOP_PIPELINED && precond), "the pipelined loop has no preconditioned form here");
     CM_ARG(maxit >= 0, "maxit");
     CM_ARG(!(precond == CUDAMAT_PRECOND_ILU0 && s->sharded),
            "ILU(0) of the whole matrix is single-GPU only (SURVEY 8e); sharded runs take CUDAMAT_PRECOND_BLOCK_ILU0");
@@ -822,11 +822,19 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     }
     CM_TRY(launch_init_finish(st, s->st, full_src, tol, abs_tol));
 
-    // Pipelined BiCGStab (kernels.hip): extra vectors, w0 = A r0 (with rw.w0), t0 = A w0, and the seed
+    // Pipelined BiCGStab (kernels.hip): extra vectors, w0 = A rh0 (with rw.w0), t0 = A wh0, and the seed
     // [rw.r0, rw.w0, 0, 0, r0.r0] of the first k_pipe_a.  A reduction phase = the per-workgroup partials of a
     // kernel summed (and, sharded, all-reduced) into red_pipe: on the communicator's reduce stream when it has one,
     // so that it runs beside the SpMV that follows the kernel.
+    // With a preconditioner (ILU(0), or block-Jacobi ILU(0) when sharded: SURVEY 8 f4) the hatted vectors M^-1 r,
+    // M^-1 w, M^-1 s, M^-1 z, M^-1 q are carried too and M^-1 is applied in front of each SpMV, where
+    // pbicgstab.cu:92-98,121-127 apply it.
     const bool pipelined = loop == CUDAMAT_LOOP_PIPELINED;
+    const bool pipe_pc = pipelined && precond != CUDAMAT_PRECOND_NONE;
+    // residual replacement period (Cools & Vanroose): every rr-th iteration r, w, s, z (and their hatted forms, and v)
+    // are recomputed from x and p, which discards the rounding errors the recurrences have accumulated
+    int pipe_rr = kPipeRR;
+    if (const char *e = getenv("CUDAMAT_PIPE_RR")) pipe_rr = atoi(e);
     ScalarSrc pipeB_src{nullptr, 0, 1};
     hipStream_t rst = nullptr;
     if (pipelined) {
@@ -841,6 +849,13 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             CM_TRY(dev_alloc((void **)&s->pipeB, sizeof(double) * 5 * kVecGridMax));
             CM_TRY(dev_alloc((void **)&s->red_pipe, sizeof(double) * 16));
         }
+        if (pipe_pc && !s->prh) {
+            double **vs[] = {&s->prh, &s->pwh, &s->psh, &s->pzh, &s->pqh, &s->ptmp};
+            for (double **q : vs) {
+                CM_TRY(dev_alloc((void **)q, nb));
+                CM_HIP(hipMemsetAsync(*q, 0, nb, st));
+            }
+        }
         if (sharded && s->comm.allreduce_side && s->comm.reduce_stream) {
             rst = (hipStream_t)s->comm.reduce_stream;
             for (int e = 0; e < 2; e++) {
@@ -849,14 +864,18 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             }
         }
         const LoopArgs la_freeze{s->st, nullptr, 0, loop, 0};      // (returns at once when the initial guess already passes: restarts)
-        CM_TRY(spmv_local(s, s->r, s->pww, 1, s->rw, s->parts_rv, la_freeze, CHECK_NONE, nosrc));     // w0 = A r0, rw.w0
+        const double *rh0 = s->r;
+        if (pipe_pc) { CM_TRY(precond_apply(s, s->r, s->ptmp, s->prh)); rh0 = s->prh; }              // rh0 = M^-1 r0
+        CM_TRY(spmv_local(s, rh0, s->pww, 1, s->rw, s->parts_rv, la_freeze, CHECK_NONE, nosrc));      // w0 = A rh0, rw.w0
         ScalarSrc rww{s->parts_rv, spmv_parts(s), 2};
         if (sharded) {
             CM_TRY(launch_reduce_parts(st, rww, 1, s->red + 0, 0));
             CM_TRY(allreduce(s, s->red + 0, 1));
             rww = ScalarSrc{s->red + 0, 0, 1};
         }
-        CM_TRY(spmv_local(s, s->pww, s->t, 0, nullptr, nullptr, la_freeze, CHECK_NONE, nosrc));       // t0 = A w0
+        const double *wh0 = s->pww;
+        if (pipe_pc) { CM_TRY(precond_apply(s, s->pww, s->ptmp, s->pwh)); wh0 = s->pwh; }            // wh0 = M^-1 w0
+        CM_TRY(spmv_local(s, wh0, s->t, 0, nullptr, nullptr, la_freeze, CHECK_NONE, nosrc));          // t0 = A wh0
         CM_TRY(launch_pipe_seed(st, full_src, rww, s->red_pipe + 8));
         pipeB_src = ScalarSrc{s->red_pipe + 8, 0, 1};
     }
@@ -984,24 +1003,53 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
         }
         la.k = k;
         if (pipelined) {
-            // full-step test of iteration k-1, beta, alpha, the five recurrences; dots (q.y, y.y, q.q)
+            const PipeHatA hat_a = pipe_pc ? PipeHatA{s->prh, s->pwh, s->pzh, s->psh, s->pqh} : PipeHatA{nullptr, nullptr, nullptr, nullptr, nullptr};
+            const PipeHatB hat_b = pipe_pc ? PipeHatB{s->pqh, s->pwh, s->pzh, s->prh} : PipeHatB{nullptr, nullptr, nullptr, nullptr};
+            double *const rh = pipe_pc ? s->prh : s->r, *const wh = pipe_pc ? s->pwh : s->pww;
+            double *const sh = pipe_pc ? s->psh : s->s, *const zh = pipe_pc ? s->pzh : s->pz;
+            // full-step test of iteration k-1, beta, alpha, the recurrences; dots (q.y, y.y, q.q)
             CM_TRY(launch_pipe_a(st, la, pipeB_src, n, s->r, s->pww, s->t, s->v, s->p, s->s, s->pz, s->pq, s->py, x, s->pxh,
-                                 s->pipeA, &np_a));
+                                 s->pipeA, &np_a, hat_a));
             ScalarSrc a_src{s->pipeA, np_a, 3};
             CM_TRY(pipe_reduce(a_src, 3, s->red_pipe + 0, 0));
             if (sharded) a_src = ScalarSrc{s->red_pipe + 0, 0, 1};
+            if (pipe_pc) {                                                                            // zh = M^-1 z   :92-98
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+                CM_TRY(precond_apply(s, s->pz, s->ptmp, s->pzh));
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+            }
             if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(spmv_local(s, s->pz, s->v, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));           // v = A z
+            CM_TRY(spmv_local(s, zh, s->v, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));              // v = A zh
             if (profile) hipEventRecord(prof_event(s, pe++), st);
             CM_TRY(pipe_wait(0));
-            // half-step test, omega, x, r, w; dots (rw.r, rw.w, rw.s, rw.z, r.r); i++
+            // half-step test, omega, x, r, rh, w; dots (rw.r, rw.w, rw.s, rw.z, r.r); i++
             CM_TRY(launch_pipe_b(st, la, a_src, n, s->pq, s->py, s->t, s->v, s->rw, s->s, s->pz, s->pxh, x, s->r, s->pww,
-                                 s->pipeB, &np_b));
+                                 s->pipeB, &np_b, hat_b));
+            if (pipe_rr > 0 && (k + 1) % pipe_rr == 0) {
+                // Residual replacement.  q and y are free until the next k_pipe_a; pw is not used by this loop.  The
+                // kernels below return at once when the loop is frozen (`la`), the triangular solves do not look.
+                CM_HIP(hipMemcpyAsync(s->pw, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+                CM_TRY(spmv_local(s, s->pw, s->pq, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));      // q = A x
+                CM_TRY(launch_residual(st, n, b, s->pq, s->r));                                       // r = b - A x
+                if (pipe_pc) CM_TRY(precond_apply(s, s->r, s->ptmp, s->prh));                         // rh = M^-1 r
+                CM_TRY(spmv_local(s, rh, s->pww, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));        // w = A rh
+                CM_TRY(spmv_local(s, s->p, s->s, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));        // s = A ph
+                if (pipe_pc) CM_TRY(precond_apply(s, s->s, s->ptmp, s->psh));                         // sh = M^-1 s
+                CM_TRY(spmv_local(s, sh, s->pz, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));         // z = A sh
+                if (pipe_pc) CM_TRY(precond_apply(s, s->pz, s->ptmp, s->pzh));                        // zh = M^-1 z
+                CM_TRY(spmv_local(s, zh, s->v, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));          // v = A zh
+                CM_TRY(launch_pipe_dots(st, n, s->rw, s->r, s->pww, s->s, s->pz, s->pipeB, &np_b));
+            }
             pipeB_src = ScalarSrc{s->pipeB, np_b, 5};
             CM_TRY(pipe_reduce(pipeB_src, 5, s->red_pipe + 8, 1));
             if (sharded) pipeB_src = ScalarSrc{s->red_pipe + 8, 0, 1};
+            if (pipe_pc) {                                                                            // wh = M^-1 w   :121-127
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+                CM_TRY(precond_apply(s, s->pww, s->ptmp, s->pwh));
+                if (profile) hipEventRecord(prof_event(s, pe++), st);
+            }
             if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(spmv_local(s, s->pww, s->t, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));          // t = A w
+            CM_TRY(spmv_local(s, wh, s->t, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));              // t = A wh
             if (profile) hipEventRecord(prof_event(s, pe++), st);
             CM_TRY(pipe_wait(1));
             continue;

@@ -58,6 +58,8 @@ def lib():
                                     C.c_double, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_pipelined_bicgstab.argtypes = [C.c_int, i32p, i32p, f64p, f64p, f64p, C.c_int, C.c_double,
                                              C.c_void_p, C.c_int, C.POINTER(Stats)]
+        L.orc_ppipelined_bicgstab.argtypes = [C.c_int, i32p, i32p, f64p, C.c_void_p, f64p, f64p, C.c_int, C.c_double,
+                                              C.c_int, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_pbicgstab2.argtypes = [C.c_int, i32p, i32p, f64p, C.c_void_p, f64p, f64p, C.c_int,
                                      C.c_double, f64p, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_ilu0.argtypes = [C.c_int, i32p, i32p, f64p]
@@ -202,18 +204,26 @@ def pbicgstab(A, f, x0=None, vm=None, maxit=2000, tol=1e-6, want_hist=False):
     return (x, st, hist) if want_hist else (x, st)
 
 
-def pipelined_bicgstab(A, f, x0=None, maxit=2000, tol=1e-6, want_hist=False, verify=True):
+PIPE_RR = 32        # residual replacement period of the pipelined loop (csrc/solver.hip kPipeRR)
+
+
+def pipelined_bicgstab(A, f, x0=None, maxit=2000, tol=1e-6, want_hist=False, verify=True, vm=None, rr=None):
     """pipelined BiCGStab (Cools & Vanroose 2017, Alg. 4), stopping rules of pbicgstab.cu:116,147; x0 defaults to ones.
+    vm: ILU(0) values on A's pattern = right preconditioner applied where pbicgstab.cu:92-98,121-127 apply it (None: M = I);
+    rr: residual replacement every rr iterations (0: never; default PIPE_RR, the product's default).
     verify (the product's rule, csrc/solver.hip cudamat_solver_solve): an iterate the loop calls converged is checked
     against its TRUE residual; beyond twice the target the loop is restarted from it towards the same absolute target,
     at most three times within maxit.  st.iters is the total; the history is that of the first segment."""
     x = np.ones(A.n) if x0 is None else _f(x0).copy()
+    rr = PIPE_RR if rr is None else rr
     st = Stats()
     hist = np.full(2 * maxit, np.nan) if want_hist else None
     fb = _f(f)
-    lib().orc_pipelined_bicgstab(A.n, A.rowptr, A.colidx, A.val, fb, x, maxit, tol,
-                                 None if hist is None else hist.ctypes.data_as(C.c_void_p),
-                                 0 if hist is None else len(hist), C.byref(st))
+    vm_keep = None if vm is None else _f(vm)
+    vmp = None if vm_keep is None else vm_keep.ctypes.data_as(C.c_void_p)
+    lib().orc_ppipelined_bicgstab(A.n, A.rowptr, A.colidx, A.val, vmp, fb, x, maxit, tol, int(rr),
+                                  None if hist is None else hist.ctypes.data_as(C.c_void_p),
+                                  0 if hist is None else len(hist), C.byref(st))
     st.restarts = 0
     if verify and st.converged and st.nrm0 > 0.0:
         target = tol * st.nrm0
@@ -225,8 +235,8 @@ def pipelined_bicgstab(A, f, x0=None, maxit=2000, tol=1e-6, want_hist=False, ver
                 st.nrm = true
                 break
             st2 = Stats()
-            lib().orc_pipelined_bicgstab(A.n, A.rowptr, A.colidx, A.val, fb, x, maxit - st.iters, target / true, None, 0,
-                                         C.byref(st2))
+            lib().orc_ppipelined_bicgstab(A.n, A.rowptr, A.colidx, A.val, vmp, fb, x, maxit - st.iters, target / true, int(rr),
+                                          None, 0, C.byref(st2))
             st.restarts += 1
             st.iters += st2.iters
             st.converged, st.half_exit, st.nrm = st2.converged, st2.half_exit, st2.nrm

@@ -386,8 +386,35 @@ int orc_pbicgstab2(int n, const int *rp, const int *ci, const double *a0,
 int orc_pipelined_bicgstab(int n, const int *rp, const int *ci, const double *a, const double *f, double *x,
                            int maxit, double tol, double *hist, int hist_cap, orc_stats *st)
 {
-    double *r = dalloc(n), *rw = dalloc(n), *p = dalloc(n), *s = dalloc(n), *z = dalloc(n), *v = dalloc(n);
-    double *w = dalloc(n), *t = dalloc(n), *q = dalloc(n), *y = dalloc(n);
+    return orc_ppipelined_bicgstab(n, rp, ci, a, NULL, f, x, maxit, tol, 0, hist, hist_cap, st);
+}
+
+/* =========================================================================
+ * The PRECONDITIONED pipelined loop with RESIDUAL REPLACEMENT ("lifts the 8-GPU preconditioned
+ * case").  Cools & Vanroose 2017, the preconditioned form of their Alg. 4 (right preconditioning, M^-1 applied where
+ * pbicgstab.cu:92-98,121-127 apply it: in front of each of the two SpMVs of an iteration) and their residual
+ * replacement.  Hatted vectors are M^-1 times the plain ones; with vm == NULL (M = I) they ARE the plain ones and the
+ * loop is the un-preconditioned one above, operation for operation.
+ *   rh = M^-1 r, w = A rh, wh = M^-1 w, t = A wh;   s = A ph, z = A sh, v = A zh
+ *   ph = rh + beta (ph - omega sh);  s = w + beta (s - omega z);  sh = wh + beta (sh - omega zh);  z = t + beta (z - omega v)
+ *   q = r - alpha s;  qh = rh - alpha sh;  y = w - alpha z;      [dots (q,y) (y,y) (q,q)]  ||  zh = M^-1 z, v = A zh
+ *   omega = (q,y)/(y,y);  x += alpha ph + omega qh;  r' = q - omega y;  rh' = qh - omega (wh - alpha zh);
+ *   w' = y - omega (t - alpha v)              [dots (rw,r') (rw,w') (rw,s) (rw,z) (r',r')]  ||  wh' = M^-1 w', t' = A wh'
+ * Residual replacement, every `rr` iterations (rr = 0: never), right after x, r', rh', w' of that iteration:
+ *   r' = f - A x;  rh' = M^-1 r';  w' = A rh';  s = A ph;  sh = M^-1 s;  z = A sh;  zh = M^-1 z;  v = A zh
+ * -- every carried vector is recomputed from x and ph, so the rounding errors the recurrences have accumulated are
+ * discarded (the published replacement renews r, w, s, z; zh and v are renewed here too, so that the next z recurrence
+ * is consistent with the renewed z: one more solve and product per replacement).
+ * Stopping tests on the UN-preconditioned residuals ||q||, ||r'|| as in the reference loop (:116, :147).
+ * ========================================================================= */
+int orc_ppipelined_bicgstab(int n, const int *rp, const int *ci, const double *a, const double *vm, const double *f, double *x,
+                            int maxit, double tol, int rr, double *hist, int hist_cap, orc_stats *st)
+{
+    double *r = dalloc(n), *rw = dalloc(n), *ph = dalloc(n), *s = dalloc(n), *z = dalloc(n), *v = dalloc(n);
+    double *w = dalloc(n), *t = dalloc(n), *q = dalloc(n), *y = dalloc(n), *tmp = dalloc(n);
+    /* the hatted copies exist only with a preconditioner */
+    double *rh = vm ? dalloc(n) : r, *wh = vm ? dalloc(n) : w, *sh = vm ? dalloc(n) : s, *zh = vm ? dalloc(n) : z;
+    double *qh = vm ? dalloc(n) : q;
     double alpha = 0.0, beta = 0.0, omega = 0.0, rho, rho_new, rw_w, rw_s = 0.0, rw_z = 0.0, nrmr, nrmr0;
     int i = 0, k, half_exit = 0, converged = 0;
 
@@ -396,45 +423,67 @@ int orc_pipelined_bicgstab(int n, const int *rp, const int *ci, const double *a,
     memcpy(rw, r, sizeof(double) * (size_t)n);                /* shadow residual (:72)  */
     nrmr0 = orc_nrm2(n, r);
     nrmr = nrmr0;
-    orc_csrmv(n, rp, ci, a, 1.0, r, 0.0, w);                  /* w0 = A r0 */
-    orc_csrmv(n, rp, ci, a, 1.0, w, 0.0, t);                  /* t0 = A w0 */
+    if (vm) precond_apply(n, rp, ci, vm, r, tmp, rh);         /* rh0 = M^-1 r0 */
+    orc_csrmv(n, rp, ci, a, 1.0, rh, 0.0, w);                 /* w0 = A rh0 */
+    if (vm) precond_apply(n, rp, ci, vm, w, tmp, wh);         /* wh0 = M^-1 w0 */
+    orc_csrmv(n, rp, ci, a, 1.0, wh, 0.0, t);                 /* t0 = A wh0 */
     rho = orc_dot(n, rw, r);
     rw_w = orc_dot(n, rw, w);
     if (nrmr0 == 0.0) { converged = 1; maxit = 0; }
     for (i = 0; i < maxit;) {
         if (i == 0) {
             alpha = rho / rw_w;
-            for (k = 0; k < n; k++) { p[k] = r[k]; s[k] = w[k]; z[k] = t[k]; }
+            for (k = 0; k < n; k++) { ph[k] = rh[k]; s[k] = w[k]; z[k] = t[k]; }
+            if (vm) memcpy(sh, wh, sizeof(double) * (size_t)n);
         } else {
             alpha = rho / (rw_w + beta * rw_s - beta * omega * rw_z);
             for (k = 0; k < n; k++) {
-                p[k] = r[k] + beta * (p[k] - omega * s[k]);
+                ph[k] = rh[k] + beta * (ph[k] - omega * sh[k]);
+                if (vm) sh[k] = wh[k] + beta * (sh[k] - omega * zh[k]);
                 s[k] = w[k] + beta * (s[k] - omega * z[k]);
                 z[k] = t[k] + beta * (z[k] - omega * v[k]);
             }
         }
-        for (k = 0; k < n; k++) { q[k] = r[k] - alpha * s[k]; y[k] = w[k] - alpha * z[k]; }
+        for (k = 0; k < n; k++) {
+            q[k] = r[k] - alpha * s[k];
+            if (vm) qh[k] = rh[k] - alpha * sh[k];
+            y[k] = w[k] - alpha * z[k];
+        }
         const double qy = orc_dot(n, q, y), yy = orc_dot(n, y, y);
         nrmr = orc_nrm2(n, q);
-        orc_csrmv(n, rp, ci, a, 1.0, z, 0.0, v);              /* v = A z   (overlaps the reduction) */
+        if (vm) precond_apply(n, rp, ci, vm, z, tmp, zh);     /* zh = M^-1 z (:92-98) */
+        orc_csrmv(n, rp, ci, a, 1.0, zh, 0.0, v);             /* v = A zh  (overlaps the reduction) */
         if (hist && 2 * i < hist_cap) hist[2 * i] = nrmr;
         if (nrmr < tol * nrmr0) {                             /* half-step exit (:116) */
-            for (k = 0; k < n; k++) x[k] += alpha * p[k];
+            for (k = 0; k < n; k++) x[k] += alpha * ph[k];
             half_exit = 1; converged = 1;
             break;
         }
         omega = qy / yy;
         for (k = 0; k < n; k++) {
-            x[k] += alpha * p[k] + omega * q[k];
+            x[k] += alpha * ph[k] + omega * qh[k];
             r[k] = q[k] - omega * y[k];
+            if (vm) rh[k] = qh[k] - omega * (wh[k] - alpha * zh[k]);
             w[k] = y[k] - omega * (t[k] - alpha * v[k]);
+        }
+        if (rr > 0 && (i + 1) % rr == 0) {                    /* residual replacement */
+            orc_csrmv(n, rp, ci, a, 1.0, x, 0.0, tmp);
+            for (k = 0; k < n; k++) r[k] = f[k] - tmp[k];
+            if (vm) precond_apply(n, rp, ci, vm, r, tmp, rh);
+            orc_csrmv(n, rp, ci, a, 1.0, rh, 0.0, w);
+            orc_csrmv(n, rp, ci, a, 1.0, ph, 0.0, s);
+            if (vm) precond_apply(n, rp, ci, vm, s, tmp, sh);
+            orc_csrmv(n, rp, ci, a, 1.0, sh, 0.0, z);
+            if (vm) precond_apply(n, rp, ci, vm, z, tmp, zh);
+            orc_csrmv(n, rp, ci, a, 1.0, zh, 0.0, v);
         }
         rho_new = orc_dot(n, rw, r);
         rw_w = orc_dot(n, rw, w);
         rw_s = orc_dot(n, rw, s);
         rw_z = orc_dot(n, rw, z);
         nrmr = orc_nrm2(n, r);
-        orc_csrmv(n, rp, ci, a, 1.0, w, 0.0, t);              /* t = A w   (overlaps the reduction) */
+        if (vm) precond_apply(n, rp, ci, vm, w, tmp, wh);     /* wh = M^-1 w (:121-127) */
+        orc_csrmv(n, rp, ci, a, 1.0, wh, 0.0, t);             /* t = A wh  (overlaps the reduction) */
         beta = (alpha / omega) * (rho_new / rho);
         rho = rho_new;
         if (hist && 2 * i + 1 < hist_cap) hist[2 * i + 1] = nrmr;
@@ -445,6 +494,7 @@ int orc_pipelined_bicgstab(int n, const int *rp, const int *ci, const double *a,
         st->iters = i; st->half_exit = half_exit; st->converged = converged; st->breakdown = 0;
         st->nrm0 = nrmr0; st->nrm = nrmr;
     }
-    free(r); free(rw); free(p); free(s); free(z); free(v); free(w); free(t); free(q); free(y);
+    free(r); free(rw); free(ph); free(s); free(z); free(v); free(w); free(t); free(q); free(y); free(tmp);
+    if (vm) { free(rh); free(wh); free(sh); free(zh); free(qh); }
     return 0;
 }
