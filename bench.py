@@ -32,6 +32,18 @@ except AttributeError:
     HOST_CPUS = os.cpu_count() or 1
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 
+
+
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max), or None when unlimited / unknown: a one-GPU box of
+    the pool shows 256 CPUs and is throttled to 16"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 CHUNK = 25              # steps per restart (fast-converging synthetic systems: the residual underflows soon after)
 CHUNK_SMALL = 100       # ... of the latency-bound small Poisson-type systems (C2 needs ~190 iterations to 1e-8)
@@ -55,6 +67,9 @@ def parse():
                     help="pbicgstab: the reference's loop (pbicgstab.cu:45-154), the headline; pipelined: the same "
                          "recurrences re-arranged so that the reductions run beside the SpMVs (SURVEY 8 f4; with --precond: its preconditioned form)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--drop-in", default="auto", choices=["auto", "off"],
+                    help="auto: also time the host-pointer entry point (cudamat_solve = bicgstab(), pbicgstab.h:113) end to end, "
+                         "twice (one GPU only; the second call reuses the first one's plan)")
     ap.add_argument("--cpu-iters-full", type=int, default=3, help="iterations of the CPU baseline on the full matrix")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     return ap.parse_args()
@@ -266,7 +281,7 @@ def cpu_baseline(args):
                   "built in host memory by the same generator; %d threads = the fastest team of the sweep"
                   % (it, n, args.per_row if args.workload == "rand50" else 5, t_best),
         "loop_seconds": t_loop, "transpose_seconds": t_tr, "build_seconds": t_build,
-        "threads": {"nproc": os.cpu_count(), "sched_affinity_at_start": HOST_CPUS,
+        "threads": {"nproc": os.cpu_count(), "sched_affinity_at_start": HOST_CPUS, "cgroup_cpu_quota_cores": cpu_quota(),
                     "omp_threads_used": t_best, "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
                     "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
                     "spmv_seconds_by_threads": {str(k): v for k, v in sweep.items()}},
@@ -584,6 +599,47 @@ def run_bench(args):
                 if s2 is not None:
                     s2.close()
 
+        # The drop-in entry point end to end (the reference's "total delta time" next to its "algorithm delta time",
+        # example.cpp:364-365): ONE call of cudamat_solve() on HOST arrays -- upload over PCIe, analysis, loop, download --
+        # and a second call with the same matrix, which reuses the first one's plan.  Outside the judged region.
+        drop_in = None
+        if world == 1 and args.drop_in != "off" and precond == cm.PRECOND_NONE and not latency_bound:
+            try:
+                import numpy as np
+                from cuda_mat_amd import api as cm_api
+                rn = cm.lib().cudamat_rand_row_nnz(n, args.per_row) if args.workload == "rand50" else 5
+                rp_d = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                ci_d = torch.empty(n * rn, dtype=torch.int32, device=dev)
+                va_d = torch.empty(n * rn, dtype=torch.float64, device=dev)
+                if args.workload == "rand50":
+                    ctx.gen_rand_rows(n, args.per_row, args.seed, 0, n, 0, rp_d, ci_d, va_d)
+                else:
+                    ctx.gen_poisson5(nx, ny, 0, n, 0, rp_d, ci_d, va_d)
+                torch.cuda.synchronize()
+                rp_h = rp_d.cpu().numpy()
+                nz = int(rp_h[-1])
+                ci_h, va_h, b_h = ci_d[:nz].cpu().numpy(), va_d[:nz].cpu().numpy(), b.cpu().numpy()
+                del rp_d, ci_d, va_d
+                torch.cuda.empty_cache()
+                cm.lib().cudamat_plan_cache_clear()
+                calls = []
+                for _ in range(2):
+                    t1 = time.perf_counter()
+                    xh, sth = cm_api._solve(n, nz, va_h, rp_h, ci_h, None, None, b_h, cm.PRECOND_NONE, cm.LOOP_PBICGSTAB, 200, 1e-8, False)
+                    wall = time.perf_counter() - t1
+                    calls.append({"end_to_end_s": wall, "upload_s": sth.t_upload, "setup_s": sth.t_setup, "tune_s": sth.t_tune,
+                                  "loop_s": sth.t_solve, "library_total_s": sth.t_total, "iters": sth.iters,
+                                  "converged": bool(sth.converged), "spmv_mode": sth.spmv_mode, "plan_reused": sth.plan_reused,
+                                  "max_abs_err": float(np.abs(xh - xs.cpu().numpy()).max())})
+                cm.lib().cudamat_plan_cache_clear()
+                drop_in = {"call": "cudamat_solve() on host CSR arrays, tol 1e-8 (= bicgstab(), pbicgstab.h:113; the reference's "
+                                   "'total delta time' vs 'algorithm delta time', example.cpp:364-365)",
+                           "host_bytes_uploaded": 12.0 * nz + 4.0 * (n + 1) + 8.0 * n,
+                           "first_call": calls[0], "second_call_same_matrix": calls[1]}
+                del rp_h, ci_h, va_h, b_h
+            except Exception as e:  # noqa: BLE001 - a side measurement must never take the bench line down
+                drop_in = {"error": "%s: %s" % (type(e).__name__, e)}
+
     its = args.steps / dt * (world if replicas else 1)      # replicas: N independent solves in the same time
     spmv_ms = ms_spmv / max(n_spmv, 1)
     # algorithmic bytes of one local SpMV launch: values+colidx, rowptr, x once, y once
@@ -656,6 +712,8 @@ def run_bench(args):
                                 "CUDAMAT_VALUE_DICT=0, i.e. on the fp64 values a matrix of arbitrary coefficients has"
                                 % side["value_dictionary"])
             out["with_value_dictionary"] = side
+        if drop_in is not None:
+            out["drop_in"] = drop_in
         if comm is not None:
             # rank 0's exchanges inside the timed region (HIP events recorded by the C++ loop, cudamat_stats): the
             # all-gathers of the SpMV inputs, the part of them rank 0's stream actually waited for ("exposed"; the

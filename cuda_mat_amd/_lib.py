@@ -34,7 +34,8 @@ class Stats(C.Structure):
                 ("n_gather", C.c_int), ("n_allreduce", C.c_int), ("ms_gather", C.c_double),
                 ("ms_gather_exposed", C.c_double), ("ms_allreduce", C.c_double), ("overlapped", C.c_int),
                 ("loop_form", C.c_int), ("gather_fraction", C.c_double), ("ms_spmv_alone", C.c_double),
-                ("loop_fallbacks", C.c_int), ("restarts", C.c_int)]
+                ("loop_fallbacks", C.c_int), ("restarts", C.c_int), ("t_upload", C.c_double), ("t_setup", C.c_double),
+                ("t_tune", C.c_double), ("spmv_mode", C.c_int), ("plan_reused", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -119,6 +120,7 @@ _SIGS = {
     "cudamat_solver_history": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "cudamat_solve": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                                 C.c_double, C.c_int, _P, C.POINTER(Stats)]),
+    "cudamat_plan_cache_clear": (C.c_int, []),
     "cudamat_poisson5_nnz": (C.c_int64, [C.c_int, C.c_int]),
     "cudamat_gen_poisson5": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P]),
     "cudamat_rand_row_nnz": (C.c_int, [C.c_int64, C.c_int]),

@@ -41,6 +41,10 @@ struct cudamat_solver {
     cm::PbPlan pb{};
     cm::SellPlan sell{};
     double ms_csr = 0.0, ms_pb = 0.0, ms_sell = 0.0;   // auto-tune timings
+    double t_create = 0.0;       // s: upload-side copies, validation, CSR launch plan (cudamat_solver_create)
+    double t_spmv_setup = 0.0;   // s: ensure_spmv_mode in all (copies of the matrix in other layouts + timing of candidates)
+    double t_spmv_timing = 0.0;  // s: of that, the timed candidate launches
+    double col_span_bytes = -1.0; // mean (last - first column) * 8 over sampled rows (-1: not sampled)
 
     // work vectors (n_pad doubles each, pad kept zero)
     double *r = nullptr, *rw = nullptr, *p = nullptr, *pw = nullptr, *s = nullptr, *t = nullptr,

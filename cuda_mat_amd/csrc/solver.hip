@@ -17,6 +17,7 @@
 //   * row-sharded operation: the same loop, with the SpMV input gathered and the
 //     scalar partials all-reduced through caller-supplied collectives (RCCL).
 #include <chrono>
+#include <mutex>
 #include <utility>
 #include <math.h>
 #include <stdlib.h>
@@ -141,6 +142,7 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
     CM_ARG(base == 0 || base == 1, "base in {0,1}");
     CM_ARG(rowptr && (nnz == 0 || (colidx && val)), "null CSR array");
     CM_HIP(hipSetDevice(ctx->device));
+    const double t_create0 = now_s();
     cudamat_solver *s = new cudamat_solver();
     s->ctx = ctx;
     s->n = n_local;
@@ -205,6 +207,7 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
             }
         }
     }
+    s->t_create = now_s() - t_create0;
     *out = s;
     return CUDAMAT_OK;
 }
@@ -436,15 +439,62 @@ static int spmv_parts(const cudamat_solver *s)
     return s->spmv_mode == 1 ? s->pb.NRB : s->spmv_mode == 2 ? s->sell.grid : plan_spmv_parts(s->plan);
 }
 
+// How scattered are a row's columns?  Mean of (last - first column) over <= 4096 evenly spaced rows (sorted rows: the
+// two ends of a row are its extremes).  One tiny launch; decides whether candidates that cannot win are timed at all.
+__global__ __launch_bounds__(kBlock) void k_col_span(int n, const int *rp, const int *ci, int samples, unsigned long long *sum, int *cnt)
+{
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= samples) return;
+    const int row = (int)((long long)q * n / samples);
+    const int s = rp[row], e = rp[row + 1];
+    if (e - s < 2) return;
+    atomicAdd(sum, (unsigned long long)(ci[e - 1] - ci[s]));
+    atomicAdd(cnt, 1);
+}
+
+static int col_span_bytes(cudamat_solver *s, double *out)
+{
+    *out = 0.0;
+    hipStream_t st = s->ctx->stream;
+    unsigned long long *d = nullptr, h[2] = {0ULL, 0ULL};
+    CM_HIP(hipMalloc((void **)&d, sizeof(h)));
+    hipMemsetAsync(d, 0, sizeof(h), st);
+    const int samples = s->n < 4096 ? s->n : 4096;
+    hipLaunchKernelGGL(k_col_span, dim3((samples + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s->n, s->rp, s->ci, samples, d, (int *)(d + 1));
+    hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d);
+    CM_HIP(e);
+    const int cnt = (int)(h[1] & 0xffffffffULL);
+    *out = cnt > 0 ? 8.0 * (double)h[0] / cnt : 0.0;
+    return CUDAMAT_OK;
+}
+
 // Choose the SpMV implementation for this matrix (once), by TIMING the candidates on this device:
 //   0  the CSR forms (lanes per row / stream tiles / nnz-balanced tiles, plan_spmv_refine) -- always a candidate;
 //   1  the blocked two-phase kernels, when the columns are scattered over a vector far larger than L2 (pb_candidate);
 //   2  SELL-C-sigma, for rows of 8 entries and more whose padded copy stays below 1.5 x the entries (banded
 //      matrices: 2-2.7 x the lanes-per-row kernel; short rows belong to the stream kernel).
 // CUDAMAT_SPMV_MODE=csr|pb|sell overrides.
+// Candidates that cannot win are not timed (round 3; the drop-in entry points pay this on every call): when a row's
+// columns span far more than the L2s hold (mean span >= 16 MB of x; C4: 77 MB) and rows have >= 8 entries, every gather
+// of the lanes-per-row kernel and of SELL misses L2 -- measured 9.8 / 9.1 ms against 2.8 ms blocked at C4, the same
+// ratio on every scattered matrix of DESIGN section 4 -- so the blocked copy is selected without building the SELL copy
+// or timing anything (a sharded solver still times the blocked form alone: ms_spmv_alone feeds the exposed-gather
+// figure).  CUDAMAT_SPMV_TUNE=full restores the timing of every candidate.
+static int ensure_spmv_mode_inner(cudamat_solver *s);
 static int ensure_spmv_mode(cudamat_solver *s)
 {
     if (s->spmv_mode >= 0) return CUDAMAT_OK;
+    const double t0 = now_s();
+    const int rc = ensure_spmv_mode_inner(s);
+    hipStreamSynchronize(s->ctx->stream);
+    s->t_spmv_setup = now_s() - t0;
+    return rc;
+}
+
+static int ensure_spmv_mode_inner(cudamat_solver *s)
+{
     hipStream_t st = s->ctx->stream;
     const char *env = getenv("CUDAMAT_SPMV_MODE");
     const bool force_csr = env && !strcmp(env, "csr");
@@ -475,13 +525,31 @@ static int ensure_spmv_mode(cudamat_solver *s)
         if (force_pb && !s->sharded) { s->spmv_mode = 1; return CUDAMAT_OK; }
         if (force_pb) { have[0] = false; }      // sharded: still time it (ms_spmv_alone feeds the exposed-gather figure)
     }
+    // scattered columns: the gather-based forms cannot win (see above)
+    bool scattered = false;
+    {
+        const char *tune = getenv("CUDAMAT_SPMV_TUNE");
+        if (have[1] && !force_pb && !force_sell && !(tune && !strcmp(tune, "full")) && s->nnz >= 8 * (int64_t)s->n) {
+            CM_TRY(col_span_bytes(s, &s->col_span_bytes));
+            scattered = s->col_span_bytes >= 16.0 * 1024 * 1024;
+        }
+        if (scattered) {
+            have[0] = false;
+            if (!s->sharded) {
+                s->spmv_mode = 1;
+                if (getenv("CUDAMAT_VERBOSE"))
+                    fprintf(stderr, "cudamat: SpMV: a row's columns span %.1f MB of x on average -> blocked, nothing timed\n", s->col_span_bytes / 1048576.0);
+                return CUDAMAT_OK;
+            }
+        }
+    }
     // ---- SELL-C-sigma copy: rows of 8 entries and more (shorter rows belong to the stream kernel, which measures
     // faster there: C3 0.174 vs 0.191 ms) whose padded copy stays below 1.5 x the entries.  Measured on 2e6-row banded
     // matrices (scripts/sell_probe.py): row lengths 14..70 0.46 ms vs 0.94 (CSR forms) / 0.66 (blocked); 13..20 0.18
     // vs 0.40 / 0.26; with scattered columns the blocked form wins (0.48 vs 1.07) -- hence: time them.
     const char *se = getenv("CUDAMAT_SPMV_SELL");
     const bool sell_off = se && se[0] == '0';
-    if (force_sell || (!force_pb && !sell_off && s->n >= 4096 && s->nnz >= (1 << 16) && s->plan.stream_rows == 0 && s->nnz >= 8 * (int64_t)s->n)) {
+    if (force_sell || (!force_pb && !scattered && !sell_off && s->n >= 4096 && s->nnz >= (1 << 16) && s->plan.stream_rows == 0 && s->nnz >= 8 * (int64_t)s->n)) {
         const int rc = sell_build(st, s->n, s->nnz, s->rp, s->ci, s->val, &s->sell, force_sell ? 0.0 : 1.5);
         if (rc != CUDAMAT_OK && force_sell) return rc;
         have[2] = rc == CUDAMAT_OK;
@@ -498,6 +566,7 @@ static int ensure_spmv_mode(cudamat_solver *s)
     hipEventCreate(&e1);
     float ms[3] = {0.f, 0.f, 0.f};
     int rc = CUDAMAT_OK;
+    const double t_timing0 = now_s();
     for (int mode = 0; mode < 3 && rc == CUDAMAT_OK; mode++) {
         if (!have[mode]) continue;
         SpmvArgs a{};
@@ -513,6 +582,7 @@ static int ensure_spmv_mode(cudamat_solver *s)
     }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
+    s->t_spmv_timing = now_s() - t_timing0;
     CM_HIP(hipMemsetAsync(s->v, 0, sizeof(double) * (size_t)(s->n_pad > 0 ? s->n_pad : 1), st));
     s->ms_csr = ms[0] / 2;
     s->ms_pb = ms[1] / 2;
@@ -1206,6 +1276,9 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     stt.overlapped = sharded && s->windowed ? 2 : (sharded && s->overlap && s->spmv_mode == 1) ? 1 : 0;
     stt.gather_fraction = sharded ? s->gather_fraction : 0.0;
     stt.ms_spmv_alone = s->ms_spmv_alone;
+    stt.t_setup = s->t_create + s->t_spmv_setup;
+    stt.t_tune = s->t_spmv_timing;
+    stt.spmv_mode = s->spmv_mode;
     if (s->profiling) {
         // exposed part of an overlapped gather: the waits (kind 1), clipped to the gather they wait for only by
         // construction -- the solver's stream idles there for nothing else
@@ -1356,6 +1429,64 @@ extern "C" int cudamat_solver_history(cudamat_solver *s, double *hist_host, int 
 // ---------------------------------------------------------------------------------------
 // Drop-in host-pointer solve: pbicgstab.cu:157-409 / :756-922 / :926-1088 in one call.
 // ---------------------------------------------------------------------------------------
+// The reference allocates, analyses, solves and frees per call (pbicgstab.cu:157-409).  Here the solver of the last
+// call stays alive: when the next call brings the same matrix (same n, nnz, base and -- compared ON THE DEVICE after
+// the upload, 12 bytes per entry read twice: ~2.5 ms at C4 -- the same row pointers, column indices and values), its
+// device copies, SpMV plan, value dictionary and ILU(0) factors are reused and the call costs upload + loop.
+namespace {
+struct PlanCache {
+    std::mutex mu;
+    cudamat_ctx *ctx = nullptr;
+    cudamat_solver *s = nullptr;
+    int n = 0, nnz = 0, base = 0;
+    bool has_shift = false;
+    double *d_d = nullptr;          // the (A0 + I d) diagonal the cached solver points at
+};
+PlanCache g_cache;
+
+void cache_drop_locked()
+{
+    if (g_cache.s) cudamat_solver_destroy(g_cache.s);
+    if (g_cache.d_d) cudamat_free(g_cache.ctx, g_cache.d_d);
+    if (g_cache.ctx) cudamat_ctx_destroy(g_cache.ctx);
+    g_cache.s = nullptr;
+    g_cache.d_d = nullptr;
+    g_cache.ctx = nullptr;
+}
+
+bool cache_enabled()
+{
+    const char *e = getenv("CUDAMAT_PLAN_CACHE");
+    return !(e && e[0] == '0');
+}
+}  // namespace
+
+// flag[0] = 1 when a[i] != b[i] for some i (raw 32-bit words)
+__global__ __launch_bounds__(kBlock) void k_differs(long long words, const unsigned *a, const unsigned *b, int *flag)
+{
+    bool diff = false;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < words; i += (long long)gridDim.x * kBlock) diff |= a[i] != b[i];
+    if (diff) *flag = 1;
+}
+
+static int device_equal(hipStream_t st, const void *a, const void *b, size_t bytes, int *flag_dev)
+{
+    const long long words = (long long)(bytes / 4);
+    if (words == 0) return CUDAMAT_OK;
+    long long g = (words + kBlock * 8LL - 1) / (kBlock * 8LL);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_differs, dim3((unsigned)g), dim3(kBlock), 0, st, words, (const unsigned *)a, (const unsigned *)b, flag_dev);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_plan_cache_clear(void)
+{
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    cache_drop_locked();
+    return CUDAMAT_OK;
+}
+
 extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, const int *jA,
                              const double *d, const double *x0, const double *b, int precond,
                              int loop, int maxit, double tol, int debug, double *x,
@@ -1367,14 +1498,22 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
     CM_ARG(iA[n] - base == nnz, "nnz != iA[n] - iA[0]");
     const double t0 = now_s();
     if (debug && loop == CUDAMAT_LOOP_PBICGSTAB) printf("N=%d, nnz=%d\n", n, nnz);   // :204
-    cudamat_ctx *ctx = nullptr;
-    CM_TRY(cudamat_ctx_create(0, nullptr, &ctx));
+    std::lock_guard<std::mutex> cache_lock(g_cache.mu);            // (the entry points are not re-entrant upstream either)
+    const bool use_cache = cache_enabled();
+    if (!use_cache) cache_drop_locked();
+    // same shape as the cached system?  then its context (device, stream) carries this call too
+    const bool candidate = use_cache && g_cache.s && g_cache.n == n && g_cache.nnz == nnz && g_cache.base == base;
+    if (!candidate) cache_drop_locked();
+    cudamat_ctx *ctx = candidate ? g_cache.ctx : nullptr;
+    if (!ctx) CM_TRY(cudamat_ctx_create(0, nullptr, &ctx));
     int *d_rp = nullptr, *d_ci = nullptr;
     double *d_val = nullptr, *d_b = nullptr, *d_x = nullptr, *d_d = nullptr;
     cudamat_solver *s = nullptr;
+    bool reused = false;
     int rc = CUDAMAT_OK;
     cudamat_stats st;
     memset(&st, 0, sizeof(st));
+    double t_up = 0.0;
     do {
         if ((rc = cudamat_malloc(ctx, sizeof(int) * ((size_t)n + 1), (void **)&d_rp))) break;
         if ((rc = cudamat_malloc(ctx, sizeof(int) * (size_t)nnz, (void **)&d_ci))) break;
@@ -1390,14 +1529,43 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
             if ((rc = cudamat_malloc(ctx, sizeof(double) * (size_t)n, (void **)&d_d))) break;
             if ((rc = cudamat_h2d(ctx, d_d, d, sizeof(double) * (size_t)n))) break;
         }
-        if ((rc = cudamat_solver_create(ctx, n, n, nnz, d_rp, d_ci, d_val, base, &s))) break;
-        if (d_d && (rc = cudamat_solver_set_shift(s, d_d))) break;
-        if (precond != CUDAMAT_PRECOND_NONE) {
-            if ((rc = cudamat_solver_ilu0(s))) break;
-            if (debug) {
-                printf("analysis lower %f (s), upper %f (s) \n", s->t_analysis_l, s->t_analysis_u);     // :349
-                printf("csrilu0 (HIP, level-scheduled) time(s) = %10.8f \n", s->t_factor);            // :355,363
+        if ((rc = cudamat_ctx_sync(ctx))) break;
+        t_up = now_s() - t0;
+        if (candidate) {
+            // the cached solver holds the matrix rebased to 0: compare the uploaded arrays with it on the device
+            int *flag = nullptr, h = 1;
+            if ((rc = cudamat_malloc(ctx, sizeof(int), (void **)&flag))) break;
+            hipMemsetAsync(flag, 0, sizeof(int), ctx->stream);
+            cudamat_solver *c = g_cache.s;
+            int *tmp = nullptr;          // rebased copies of the uploaded index arrays
+            rc = cudamat_malloc(ctx, sizeof(int) * ((size_t)nnz > (size_t)n + 1 ? (size_t)nnz : (size_t)n + 1), (void **)&tmp);
+            if (!rc) rc = launch_rebase(ctx->stream, (int64_t)n + 1, d_rp, -base, tmp);
+            if (!rc) rc = device_equal(ctx->stream, tmp, c->rp, sizeof(int) * ((size_t)n + 1), flag);
+            if (!rc && nnz) rc = launch_rebase(ctx->stream, nnz, d_ci, -base, tmp);
+            if (!rc && nnz) rc = device_equal(ctx->stream, tmp, c->ci, sizeof(int) * (size_t)nnz, flag);
+            if (!rc && nnz) rc = device_equal(ctx->stream, d_val, c->val, sizeof(double) * (size_t)nnz, flag);
+            if (!rc && hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = CUDAMAT_ERR_HIP;
+            if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = CUDAMAT_ERR_HIP;
+            if (tmp) cudamat_free(ctx, tmp);
+            cudamat_free(ctx, flag);
+            if (rc) break;
+            if (h == 0) {
+                s = g_cache.s;
+                reused = true;
+            } else {                     // same shape, another matrix: the old solver goes, its context stays
+                cudamat_solver_destroy(g_cache.s);
+                g_cache.s = nullptr;
             }
+        }
+        if (g_cache.d_d) { cudamat_free(ctx, g_cache.d_d); g_cache.d_d = nullptr; }
+        if (!s && (rc = cudamat_solver_create(ctx, n, n, nnz, d_rp, d_ci, d_val, base, &s))) break;
+        if ((rc = cudamat_solver_set_shift(s, d_d))) break;
+        if (precond != CUDAMAT_PRECOND_NONE && !(reused && s->has_ilu && !s->ilu_block)) {
+            if ((rc = cudamat_solver_ilu0(s))) break;
+        }
+        if (precond != CUDAMAT_PRECOND_NONE && debug) {
+            printf("analysis lower %f (s), upper %f (s) \n", s->t_analysis_l, s->t_analysis_u);     // :349
+            printf("csrilu0 (HIP, level-scheduled) time(s) = %10.8f \n", s->t_factor);            // :355,363
         }
         int flags = (debug ? CUDAMAT_FLAG_DEBUG : 0) | (x0 ? 0 : CUDAMAT_FLAG_X0_ONES);
         if ((rc = cudamat_solver_solve(s, d_b, d_x, precond, loop, maxit, tol, flags, &st))) break;
@@ -1406,11 +1574,31 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
     char saved[512];
     strncpy(saved, cudamat_last_error(), sizeof(saved) - 1);
     saved[sizeof(saved) - 1] = 0;
-    if (s) cudamat_solver_destroy(s);
+    st.t_upload = t_up;
+    st.plan_reused = reused ? 1 : 0;
+    if (reused) { st.t_setup = 0.0; st.t_tune = 0.0; st.t_analysis = 0.0; st.t_factor = 0.0; }
+    // keep the solver for the next call (it owns its own copies of the matrix; the upload buffers go)
+    cudamat_solver *const old = g_cache.s;       // the previous call's solver, when it is still alive (may be s itself)
+    if (s && rc == CUDAMAT_OK && use_cache) {
+        if (old && old != s) cudamat_solver_destroy(old);
+        g_cache.ctx = ctx;
+        g_cache.s = s;
+        g_cache.n = n; g_cache.nnz = nnz; g_cache.base = base;
+        g_cache.d_d = d_d;               // the solver points at it (set_shift); replaced by the next call
+        d_d = nullptr;
+    } else {
+        if (s) cudamat_solver_destroy(s);
+        if (old && old != s) cudamat_solver_destroy(old);
+        g_cache.s = nullptr;
+    }
     void *ptrs[] = {d_rp, d_ci, d_val, d_b, d_x, d_d};
     for (void *p : ptrs)
         if (p) cudamat_free(ctx, p);
-    cudamat_ctx_destroy(ctx);
+    if (!g_cache.s) {                    // nothing kept: the context goes too
+        if (g_cache.d_d) { cudamat_free(ctx, g_cache.d_d); g_cache.d_d = nullptr; }
+        cudamat_ctx_destroy(ctx);
+        g_cache.ctx = nullptr;
+    }
     if (rc) set_error("%s", saved);
     st.t_total = now_s() - t0;
     if (out) *out = st;

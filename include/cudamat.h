@@ -122,6 +122,15 @@ typedef struct cudamat_stats {
                             * grid barrier of the single-launch loop ran into its bound (GPU shared; 0 in a healthy run) */
     int restarts;          /* pipelined loop only: how often an iterate it called converged failed the check of its TRUE
                             * residual (one SpMV) and the loop was restarted from it (0 in most solves, at most 3)       */
+    /* where a call's time went beyond t_analysis / t_factor / t_solve (the reference prints "total delta time" next to
+     * "algorithm delta time", example.cpp:364-365; pbicgstab.cu:365-374):                                              */
+    double t_upload;       /* s, cudamat_solve / cudamat_solve_sharded: device allocations + host-to-device copies       */
+    double t_setup;        /* s, solver creation (copies, validation, CSR launch plan) + choice of the SpMV form incl. the
+                            * matrix copies in other layouts; 0 when the plan of the previous call was reused            */
+    double t_tune;         /* s, of t_setup: timed candidate launches (0 when the choice needed none)                    */
+    int spmv_mode;         /* the SpMV form the solve used: 0 CSR forms, 1 blocked two-phase, 2 SELL-C-sigma             */
+    int plan_reused;       /* cudamat_solve: 1 = the previous call brought the same matrix (pattern AND values): its solver
+                            * -- device copies, SpMV plan, value dictionary, ILU(0) factors -- was reused; 0 = built anew */
 } cudamat_stats;
 
 /* Collectives for a row-sharded solve.  Either supplied by the host program (e.g.
@@ -299,6 +308,12 @@ int cudamat_solve(int n, int nnz, const double *A, const int *iA, const int *jA,
  * thread and one RCCL rank per device (csrc/sharded.cpp).  precond: NONE or BLOCK_ILU0 (each
  * rank's diagonal block; ILU0 of the whole matrix does not shard => CUDAMAT_ERR_ARG).
  * ngpu <= 1 is cudamat_solve.  st receives rank 0's statistics (all ranks decide alike).     */
+/* cudamat_solve keeps the solver of its LAST call (CSR copies, SpMV plan, ILU(0) factors: device memory) so that a
+ * caller who solves with the same matrix again -- time steps, several right-hand sides: the reference's per-call shape,
+ * pbicgstab.cu:157-409 -- pays the upload and a device-side comparison but no analysis.  The next call with a different
+ * matrix replaces it; cudamat_plan_cache_clear() (or CUDAMAT_PLAN_CACHE=0 in the environment) releases / disables it. */
+int cudamat_plan_cache_clear(void);
+
 int cudamat_solve_sharded(int ngpu, int n, int nnz, const double *A, const int *iA, const int *jA,
                           const double *d, const double *x0, const double *b, int precond,
                           int loop, int maxit, double tol, int debug, double *x,

@@ -1305,6 +1305,52 @@ def test_drop_in_entry_points_over_several_ranks(cm, oracle, golden_dir, monkeyp
         cm.use_gpus(1)
 
 
+def test_drop_in_call_reuses_the_plan_of_the_previous_call(cm, oracle, monkeypatch):
+    """cudamat_solve keeps the solver of its last call: the same matrix again (compared on the device after the upload)
+    costs upload + loop, no analysis (plan_reused = 1, t_setup = 0, same SpMV form, ILU(0) factors kept); a changed value
+    or another matrix builds anew.  And the tuner no longer times forms that cannot win: a matrix whose rows span far more
+    than the L2s goes to the blocked form with nothing timed -- the same form the full timing picks."""
+    cm.lib().cudamat_plan_cache_clear()
+    A = oracle.rand_rows(200000, 20, 0xABCD)
+    xs = oracle.xstar(A.n, 5)
+    b = oracle.spmv(A, xs)
+    ok, x, dt, st = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 200, 1e-8)
+    assert ok and st.plan_reused == 0 and st.t_setup > 0 and st.t_upload > 0
+    b2 = oracle.spmv(A, 2.0 * xs)
+    ok2, x2, dt2, st2 = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, b2, 200, 1e-8)
+    assert ok2 and st2.plan_reused == 1 and st2.t_setup == 0 and st2.t_tune == 0 and st2.spmv_mode == st.spmv_mode
+    np.testing.assert_allclose(x2, 2.0 * xs, rtol=1e-6)
+    # the preconditioned entry point on the same matrix: reuses the solver, adds the factors; once more: keeps them
+    okp, xp, dtp, stp = cm.bicgstab_lu_precond(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, 200, 1e-8)
+    assert okp and stp.converged and stp.plan_reused == 1 and stp.t_factor > 0
+    okq, xq, dtq, stq = cm.bicgstab_lu_precond(A.n, A.nnz, A.val, A.rowptr, A.colidx, b2, 200, 1e-8)
+    assert stq.converged and stq.plan_reused == 1 and stq.t_factor == 0 and stq.t_analysis == 0
+    np.testing.assert_allclose(xq, 2.0 * xs, rtol=1e-6)
+    # one value changed: not the same matrix
+    v2 = A.val.copy()
+    v2[12345] *= 1.5
+    A2 = oracle.Csr(A.n, A.rowptr, A.colidx, v2, A.n)
+    ok3, x3, dt3, st3 = cm.bicgstab(A.n, A.nnz, v2, A.rowptr, A.colidx, oracle.spmv(A2, xs), 200, 1e-8)
+    assert ok3 and st3.plan_reused == 0 and st3.t_setup > 0
+    np.testing.assert_allclose(x3, xs, rtol=1e-6)
+    # CUDAMAT_PLAN_CACHE=0: every call builds anew
+    monkeypatch.setenv("CUDAMAT_PLAN_CACHE", "0")
+    ok4, x4, dt4, st4 = cm.bicgstab(A.n, A.nnz, v2, A.rowptr, A.colidx, oracle.spmv(A2, xs), 200, 1e-8)
+    assert ok4 and st4.plan_reused == 0
+    monkeypatch.delenv("CUDAMAT_PLAN_CACHE")
+    # scattered columns: nothing is timed, and the full timing agrees with the shortcut
+    S = oracle.rand_rows(2_500_000, 9, 0x77)
+    bs = oracle.spmv(S, oracle.xstar(S.n, 6))
+    oks, xs_, dts, sts = cm.bicgstab(S.n, S.nnz, S.val, S.rowptr, S.colidx, bs, 200, 1e-8)
+    assert oks and sts.plan_reused == 0 and sts.spmv_mode == 1 and sts.t_tune == 0
+    monkeypatch.setenv("CUDAMAT_SPMV_TUNE", "full")
+    monkeypatch.setenv("CUDAMAT_PLAN_CACHE", "0")
+    okf, xf, dtf, stf = cm.bicgstab(S.n, S.nnz, S.val, S.rowptr, S.colidx, bs, 200, 1e-8)
+    assert okf and stf.spmv_mode == 1 and stf.t_tune > 0
+    np.testing.assert_array_equal(xf, xs_)
+    cm.lib().cudamat_plan_cache_clear()
+
+
 def test_a_failing_rank_does_not_strand_its_peers(cm, oracle, golden_dir, monkeypatch):
     """cudamat_solve_sharded with one rank whose k-th all-reduce fails (injected): that rank leaves the solve while its
     peers are inside the next collective -- the call must RETURN (an error naming the rank), not hang: the failing rank
