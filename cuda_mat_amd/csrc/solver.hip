@@ -182,19 +182,31 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
         cudamat_solver_destroy(s);
         return rc;
     }
+    const bool verbose = getenv("CUDAMAT_VERBOSE") != nullptr;
+    double t_mark = now_s();
+    auto stamp = [&](const char *what) {
+        if (!verbose) return;
+        const double t = now_s();
+        fprintf(stderr, "[cudamat] create %-34s %8.3f ms\n", what, (t - t_mark) * 1e3);
+        t_mark = t;
+    };
+    if (verbose) fprintf(stderr, "[cudamat] create %-34s %8.3f ms\n", "allocations + copies", (t_mark - t_create0) * 1e3);
     if (int rcv = validate_csr(s)) {
         cudamat_solver_destroy(s);
         return rcv;
     }
+    stamp("validation");
     s->plan = plan_spmv(n_local, nnz);
     if (int rc2 = plan_spmv_refine(st, n_local, nnz, s->rp, 0, &s->plan)) {
         cudamat_solver_destroy(s);
         return rc2;
     }
+    stamp("CSR launch plan (refine)");
     if (int rc3 = plan_spmv_compress(st, n_local, nnz, s->rp, s->ci, &s->plan)) {
         cudamat_solver_destroy(s);
         return rc3;
     }
+    stamp("compressed-index attempt");
     if (s->plan.c_off16) {          // compressed stream kernel: 8-bit value indices too when the matrix has a dictionary
         if (int rc4 = ensure_valdict(s)) {
             cudamat_solver_destroy(s);
@@ -490,6 +502,9 @@ static int ensure_spmv_mode(cudamat_solver *s)
     const int rc = ensure_spmv_mode_inner(s);
     hipStreamSynchronize(s->ctx->stream);
     s->t_spmv_setup = now_s() - t0;
+    if (getenv("CUDAMAT_VERBOSE"))
+        fprintf(stderr, "[cudamat] SpMV form %d chosen in %.3f ms (blocked copy %.3f ms, timing %.3f ms)\n", s->spmv_mode,
+                s->t_spmv_setup * 1e3, s->pb.build_seconds * 1e3, s->t_spmv_timing * 1e3);
     return rc;
 }
 
@@ -1509,7 +1524,7 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
     int *d_rp = nullptr, *d_ci = nullptr;
     double *d_val = nullptr, *d_b = nullptr, *d_x = nullptr, *d_d = nullptr;
     cudamat_solver *s = nullptr;
-    bool reused = false;
+    bool reused = false, built_ilu = false;
     int rc = CUDAMAT_OK;
     cudamat_stats st;
     memset(&st, 0, sizeof(st));
@@ -1562,6 +1577,7 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
         if ((rc = cudamat_solver_set_shift(s, d_d))) break;
         if (precond != CUDAMAT_PRECOND_NONE && !(reused && s->has_ilu && !s->ilu_block)) {
             if ((rc = cudamat_solver_ilu0(s))) break;
+            built_ilu = true;
         }
         if (precond != CUDAMAT_PRECOND_NONE && debug) {
             printf("analysis lower %f (s), upper %f (s) \n", s->t_analysis_l, s->t_analysis_u);     // :349
@@ -1576,7 +1592,8 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
     saved[sizeof(saved) - 1] = 0;
     st.t_upload = t_up;
     st.plan_reused = reused ? 1 : 0;
-    if (reused) { st.t_setup = 0.0; st.t_tune = 0.0; st.t_analysis = 0.0; st.t_factor = 0.0; }
+    if (reused) { st.t_setup = 0.0; st.t_tune = 0.0; }                       // (they describe the call that built the plan)
+    if (reused && !built_ilu) { st.t_analysis = 0.0; st.t_factor = 0.0; }
     // keep the solver for the next call (it owns its own copies of the matrix; the upload buffers go)
     cudamat_solver *const old = g_cache.s;       // the previous call's solver, when it is still alive (may be s itself)
     if (s && rc == CUDAMAT_OK && use_cache) {

@@ -12,6 +12,28 @@ ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = 0
 forms = {}
 dicts = 0
+
+
+def oracle_spread(A, b, loop, precond, first):
+    """iteration counts of the oracle's loop on P A P^T, P b for 8 random permutations P: the same system in exact
+    arithmetic, other summation orders in the dots and row sums"""
+    base = int(A.rowptr[0])
+    S = sp.csr_matrix((A.val, A.colidx - base, A.rowptr - base), shape=(A.n, A.n))
+    prng = np.random.default_rng(12345)
+    counts = [first]
+    for _ in range(8):
+        perm = prng.permutation(A.n)
+        P = sp.csr_matrix((np.ones(A.n), (np.arange(A.n), perm)), shape=(A.n, A.n))
+        Sp = (P @ S @ P.T).tocsr(); Sp.sort_indices()
+        Ap = O.Csr(A.n, (Sp.indptr + base).astype(np.int32), (Sp.indices + base).astype(np.int32), Sp.data.copy(), A.n)
+        bp = np.asarray(P @ b).ravel()
+        if loop == 0: _, sp_ = O.pbicgstab(Ap, bp, vm=O.ilu0(Ap) if precond else None, maxit=500, tol=1e-9)
+        elif loop == 2: _, sp_ = O.pipelined_bicgstab(Ap, bp, maxit=500, tol=1e-9)
+        else: _, _, sp_ = O.pbicgstab2(Ap, bp, maxit=500, tol=1e-9)
+        if sp_.converged: counts.append(sp_.iters)
+    return min(counts), max(counts)
+
+
 for case in range(ncase):
     n = int(rng.integers(1, 40000))
     per = float(rng.choice([1.5, 4, 9, 30, 80]))
@@ -76,10 +98,17 @@ for case in range(ncase):
             if bool(so.converged) and not bool(st.converged) and so.iters < 400: msgs.append("loop%d pc%d GPU did not converge, oracle did in %d" % (loop, precond, so.iters))
             elif bool(st.converged) != bool(so.converged) and not long_run: msgs.append("loop%d pc%d converged %d vs %d" % (loop, precond, st.converged, so.converged))
             if st.converged and so.converged:
-                # (the pipelined loop's longer recurrences wander further near the attainable accuracy: 30 %)
-                # (33 vs 39 iterations were seen with all three GPU loop forms agreeing among themselves: 20 %)
-                lim = so.iters if long_run else max(2, (0.3 if loop == 2 else 0.2) * so.iters)
-                if abs(st.iters - so.iters) > lim: msgs.append("loop%d pc%d iters %d vs %d" % (loop, precond, st.iters, so.iters))
+                # iteration count within +-10 % (>= +-2) of the CPU restatement.  BiCGSTAB amplifies rounding
+                # differences on some systems (seed 202 case 77: histories equal to 1e-11 up to iteration 5, 1e-3 apart at
+                # iteration 10, unrelated from 25 on; the oracle's OWN count moves between 31 and 41 over 24 symmetric
+                # permutations of the system, 33...39 when b is scaled by one ulp; the GPU needs 33) -- so a count outside
+                # the band is a finding only if it is also outside the band around the oracle's own spread over other
+                # summation orders (8 symmetric permutations of the same system)
+                lim = so.iters if long_run else max(2, 0.1 * so.iters)
+                if abs(st.iters - so.iters) > lim:
+                    lo, hi = oracle_spread(A, b, loop, precond, so.iters)
+                    if not (lo - max(2, 0.1 * lo) <= st.iters <= hi + max(2, 0.1 * hi)):
+                        msgs.append("loop%d pc%d iters %d vs %d (oracle over other summation orders: %d..%d)" % (loop, precond, st.iters, so.iters, lo, hi))
             if st.converged:
                 if so.converged and np.linalg.norm(xg - xo) > 1e-5 * np.linalg.norm(xo): msgs.append("loop%d pc%d x differs" % (loop, precond))
                 if np.linalg.norm(b - O.spmv(A, xg)) > 1e-7 * so.nrm0 + 1e-300: msgs.append("loop%d pc%d residual" % (loop, precond))
