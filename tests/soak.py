@@ -16,12 +16,17 @@ dicts = 0
 
 def oracle_spread(A, b, loop, precond, first):
     """iteration counts of the oracle's loop on P A P^T, P b for 8 random permutations P: the same system in exact
-    arithmetic, other summation orders in the dots and row sums"""
+    arithmetic, other summation orders in the dots and row sums.  (With ILU(0), whose factors depend on the ordering, b
+    is scaled by 1 + k ulp instead: the same solution path up to rounding-sized input changes.)"""
     base = int(A.rowptr[0])
     S = sp.csr_matrix((A.val, A.colidx - base, A.rowptr - base), shape=(A.n, A.n))
     prng = np.random.default_rng(12345)
     counts = [first]
-    for _ in range(8):
+    for k in range(8):
+        if precond:
+            _, sp_ = O.pbicgstab(A, b * (1.0 + (k - 4 + (k >= 4)) * 1.1e-16), vm=O.ilu0(A), maxit=500, tol=1e-9)
+            if sp_.converged: counts.append(sp_.iters)
+            continue
         perm = prng.permutation(A.n)
         P = sp.csr_matrix((np.ones(A.n), (np.arange(A.n), perm)), shape=(A.n, A.n))
         Sp = (P @ S @ P.T).tocsr(); Sp.sort_indices()
