@@ -341,11 +341,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_ilu0_level_fast(int row_begin, i
 }
 
 // ---------------------------------------------------------------- triangular solves
-// out[row] = (rhs[row] - sum_k val[k] out[col[k]]) * dinv   for the permuted rows [r0, r1).
+// out[o(pr)] = (rhs[i(pr)] - sum_k val[k] out[col[k]]) * dinv   for the permuted rows [r0, r1).
+// Index spaces: a permuted row pr reads rhs at rhs_of[pr] and writes out at out_of[pr] (a nullptr map = pr itself);
+// the stored columns are indices into `out`.  Factors in ORIGINAL index space have rhs_of = out_of = row_of; factors
+// in LEVEL-MAJOR space (hybrid, TriFactor::lm) have out_of = nullptr -- the solve writes a contiguous stream -- and
+// rhs_of = nullptr (L: the right-hand side is in L's space) or the U-position -> L-position map (U).
 // LANES lanes per row, exactly the SpMV inner loop; rows of one level are independent.
 template <int LANES>
 __device__ __forceinline__ void trsv_rows(int r0, int r1, int first, int stride, const int *frp, const int *fci,
-                                          const double *fval, const int *row_of, const double *dinv,
+                                          const double *fval, const int *rhs_of, const int *out_of, const double *dinv,
                                           const double *far, const double *rhs, double *out)
 {
     const int lane = threadIdx.x & (LANES - 1);
@@ -356,23 +360,22 @@ __device__ __forceinline__ void trsv_rows(int r0, int r1, int first, int stride,
 #pragma unroll
         for (int o = LANES / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         if (lane == 0) {
-            const int r = row_of[pr];
-            double v = rhs[r] - sum;
+            double v = rhs[rhs_of ? rhs_of[pr] : pr] - sum;
             if (far) v -= far[pr];              // entries whose column lies in an earlier group
             if (dinv) v *= dinv[pr];
-            out[r] = v;
+            out[out_of ? out_of[pr] : pr] = v;
         }
     }
 }
 
 template <int LANES>
 __global__ __launch_bounds__(kBlock) void k_trsv_level(int r0, int r1, const int *frp, const int *fci,
-                                                       const double *fval, const int *row_of,
+                                                       const double *fval, const int *rhs_of, const int *out_of,
                                                        const double *dinv, const double *far, const double *rhs,
                                                        double *out)
 {
     constexpr int RPB = kBlock / LANES;
-    trsv_rows<LANES>(r0, r1, blockIdx.x * RPB + threadIdx.x / LANES, gridDim.x * RPB, frp, fci, fval, row_of,
+    trsv_rows<LANES>(r0, r1, blockIdx.x * RPB + threadIdx.x / LANES, gridDim.x * RPB, frp, fci, fval, rhs_of, out_of,
                      dinv, far, rhs, out);
 }
 
@@ -381,12 +384,12 @@ __global__ __launch_bounds__(kBlock) void k_trsv_level(int r0, int r1, const int
 template <int LANES>
 __global__ __launch_bounds__(kBlock) void k_trsv_small_levels(int l0, int l1, const int *level_ptr,
                                                               const int *frp, const int *fci, const double *fval,
-                                                              const int *row_of, const double *dinv,
+                                                              const int *rhs_of, const int *out_of, const double *dinv,
                                                               const double *far, const double *rhs, double *out)
 {
     constexpr int RPB = kBlock / LANES;
     for (int l = l0; l < l1; l++) {
-        trsv_rows<LANES>(level_ptr[l], level_ptr[l + 1], threadIdx.x / LANES, RPB, frp, fci, fval, row_of, dinv,
+        trsv_rows<LANES>(level_ptr[l], level_ptr[l + 1], threadIdx.x / LANES, RPB, frp, fci, fval, rhs_of, out_of, dinv,
                          far, rhs, out);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_not_ready(long long n, unsigned
 
 template <int LANES, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_trsv_syncfree(int r0, int r1, const int *frp, const int *fci,
-                                                          const double *fval, const int *row_of,
+                                                          const double *fval, const int *rhs_of, const int *out_of,
                                                           const double *dinv, const double *far,
                                                           const double *rhs, double *out, int *err, int spin_limit,
                                                           int nap, unsigned *ticket, int steps)
@@ -460,8 +463,8 @@ __global__ __launch_bounds__(BLOCK) void k_trsv_syncfree(int r0, int r1, const i
     int r = 0;
     double base = 0.0, fr = 0.0, di = 1.0;
     if (valid && lane == 0) {
-        r = row_of[pr];
-        base = rhs[r];
+        r = out_of ? out_of[pr] : pr;
+        base = rhs[rhs_of ? rhs_of[pr] : pr];
         if (far) fr = far[pr];
         if (dinv) di = dinv[pr];
     }
@@ -616,6 +619,8 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
     std::vector<PbPlan> far;               // far[g]: rows of group g x columns of groups < g
     double *far_buf = nullptr;             // n doubles in level-major row order: far_g . out
     std::vector<int> lev_host;             // level of every original row (kept until the split)
+    std::vector<int> row_of_host;          // original row of every level-major position (kept until the permuted matrix is built)
+    bool want_hybrid = false;              // this factor alone would take the hybrid solve (the two factors decide together)
     bool syncfree = false;                 // one dependency-driven launch per group instead of one launch per level
     int spin_limit = kSpinLimit;
     int nap = 2;                           // s_sleep between polls (CUDAMAT_TRSV_NAP = 0, 1, 2, 4)
@@ -630,6 +635,11 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
 struct IluPlans {
     cm::TriHost L, U;
     int *err_host = nullptr, *err_dev = nullptr;   // pinned word a timed-out spin of k_trsv_syncfree sets
+    // level-major index spaces (both factors hybrid): U-position of every original row (the column map of the permuted
+    // matrix, solver.hip ensure_perm_matrix), scratch vectors of the original-space wrapper (precond_apply_any)
+    int *posU = nullptr;
+    double *perm_a = nullptr, *perm_b = nullptr;
+    std::vector<int> h_rp;                         // host copy of the matrix row pointers (until the permuted matrix is built)
 };
 
 static IluPlans *plans_of(cudamat_solver *s, bool create)
@@ -645,6 +655,7 @@ static void free_factor(TriFactor &F)
     void *ptrs[] = {F.rp, F.ci, F.val, F.row_of, F.dinv};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    if (F.lm && F.rhs_of) hipFree(F.rhs_of);       // (in original space the maps alias row_of)
     F = TriFactor();
 }
 
@@ -652,6 +663,11 @@ int ilu0_release(cudamat_solver *s)
 {
     free_factor(s->L);
     free_factor(s->U);
+    pb_free(&s->pb_perm);
+    valdict_free(&s->vd_perm);
+    if (s->x_perm) { hipFree(s->x_perm); s->x_perm = nullptr; }
+    if (s->b_perm) { hipFree(s->b_perm); s->b_perm = nullptr; }
+    s->perm_ready = false;
     if (s->lu) hipFree(s->lu);
     if (s->diag_pos) hipFree(s->diag_pos);
     if (s->pm_owned) {
@@ -676,6 +692,9 @@ int ilu0_release(cudamat_solver *s)
             if (h->tickets) hipFree(h->tickets);
         }
         if (pl->err_host) hipHostFree(pl->err_host);
+        if (pl->posU) hipFree(pl->posU);
+        if (pl->perm_a) hipFree(pl->perm_a);
+        if (pl->perm_b) hipFree(pl->perm_b);
         delete pl;
         s->ilu_plans = nullptr;
     }
@@ -761,6 +780,9 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
     if (upper) CM_TRY(dalloc(&F.dinv, (size_t)n));
     CM_HIP(hipMemcpy(F.rp, frp.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
     if (n) CM_HIP(hipMemcpy(F.row_of, row_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    F.rhs_of = F.out_of = F.row_of;            // original index space (until both factors go level-major, ilu0_setup)
+    F.lm = false;
+    H.row_of_host.swap(row_of);
     CM_TRY(dalloc(&H.level_ptr_dev, (size_t)nlev + 1));
     CM_HIP(hipMemcpy(H.level_ptr_dev, F.level_ptr.data(), sizeof(int) * ((size_t)nlev + 1), hipMemcpyHostToDevice));
     CM_STAMP("factor arrays alloc + upload");
@@ -769,13 +791,20 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
         const int v = atoi(e);
         if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) H.lanes = v;
     }
-    // groups of consecutive levels for the hybrid solve: only for big factors with many wide levels whose
-    // columns are scattered (the gather-bound case); ~24 levels per group leaves ~15-20 % of the entries near
+    // the hybrid solve is for big factors with many wide levels whose columns are scattered (the gather-bound case);
+    // the two factors decide together (ilu0_setup): they share the level-major index spaces
     H.lev_host.swap(lev);
     const char *hy = getenv("CUDAMAT_TRSV_HYBRID");
-    const bool want = hy ? hy[0] == '1' : (n >= 500000 && F.nnz >= (8 << 20) && nlev >= 16 && n / nlev >= 16384);
+    H.want_hybrid = nlev >= 4 && (hy ? hy[0] == '1' : (n >= 500000 && F.nnz >= (8 << 20) && nlev >= 16 && n / nlev >= 16384));
+    return CUDAMAT_OK;
+}
+
+// groups of consecutive levels (hybrid: ~24 levels per group leaves ~15-20 % of the entries near) and the launch plan
+static void plan_groups(const TriFactor &F, TriHost &H, bool hybrid)
+{
+    const int nlev = F.nlevels;
     int K = 1;
-    if (want && nlev >= 4) {
+    if (hybrid) {
         K = nlev / 24;
         if (K < 2) K = 2;
         if (K > 16) K = 16;
@@ -805,7 +834,6 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
             l = e;
         }
     }
-    return CUDAMAT_OK;
 }
 
 // ---- hybrid split of a level-major factor into near (same group) and far (earlier groups) entries
@@ -823,8 +851,11 @@ __global__ __launch_bounds__(kBlock) void k_split_count(int n, const int *frp, c
     cnt_far[pr] = nf;
 }
 
+// pos: level-major position of every original row -- the stored columns become indices into the level-major `out`.
+// Near entries keep their order (a row is still summed in its original column order); far entries are sorted by
+// their new column afterwards (k_sort_rows: the blocked builder needs increasing columns).
 __global__ __launch_bounds__(kBlock) void k_split_fill(int n, const int *frp, const int *fci, const double *fval,
-                                                       const int *row_of, const unsigned char *grp,
+                                                       const int *row_of, const unsigned char *grp, const int *pos,
                                                        const int *nrp, int *nci, double *nval, const int *qrp,
                                                        int *qci, double *qval)
 {
@@ -834,12 +865,67 @@ __global__ __launch_bounds__(kBlock) void k_split_fill(int n, const int *frp, co
     int on = nrp[pr], of = qrp[pr];
     for (int k = frp[pr]; k < frp[pr + 1]; k++) {
         const int c = fci[k];
-        if (grp[c] == g) { nci[on] = c; nval[on++] = fval[k]; }
-        else { qci[of] = c; qval[of++] = fval[k]; }
+        if (grp[c] == g) { nci[on] = pos[c]; nval[on++] = fval[k]; }
+        else { qci[of] = pos[c]; qval[of++] = fval[k]; }
     }
 }
 
-static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H)
+// pos[row_of[pr]] = pr
+__global__ __launch_bounds__(kBlock) void k_invert_perm(int n, const int *row_of, int *pos)
+{
+    const int pr = blockIdx.x * kBlock + threadIdx.x;
+    if (pr < n) pos[row_of[pr]] = pr;
+}
+
+// map[pr] = pos[row_of[pr]]   (position in one ordering of the row at position pr of another)
+__global__ __launch_bounds__(kBlock) void k_compose_perm(int n, const int *row_of, const int *pos, int *map)
+{
+    const int pr = blockIdx.x * kBlock + threadIdx.x;
+    if (pr < n) map[pr] = pos[row_of[pr]];
+}
+
+// Rows re-ordered by a new column numbering: destination row pr takes the entries of source row src_of[pr] (nullptr: pr),
+// columns relabelled through colmap (nullptr: kept), sorted by the new column.  One wavefront per row; a row's new
+// columns are staged in LDS (<= kSortRowMax entries) and every entry finds its rank by counting the smaller ones
+// (columns are distinct) -- O(len^2 / 64) wave steps, ~50 for the 50-entry rows this is for.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_sort_rows(int nrows, const int *src_rp, const int *src_of, const int *dst_rp,
+                                                         const int *ci, const double *val, const int *colmap, int *out_ci,
+                                                         double *out_val)
+{
+    __shared__ int cols[WAVES][kSortRowMax];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long pr = (long long)blockIdx.x * WAVES + wave;
+    if (pr >= nrows) return;
+    const int r = src_of ? src_of[pr] : (int)pr;
+    const int s0 = src_rp[r], len = src_rp[r + 1] - s0, d0 = dst_rp[pr];
+    int *c = cols[wave];
+    for (int k = lane; k < len; k += 64) {
+        const int col = ci[s0 + k];
+        c[k] = colmap ? colmap[col] : col;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < len; k += 64) {
+        const int mine = c[k];
+        int rank = 0;
+        for (int j = 0; j < len; j++) rank += c[j] < mine ? 1 : 0;
+        out_ci[d0 + rank] = mine;
+        out_val[d0 + rank] = val[s0 + k];
+    }
+}
+
+int launch_sort_rows(hipStream_t st, int nrows, const int *src_rp, const int *src_of, const int *dst_rp, const int *ci,
+                     const double *val, const int *colmap, int *out_ci, double *out_val)
+{
+    if (nrows <= 0) return CUDAMAT_OK;
+    hipLaunchKernelGGL(k_sort_rows<4>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, nrows, src_rp, src_of, dst_rp, ci, val,
+                       colmap, out_ci, out_val);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *pos)
 {
     if (!H.hybrid) return CUDAMAT_OK;
     hipStream_t st = s->ctx->stream;
@@ -855,8 +941,8 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H)
         for (int i = 0; i < n; i++) hg[(size_t)i] = g_of_level[(size_t)H.lev_host[(size_t)i]];
     }
     unsigned char *d_grp = nullptr;
-    int *d_cn = nullptr, *d_cf = nullptr, *nrp = nullptr, *qrp = nullptr, *nci = nullptr, *qci = nullptr;
-    double *nval = nullptr, *qval = nullptr;
+    int *d_cn = nullptr, *d_cf = nullptr, *nrp = nullptr, *qrp = nullptr, *nci = nullptr, *qci = nullptr, *qci2 = nullptr;
+    double *nval = nullptr, *qval = nullptr, *qval2 = nullptr;
     int rc = CUDAMAT_OK;
     do {
         if ((rc = dalloc(&d_grp, (size_t)n))) break;
@@ -883,17 +969,24 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H)
         if ((rc = dalloc(&qval, (size_t)nnz_far))) break;
         if (hipMemcpy(nrp, hn.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(qrp, hf.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
-        hipLaunchKernelGGL(k_split_fill, dim3(grid), dim3(kBlock), 0, st, n, F.rp, F.ci, F.val, F.row_of, d_grp, nrp, nci,
+        hipLaunchKernelGGL(k_split_fill, dim3(grid), dim3(kBlock), 0, st, n, F.rp, F.ci, F.val, F.row_of, d_grp, pos, nrp, nci,
                            nval, qrp, qci, qval);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("factor split failed"); break; }
         CM_STAMP("split fill");
-        // one blocked SpMV plan per group: rows of the group (level-major, contiguous) x all columns
+        // the far rows in increasing (level-major) column order, as the blocked builder needs them
+        if ((rc = dalloc(&qci2, (size_t)nnz_far))) break;
+        if ((rc = dalloc(&qval2, (size_t)nnz_far))) break;
+        if ((rc = launch_sort_rows(st, n, qrp, nullptr, qrp, qci, qval, nullptr, qci2, qval2))) break;
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("far row sort failed"); break; }
+        CM_STAMP("far rows sorted by position");
+        // one blocked SpMV plan per group: rows of the group (level-major, contiguous) x the columns of the EARLIER
+        // groups -- in level-major space those are the positions [0, r0), so only that prefix of `out` is tiled
         H.far.assign((size_t)K, PbPlan());
         for (int g = 1; g < K && !rc; g++) {
             const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)g]], r1 = F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]];
             const int64_t cnt = (int64_t)hf[(size_t)r1] - hf[(size_t)r0];
             if (r1 <= r0 || cnt <= 0) continue;
-            rc = pb_build(st, r1 - r0, s->n, cnt, qrp + r0, qci, qval, &H.far[(size_t)g]);   // square: columns = local rows
+            rc = pb_build(st, r1 - r0, r0, cnt, qrp + r0, qci2, qval2, &H.far[(size_t)g]);
         }
         CM_STAMP("far plans (pb_build)");
         if (rc) break;
@@ -906,7 +999,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H)
         nrp = nullptr; nci = nullptr; nval = nullptr;
         H.lanes = pick_lanes(n ? (double)F.nnz / n : 1.0);
     } while (0);
-    void *tmp[] = {d_grp, d_cn, d_cf, nrp, qrp, nci, qci, nval, qval};
+    void *tmp[] = {d_grp, d_cn, d_cf, nrp, qrp, nci, qci, nval, qval, qci2, qval2};
     for (void *q : tmp)
         if (q) hipFree(q);
     H.lev_host.clear();
@@ -1067,6 +1160,15 @@ int ilu0_setup(cudamat_solver *s, bool block)
         s->t_analysis_l = now_s() - t0;
         const double tu = now_s();
         if ((rc = build_levels(s, true, d_lev, d_flags, s->U, pl->U, h_rp, h_diag, pl->err_host, pl->err_dev))) break;
+        int maxrow_all = 0;
+        for (int i = 0; i < n; i++) maxrow_all = std::max(maxrow_all, h_rp[(size_t)i + 1] - h_rp[(size_t)i]);
+        {
+            // the two factors take the hybrid solve TOGETHER: they then share the level-major index spaces (L's output
+            // feeds U's right-hand side, U's output the permuted matrix of the preconditioned loop)
+            const bool hybrid = pl->L.want_hybrid && pl->U.want_hybrid && maxrow_all <= kSortRowMax;
+            plan_groups(s->L, pl->L, hybrid);
+            plan_groups(s->U, pl->U, hybrid);
+        }
         s->t_analysis_u = now_s() - tu;
         s->t_analysis = now_s() - t0;
         // ---- factorisation on a copy of A's values (pbicgstab.cu:316, :356-363)
@@ -1075,8 +1177,7 @@ int ilu0_setup(cudamat_solver *s, bool block)
         if (hipMemcpyAsync(s->lu, s->pm_val, sizeof(double) * (size_t)s->pm_nnz, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             rc = CUDAMAT_ERR_HIP; set_error("copy of A values failed"); break;
         }
-        int maxrow = 0;
-        for (int i = 0; i < n; i++) maxrow = std::max(maxrow, h_rp[(size_t)i + 1] - h_rp[(size_t)i]);
+        const int maxrow = maxrow_all;
         const int cap = ((maxrow + 63) / 64) * 64 + 64;
         const bool one_wave = cap > 2048;
         const char *slow = getenv("CUDAMAT_ILU0_SIMPLE");
@@ -1117,8 +1218,44 @@ int ilu0_setup(cudamat_solver *s, bool block)
         if ((rc = fill_factor(s, true, s->U))) break;
         if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("factor fill failed"); break; }
         CM_STAMP("factor fill");
-        if ((rc = split_factor(s, s->L, pl->L))) break;
-        if ((rc = split_factor(s, s->U, pl->U))) break;
+        if (pl->L.hybrid && pl->U.hybrid) {
+            // level-major index spaces: position of every original row in L's and in U's order
+            int *posL = nullptr;
+            const unsigned gp = (unsigned)((n + kBlock - 1) / kBlock);
+            if ((rc = dalloc(&posL, (size_t)n))) break;
+            if ((rc = dalloc(&pl->posU, (size_t)n))) { hipFree(posL); break; }
+            hipLaunchKernelGGL(k_invert_perm, dim3(gp), dim3(kBlock), 0, st, n, s->L.row_of, posL);
+            hipLaunchKernelGGL(k_invert_perm, dim3(gp), dim3(kBlock), 0, st, n, s->U.row_of, pl->posU);
+            rc = split_factor(s, s->L, pl->L, posL);
+            if (!rc) rc = split_factor(s, s->U, pl->U, pl->posU);
+            int *mapUL = nullptr;
+            if (!rc && pl->L.hybrid && pl->U.hybrid) rc = dalloc(&mapUL, (size_t)n);
+            if (!rc && mapUL) {
+                hipLaunchKernelGGL(k_compose_perm, dim3(gp), dim3(kBlock), 0, st, n, s->U.row_of, posL, mapUL);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("permutation maps failed"); }
+            }
+            hipFree(posL);
+            if (rc) { if (mapUL) hipFree(mapUL); break; }
+            if (!(pl->L.hybrid && pl->U.hybrid)) {
+                // (split_factor fell back on one side: out of memory for the blocked copies) -- a half-split pair has no
+                // consistent index space
+                set_error("ILU(0): not enough device memory for the far/near split of the factors");
+                rc = CUDAMAT_ERR_NOMEM;
+                break;
+            }
+            s->L.lm = s->U.lm = true;
+            s->L.rhs_of = s->L.out_of = nullptr;       // L: right-hand side and solution in L's level-major space
+            s->U.rhs_of = mapUL;                       // U: right-hand side in L's space, solution in U's
+            s->U.out_of = nullptr;
+            if ((rc = dalloc(&pl->perm_a, (size_t)n))) break;
+            if ((rc = dalloc(&pl->perm_b, (size_t)n))) break;
+            pl->h_rp = h_rp;                           // for the permuted matrix of the preconditioned loop (built at its first use)
+        } else {
+            pl->L.row_of_host.clear(); pl->L.row_of_host.shrink_to_fit();
+            pl->L.lev_host.clear(); pl->L.lev_host.shrink_to_fit();
+        }
+        pl->U.row_of_host.clear(); pl->U.row_of_host.shrink_to_fit();
+        pl->U.lev_host.clear(); pl->U.lev_host.shrink_to_fit();
         s->t_factor = now_s() - t1;
         // solve form: one dependency-driven launch per group (default whenever there is more than one level
         // to chain), or one launch per level / run of small levels (CUDAMAT_TRSV_SYNCFREE=0)
@@ -1210,10 +1347,10 @@ static int launch_trsv_segments(hipStream_t st, const TriFactor &F, const TriHos
             int grid = (r1 - r0 + RPB - 1) / RPB;
             if (grid > 4096) grid = 4096;
             hipLaunchKernelGGL(k_trsv_level<LANES>, dim3(grid), dim3(kBlock), 0, st, r0, r1, F.rp, F.ci, F.val,
-                               F.row_of, F.dinv, far, rhs, out);
+                               F.rhs_of, F.out_of, F.dinv, far, rhs, out);
         } else {
             hipLaunchKernelGGL(k_trsv_small_levels<LANES>, dim3(1), dim3(kBlock), 0, st, l0, l1, H.level_ptr_dev,
-                               F.rp, F.ci, F.val, F.row_of, F.dinv, far, rhs, out);
+                               F.rp, F.ci, F.val, F.rhs_of, F.out_of, F.dinv, far, rhs, out);
         }
     }
     return CUDAMAT_OK;
@@ -1254,7 +1391,7 @@ static int launch_trsv_syncfree_b(hipStream_t st, const TriFactor &F, const TriH
         const size_t lds_pad = (size_t)(152 * 1024) / (size_t)per_cu;
         CM_TRY(set_max_lds((const void *)k_trsv_syncfree<LANES, BLOCK>));
         hipLaunchKernelGGL((k_trsv_syncfree<LANES, BLOCK>), dim3(grid), dim3(BLOCK), lds_pad, st, r0, r1, F.rp, F.ci, F.val,
-                           F.row_of, F.dinv, far, rhs, out, err, H.spin_limit, H.nap, H.tickets + g, steps);
+                           F.rhs_of, F.out_of, F.dinv, far, rhs, out, err, H.spin_limit, H.nap, H.tickets + g, steps);
     }
     return CUDAMAT_OK;
 }
@@ -1352,6 +1489,105 @@ int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *
     }
     CM_TRY(rc);
     CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// ---- vectors between the original row numbering and the level-major spaces
+__global__ __launch_bounds__(kBlock) void k_perm_gather(long long n, const int *map, const double *in, double *out)
+{
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) out[i] = in[map[i]];
+}
+__global__ __launch_bounds__(kBlock) void k_perm_scatter(long long n, const int *map, const double *in, double *out)
+{
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) out[map[i]] = in[i];
+}
+
+static unsigned perm_grid(int n)
+{
+    long long g = ((long long)n + kBlock - 1) / kBlock;
+    return (unsigned)(g < 1 ? 1 : g > 4096 ? 4096 : g);
+}
+
+// out[pr] = in[row at position pr of L's (upper: U's) level-major order]
+int perm_to_space(cudamat_solver *s, bool upper, const double *in, double *out)
+{
+    const TriFactor &F = upper ? s->U : s->L;
+    hipLaunchKernelGGL(k_perm_gather, dim3(perm_grid(s->n)), dim3(kBlock), 0, s->ctx->stream, (long long)s->n, F.row_of, in, out);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// out[row at position pr] = in[pr]
+int perm_from_space(cudamat_solver *s, bool upper, const double *in, double *out)
+{
+    const TriFactor &F = upper ? s->U : s->L;
+    hipLaunchKernelGGL(k_perm_scatter, dim3(perm_grid(s->n)), dim3(kBlock), 0, s->ctx->stream, (long long)s->n, F.row_of, in, out);
+    CM_HIP(hipGetLastError());
+    return CUDAMAT_OK;
+}
+
+// M^-1 on vectors in ORIGINAL numbering while the factors live in level-major spaces: permute in, solve, permute out
+int precond_apply_original(cudamat_solver *s, const double *in, double *tmp, double *out)
+{
+    IluPlans *pl = plans_of(s, false);
+    if (!pl || !pl->perm_a || !pl->perm_b) { set_error("level-major scratch vectors missing"); return CUDAMAT_ERR_ARG; }
+    CM_TRY(perm_to_space(s, false, in, pl->perm_a));
+    CM_TRY(trsv_apply(s, s->L, false, pl->perm_a, tmp));
+    CM_TRY(trsv_apply(s, s->U, true, tmp, pl->perm_b));
+    return perm_from_space(s, true, pl->perm_b, out);
+}
+
+// The solver's matrix for the loop that runs IN the level-major spaces (solver.hip, "permuted loop"): rows in L's
+// order (the residual-side vectors r, p, v, t live there), columns in U's positions (the SpMV inputs M^-1 p, M^-1 r and
+// the iterate x live there), as a blocked two-phase copy.  Built once, at the first preconditioned solve.
+int ilu_perm_matrix(cudamat_solver *s)
+{
+    if (s->perm_ready) return CUDAMAT_OK;
+    IluPlans *pl = plans_of(s, false);
+    if (!pl || !s->L.lm || !s->U.lm || !pl->posU || pl->h_rp.empty() || pl->L.row_of_host.empty()) {
+        set_error("level-major index spaces are not available");
+        return CUDAMAT_ERR_ARG;
+    }
+    hipStream_t st = s->ctx->stream;
+    const int n = s->n;
+    const int64_t nnz = s->pm_nnz;
+    const double t0 = now_s();
+    std::vector<int> nrp((size_t)n + 1, 0);
+    for (int pr = 0; pr < n; pr++) {
+        const int r = pl->L.row_of_host[(size_t)pr];
+        nrp[(size_t)pr + 1] = nrp[(size_t)pr] + (pl->h_rp[(size_t)r + 1] - pl->h_rp[(size_t)r]);
+    }
+    int *d_rp = nullptr, *d_ci = nullptr;
+    double *d_val = nullptr;
+    int rc = CUDAMAT_OK;
+    do {
+        if ((rc = dalloc(&d_rp, (size_t)n + 1))) break;
+        if ((rc = dalloc(&d_ci, (size_t)nnz))) break;
+        if ((rc = dalloc(&d_val, (size_t)nnz))) break;
+        if (hipMemcpy(d_rp, nrp.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("row pointer upload failed"); break; }
+        if ((rc = launch_sort_rows(st, n, s->pm_rp, s->L.row_of, d_rp, s->pm_ci, s->pm_val, pl->posU, d_ci, d_val))) break;
+        if (nnz >= (1 << 20)) {
+            if ((rc = valdict_build(st, nnz, d_val, &s->vd_perm))) break;       // (n == 0 afterwards: no dictionary, fp64 values)
+        }
+        if ((rc = pb_build(st, n, n, nnz, d_rp, d_ci, d_val, &s->pb_perm, nullptr, &s->vd_perm))) break;
+        if (!s->x_perm && (rc = dalloc(&s->x_perm, (size_t)(s->n_pad > n ? s->n_pad : n)))) break;
+        if (!s->b_perm && (rc = dalloc(&s->b_perm, (size_t)(s->n_pad > n ? s->n_pad : n)))) break;
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("permuted matrix build failed"); break; }
+    } while (0);
+    void *tmp[] = {d_rp, d_ci, d_val};
+    for (void *q : tmp)
+        if (q) hipFree(q);
+    if (rc) {
+        pb_free(&s->pb_perm);
+        return rc;
+    }
+    s->perm_ready = true;
+    pl->h_rp.clear(); pl->h_rp.shrink_to_fit();
+    pl->L.row_of_host.clear(); pl->L.row_of_host.shrink_to_fit();
+    hipFree(pl->posU);
+    pl->posU = nullptr;
+    s->t_perm_matrix = now_s() - t0;
+    if (verbose()) fprintf(stderr, "[cudamat] ilu0 permuted matrix (rows in L order, columns in U positions) %8.3f ms\n", s->t_perm_matrix * 1e3);
     return CUDAMAT_OK;
 }
 

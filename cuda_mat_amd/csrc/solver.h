@@ -22,6 +22,11 @@ struct TriFactor {                 // one triangular factor in level-major stora
     int *row_of = nullptr;         // device: original row id of permuted row
     double *dinv = nullptr;        // device: 1/diag in permuted order (upper only)
     int64_t nnz = 0;
+    // index spaces of a solve (ilu.hip trsv_rows): permuted row pr reads rhs[rhs_of[pr]], writes out[out_of[pr]]
+    // (nullptr = pr itself); `ci` holds indices into out.  Original space: both = row_of.  Level-major space (lm,
+    // hybrid factors): out_of = nullptr; rhs_of = nullptr for L, the U-position -> L-position map (owned) for U.
+    int *rhs_of = nullptr, *out_of = nullptr;
+    bool lm = false;
 };
 
 }  // namespace cm
@@ -117,6 +122,14 @@ struct cudamat_solver {
     int *diag_pos = nullptr;   // position of the diagonal in each row
     cm::TriFactor L, U;
     void *ilu_plans = nullptr;  // launch plans owned by ilu.hip
+    // the loop in level-major spaces (hybrid factors, one GPU): the matrix with rows in L's order and columns in U's
+    // positions as a blocked copy, b in L's space, x in U's
+    cm::PbPlan pb_perm{};
+    cm::ValDict vd_perm;
+    double *x_perm = nullptr, *b_perm = nullptr;
+    bool perm_ready = false;    // pb_perm is built
+    bool perm_active = false;   // the solve in progress runs in the level-major spaces (spmv_local uses pb_perm)
+    double t_perm_matrix = 0.0;
     double t_analysis = 0.0, t_factor = 0.0, t_analysis_l = 0.0, t_analysis_u = 0.0;
     int trsv_fallbacks = 0;     // solves redone level by level after a dependency-driven wait timed out
     cm::ValDict vd;             // value dictionary of the matrix (n == 0: more than 256 distinct values, or not looked yet)
@@ -129,9 +142,19 @@ struct cudamat_solver {
 };
 
 namespace cm {
+constexpr int kSortRowMax = 1024;     // longest row k_sort_rows stages (level-major index spaces need every row below it)
+int launch_sort_rows(hipStream_t st, int nrows, const int *src_rp, const int *src_of, const int *dst_rp, const int *ci,
+                     const double *val, const int *colmap, int *out_ci, double *out_val);
 int ilu0_setup(cudamat_solver *s, bool block);
 int ilu0_release(cudamat_solver *s);
+// rhs / out in the factor's own index spaces (TriFactor::rhs_of / out_of)
 int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *rhs, double *out);
+// level-major factors (TriFactor::lm): M^-1 on original-numbering vectors; vectors to / from L's (upper: U's) space;
+// the matrix of the loop that runs in those spaces
+int precond_apply_original(cudamat_solver *s, const double *in, double *tmp, double *out);
+int perm_to_space(cudamat_solver *s, bool upper, const double *in, double *out);
+int perm_from_space(cudamat_solver *s, bool upper, const double *in, double *out);
+int ilu_perm_matrix(cudamat_solver *s);
 int trsv_status(cudamat_solver *s);   // after a stream sync: did a dependency-driven solve give up waiting?
 bool trsv_syncfree_active(cudamat_solver *s);
 int trsv_form_code(cudamat_solver *s);           // 0 level launches, 1 dependency-driven, 2 single workgroup in LDS

@@ -430,6 +430,7 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
         for (int c = 0; c < p.chunks; c++) CM_HIP(hipStreamWaitEvent(st, s->ev_p1[c], 0));
         return launch_pb_phase2(st, p, a);
     }
+    if (s->perm_active) return launch_spmv_pb(s->ctx->stream, s->pb_perm, a);      // rows in L's space, columns in U's
     if (s->spmv_mode == 1) return launch_spmv_pb(s->ctx->stream, s->pb, a);
     if (s->spmv_mode == 2) return launch_spmv_sell(s->ctx->stream, s->sell, a);
     return launch_spmv(s->ctx->stream, s->plan, a);
@@ -448,6 +449,7 @@ static int ensure_valdict(cudamat_solver *s)
 // number of per-workgroup partial sums an SpMV launch leaves in `parts`
 static int spmv_parts(const cudamat_solver *s)
 {
+    if (s->perm_active) return s->pb_perm.NRB;
     return s->spmv_mode == 1 ? s->pb.NRB : s->spmv_mode == 2 ? s->sell.grid : plan_spmv_parts(s->plan);
 }
 
@@ -827,8 +829,11 @@ static hipEvent_t prof_event(cudamat_solver *s, size_t i)
     return s->prof_ev[i];
 }
 
-static int precond_apply(cudamat_solver *s, const double *in, double *tmp, double *out)
+// native: `in` is in L's level-major space and `out` leaves in U's (the loop that runs in those spaces); otherwise both
+// are in the caller's row numbering (level-major factors then permute on the way in and out)
+static int precond_apply(cudamat_solver *s, const double *in, double *tmp, double *out, bool native = false)
 {
+    if (s->L.lm && !native) return precond_apply_original(s, in, tmp, out);
     CM_TRY(trsv_apply(s, s->L, false, in, tmp));    // pbicgstab.cu:92-94 / :121-123
     CM_TRY(trsv_apply(s, s->U, true, tmp, out));    // pbicgstab.cu:96-98 / :125-127
     return CUDAMAT_OK;
@@ -863,6 +868,34 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
         if (rc_setup == CUDAMAT_OK && precond && (!s->has_ilu || (s->sharded && !s->ilu_block)))
             rc_setup = ilu0_setup(s, precond == CUDAMAT_PRECOND_BLOCK_ILU0);
         CM_TRY(setup_agree(s, rc_setup));        // sharded: every rank learns of a failure on any rank
+    }
+    // The loop in LEVEL-MAJOR SPACES (round 3).  With the hybrid triangular solves the factors live in level-major index
+    // spaces: L reads and writes streams in L's order, U writes a stream in U's order.  The reference loop
+    // (pbicgstab.cu:45-154) only ever combines vectors element by element within two families -- r, rw, p, v, t
+    // (residual side: outputs of A, inputs of L) and M^-1 p, M^-1 r, x (solution side: outputs of U, inputs of A) -- so
+    // the first family is kept in L's order, the second in U's, and A is stored with rows in L's order and columns in
+    // U's positions (ilu_perm_matrix).  Then no vector is permuted inside the loop: per M^-1 application the only indexed
+    // access left besides the near gathers is U reading its right-hand side from L's space (1 per row instead of 4).
+    // b and x0 are permuted on the way in, x on the way out.  One GPU, reference loop; CUDAMAT_TRSV_PERM=0 disables.
+    bool perm = false;
+    {
+        const char *pe = getenv("CUDAMAT_TRSV_PERM");
+        perm = precond == CUDAMAT_PRECOND_ILU0 && !s->sharded && loop == CUDAMAT_LOOP_PBICGSTAB && s->L.lm && s->U.lm && !s->d &&
+               !(pe && pe[0] == '0');
+        if (perm && !s->perm_ready) {
+            const int rcp = ilu_perm_matrix(s);
+            if (rcp == CUDAMAT_ERR_NOMEM) perm = false;          // no room for the second blocked copy: permute per application
+            else CM_TRY(rcp);
+        }
+    }
+    s->perm_active = perm;
+    struct PermOff { cudamat_solver *s; ~PermOff() { s->perm_active = false; } } perm_off{s};
+    double *const x_user = x;
+    if (perm) {
+        CM_TRY(perm_to_space(s, false, b, s->b_perm));
+        if (!(flags & CUDAMAT_FLAG_X0_ONES)) CM_TRY(perm_to_space(s, true, x, s->x_perm));
+        b = s->b_perm;
+        x = s->x_perm;
     }
 
     // residual history: two entries per iteration (half / full step) or one; capped at 2^20 entries (8 MB) -- a solve
@@ -1173,7 +1206,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
         const double *pw = s->p;
         if (precond) {                                            // :92-98
             if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(precond_apply(s, s->p, s->t, s->pw));
+            CM_TRY(precond_apply(s, s->p, s->t, s->pw, perm));
             if (profile) hipEventRecord(prof_event(s, pe++), st);
             pw = s->pw;
         }
@@ -1196,7 +1229,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             if (precond) {                                        // :116, :121-127
                 CM_TRY(launch_check(st, la, half_src, CHECK_HALF));
                 if (profile) hipEventRecord(prof_event(s, pe++), st);
-                CM_TRY(precond_apply(s, s->r, s->t, s->s));
+                CM_TRY(precond_apply(s, s->r, s->t, s->s, perm));
                 if (profile) hipEventRecord(prof_event(s, pe++), st);
                 sv = s->s;
                 if (profile) hipEventRecord(prof_event(s, pe++), st);
@@ -1262,6 +1295,10 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             *precond_gave_up = true;
             return CUDAMAT_OK;
         }
+    }
+    if (perm) {                              // the iterate leaves U's space
+        CM_TRY(perm_from_space(s, true, x, x_user));
+        CM_HIP(hipStreamSynchronize(st));
     }
     const LoopState fin = s->st_ring[0];
     if (pipelined && fin.state == 1) {      // left through the half step: the iterate is x + alpha p, kept in xh

@@ -617,6 +617,39 @@ def test_hybrid_triangular_solve_vs_oracle(cm, ctx, oracle, golden_dir, name, mo
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-5
 
 
+@pytest.mark.parametrize("name", ["rand20000x50", "real3000", "mat10000"])
+def test_loop_in_level_major_spaces_matches_the_permuting_loop(cm, ctx, oracle, golden_dir, name, monkeypatch):
+    """hybrid factors live in level-major index spaces; the reference loop then runs with its residual-side vectors in
+    L's order, its solution-side vectors in U's, and A stored with rows in L's order and columns in U's positions (no
+    vector is permuted inside the loop).  Same mathematics as the loop that permutes around every M^-1 application
+    (CUDAMAT_TRSV_PERM=0): same iteration count (+-1: the dot products are summed in another order), solutions equal to
+    1e-9, histories to 1e-8 over the first iterations; both agree with the oracle (solution 1e-5, count +-10 %)."""
+    monkeypatch.setenv("CUDAMAT_TRSV_HYBRID", "1")
+    if name == "rand20000x50":
+        A = oracle.rand_rows(20000, 50, 0x5EED)
+    elif name == "real3000":
+        A = _real_sparse(oracle, 3000, 0.004, 11, base=1)
+    else:
+        A = _load(oracle, golden_dir, name)
+    xs = 1.0 + np.sin(np.arange(A.n))
+    b = oracle.spmv(A, xs)
+    x0 = 1.0 + 0.25 * np.cos(np.arange(A.n))
+    xo, so, ho = oracle.pbicgstab(A, b, x0=x0, vm=oracle.ilu0(A), maxit=500, tol=1e-8, want_hist=True)
+    res = {}
+    for perm in ("1", "0"):
+        monkeypatch.setenv("CUDAMAT_TRSV_PERM", perm)
+        res[perm] = _solve_dev(cm, ctx, A, b, x0=x0, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PBICGSTAB, maxit=500, tol=1e-8)
+    (x1, st1, h1), (x0_, st0, h0) = res["1"], res["0"]
+    assert st1.converged and st0.converged and abs(st1.iters - st0.iters) <= 1
+    assert np.linalg.norm(x1 - x0_) / np.linalg.norm(x0_) <= 1e-9
+    k = min(len(h1), len(h0), 6)
+    np.testing.assert_allclose(h1[:k], h0[:k], rtol=1e-8)
+    np.testing.assert_allclose(h1[:k], ho[:k], rtol=1e-8)
+    assert abs(st1.iters - so.iters) <= max(2, 0.1 * so.iters)
+    assert np.linalg.norm(x1 - xo) / np.linalg.norm(xo) <= 1e-5
+    assert np.linalg.norm(b - oracle.spmv(A, x1)) <= 1e-7 * st1.nrm0
+
+
 def _chain_matrix(oracle, n, width, seed):
     """banded lower+upper coupling: row i depends on rows i-1 .. i-width -> n levels of one row each"""
     import scipy.sparse as sp
