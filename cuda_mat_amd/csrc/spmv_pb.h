@@ -31,6 +31,7 @@ struct PbPlan {
     int NW = 0;           // waves per phase-2 workgroup = sub-blocks per row block
     int SR = 0;           // rows per sub-block (one wave owns them)
     int LPS = 64;         // lanes per (sub-block, column block) segment in phase 2
+    int depth = 4;        // segment loads in flight per wave in phase 2
     int NSUB = 0;         // NRB * NW
     // entries in (column block, row block, row, column) order
     double *pv = nullptr;          // values (nullptr when the matrix has a value dictionary:)

@@ -261,7 +261,9 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     // lanes busy, but never fewer than 4096 waves (16 per CU) -- a shard of a row-partitioned matrix
     // has few entries per column block and would otherwise be latency-bound.
     double nsub_t = (double)nnz / ((double)p.NCB * 48.0);
-    if (nsub_t < 4096.0) nsub_t = 4096.0;
+    double min_waves = 4096.0;
+    if (const char *e = getenv("CUDAMAT_PB_MIN_WAVES")) { const double v = atof(e); if (v >= 256.0) min_waves = v; }
+    if (nsub_t < min_waves) nsub_t = min_waves;
     if (nsub_t > (double)n / 16.0) nsub_t = (double)n / 16.0;
     if (nsub_t < 4.0) nsub_t = 4.0;
     p.NW = nsub_t >= 4096.0 ? 16 : nsub_t >= 2048.0 ? 8 : 4;
@@ -279,6 +281,8 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     p.NSUB = p.NRB * p.NW;
     const double seg = (double)nnz / ((double)p.NCB * p.NSUB);      // mean entries per segment
     p.LPS = seg <= 6.0 ? 16 : seg <= 22.0 ? 32 : 64;
+    p.depth = 4;
+    if (const char *e = getenv("CUDAMAT_PB_DEPTH")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) p.depth = v; }
     if (p.NRB > kMaxParts || p.CB > 65536 || p.SR > 65536 || (size_t)p.RB * 8 > 150 * 1024 ||
         sizeof(int) * (size_t)kPbBuildWaves * p.NCB > 150 * 1024) {     // the analysis keeps one cursor per column block in LDS
         set_error("pb_build: matrix shape outside the blocked kernel's limits");
@@ -517,7 +521,8 @@ struct Pb2Args {
     const LoopState *st;
 };
 
-template <int NW, int LPS>
+// DEPTH: segment loads a wave issues before it consumes the first (4; 8 / 16 when few waves are resident: shards)
+template <int NW, int LPS, int DEPTH>
 __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) double yt[];   // NW * SR, then 2 * NW for the reduction
@@ -541,24 +546,24 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
         // LPS (its tail would land after the next block's head): such chunks take the 64-lane path.
         const bool grouped = LPS < 64 && !__any(myl > LPS);
         if (!grouped) {
-            for (int j = 0; j < lim; j += 4) {
-                int s[4], l[4];
-                double pv4[4];
-                int r4[4];
+            for (int j = 0; j < lim; j += DEPTH) {
+                int s[DEPTH], l[DEPTH];
+                double pv4[DEPTH];
+                int r4[DEPTH];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < DEPTH; u++) {
                     // lanes past `lim` carry length 0, so j + u may safely run to 63
                     s[u] = __builtin_amdgcn_readlane(mys, (j + u) & 63);
                     l[u] = __builtin_amdgcn_readlane(myl, (j + u) & 63);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < DEPTH; u++) {
                     const bool on = lane < l[u];
                     pv4[u] = on ? a.P[s[u] + lane] : 0.0;
                     r4[u] = on ? (int)a.pr[s[u] + lane] : 0;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < DEPTH; u++) {
                     if (lane < l[u]) unsafeAtomicAdd(&my[r4[u]], pv4[u]);
                     for (int off = 64 + lane; off < l[u]; off += 64)        // segments longer than a wave
                         unsafeAtomicAdd(&my[a.pr[s[u] + off]], a.P[s[u] + off]);
@@ -567,24 +572,24 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
         } else {
             constexpr int G = 64 / LPS;
             const int g = lane / LPS, li = lane % LPS;
-            for (int j = 0; j < lim; j += 4 * G) {
-                int s[4], l[4];
-                double pv4[4];
-                int r4[4];
+            for (int j = 0; j < lim; j += DEPTH * G) {
+                int s[DEPTH], l[DEPTH];
+                double pv4[DEPTH];
+                int r4[DEPTH];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < DEPTH; u++) {
                     const int cbi = j + u * G + g;
                     s[u] = __shfl(mys, cbi & 63, 64);
                     l[u] = cbi < 64 ? __shfl(myl, cbi & 63, 64) : 0;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < DEPTH; u++) {
                     const bool on = li < l[u];
                     pv4[u] = on ? a.P[s[u] + li] : 0.0;
                     r4[u] = on ? (int)a.pr[s[u] + li] : 0;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < DEPTH; u++)
                     if (li < l[u]) unsafeAtomicAdd(&my[r4[u]], pv4[u]);
             }
         }
@@ -682,10 +687,16 @@ int launch_pb_phase2(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
     b.y = a.y; b.dot = a.dot; b.w = a.w; b.parts = a.parts;
     b.st = a.loop.st;
     const size_t lds = sizeof(double) * ((size_t)p.NW * p.SR + 2 * (size_t)p.NW);
+#define CM_P2D(NWV, LPSV, DV)                                                                             \
+    do {                                                                                                  \
+        CM_TRY(set_max_lds((const void *)k_pb_phase2<NWV, LPSV, DV>));                                   \
+        hipLaunchKernelGGL((k_pb_phase2<NWV, LPSV, DV>), dim3(p.NRB), dim3(64 * NWV), lds, st, b);       \
+    } while (0)
 #define CM_P2(NWV, LPSV)                                                                                  \
     do {                                                                                                  \
-        CM_TRY(set_max_lds((const void *)k_pb_phase2<NWV, LPSV>));                                       \
-        hipLaunchKernelGGL((k_pb_phase2<NWV, LPSV>), dim3(p.NRB), dim3(64 * NWV), lds, st, b);           \
+        if (p.depth >= 16) CM_P2D(NWV, LPSV, 16);                                                         \
+        else if (p.depth >= 8) CM_P2D(NWV, LPSV, 8);                                                      \
+        else CM_P2D(NWV, LPSV, 4);                                                                        \
     } while (0)
 #define CM_P2_LPS(NWV)                                           \
     do {                                                         \
@@ -700,6 +711,7 @@ int launch_pb_phase2(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
     }
 #undef CM_P2_LPS
 #undef CM_P2
+#undef CM_P2D
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }

@@ -1372,7 +1372,7 @@ def test_drop_in_call_reuses_the_plan_of_the_previous_call(cm, oracle, monkeypat
     assert ok4 and st4.plan_reused == 0
     monkeypatch.delenv("CUDAMAT_PLAN_CACHE")
     # scattered columns: nothing is timed, and the full timing agrees with the shortcut
-    S = oracle.rand_rows(2_500_000, 9, 0x77)
+    S = oracle.rand_rows(4_000_000, 9, 0x77)       # mean column span 0.8 x 32 MB of x
     bs = oracle.spmv(S, oracle.xstar(S.n, 6))
     oks, xs_, dts, sts = cm.bicgstab(S.n, S.nnz, S.val, S.rowptr, S.colidx, bs, 200, 1e-8)
     assert oks and sts.plan_reused == 0 and sts.spmv_mode == 1 and sts.t_tune == 0
