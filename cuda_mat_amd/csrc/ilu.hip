@@ -799,13 +799,15 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
     return CUDAMAT_OK;
 }
 
-// groups of consecutive levels (hybrid: ~24 levels per group leaves ~15-20 % of the entries near) and the launch plan
+// groups of consecutive levels (hybrid: ~17 levels per group leaves ~15 % of the entries near; measured at C5, round 3:
+// 5 / 8 / 12 / 16 / 24 groups -> 4.85 / 4.79 / 5.03 / 5.54 / 6.57 ms per L^-1 U^-1 -- the near launches shrink with more
+// groups, the far SpMVs lose more on their shorter segments) and the launch plan
 static void plan_groups(const TriFactor &F, TriHost &H, bool hybrid)
 {
     const int nlev = F.nlevels;
     int K = 1;
     if (hybrid) {
-        K = nlev / 24;
+        K = nlev / 17;
         if (K < 2) K = 2;
         if (K > 16) K = 16;
         if (const char *e = getenv("CUDAMAT_TRSV_GROUPS")) {
