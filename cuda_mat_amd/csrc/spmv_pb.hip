@@ -375,9 +375,60 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
 }
 
 // ------------------------------------------------------------------ phase 1
+// The streaming loop and the memory counter (round 3, from the ISA).  gfx950 has ONE counter (vmcnt) for loads and
+// stores; the compiler cannot tell whether a pending operation it waits behind is a load or a store and puts
+// `s_waitcnt vmcnt(0)` in front of every use of a loaded value while a store is pending.  The plain loop below (4 steps:
+// 8 loads, then 4 x {wait, LDS reads, products, store}) therefore drains the wave's queue FOUR times per iteration --
+// each store's completion sits on the wave's path, a wave has ~2 KB in flight on average, 16 waves per compute unit (the
+// x tile fills the LDS) move 19.8 GB/s per unit: 1.83 ms for the 9.3 GB of a C4 launch (5.08 TB/s).  That looks
+// latency-bound, and the remedy was built: the hardware retires a wave's vector-memory operations in issue order, so with
+// loads and waits written as inline assembly (`s_waitcnt vmcnt(U)`: wait for the loads, leave the U younger stores in
+// flight) a wave keeps U = 4 loads AND 4 stores in flight at all times, no drain in the loop (ISA checked: 8 loads,
+// 4 stores, `s_waitcnt vmcnt(4)`, nothing else).  Bit-identical results -- and 7 % SLOWER on the GPU, twice in
+// alternation on one box (3.07 / 2.86 ms per SpMV against 2.85 / 2.67): as with the chunked body of the dictionary kernel
+// on fp64 values (round 2: 10 % slower), MORE traffic in flight per wave lowers this kernel's throughput.  So the launch
+// is not bound by its waves' round trips; its time is close to reading its input (5.3 GB at ~6 TB/s) plus writing its
+// output (4 GB at ~6 TB/s) one after the other, which is how the memory system treats a 10-read : 8-write mix.  The
+// pipelined form stays selectable (CUDAMAT_PB_PIPELINE=1) for other parts and mixes; the plain loop is the default.
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2d p1_load_vals(const double *p)
+{
+    v2d v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned p1_load_u32(const void *p)
+{
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned p1_load_u16(const void *p)
+{
+    unsigned v;
+    asm volatile("global_load_ushort %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// wait until all but the N youngest vector-memory operations of this wave are done; the loaded registers pass THROUGH the
+// statement, so that no use of them can be scheduled above it
+template <int N>
+__device__ __forceinline__ void p1_wait4(v2d &a, v2d &b, v2d &c, v2d &d, unsigned &e, unsigned &f, unsigned &g, unsigned &h)
+{
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void p1_wait4i(unsigned &a, unsigned &b, unsigned &c, unsigned &d, unsigned &e, unsigned &f, unsigned &g,
+                                          unsigned &h)
+{
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N) : "memory");
+}
+
+constexpr int kP1U = 4;                // steps per chunk of the pipelined loop (registers: 2 sets x 4 x (4 + 1))
+
 __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const int *col0, const int *list,
                                                           const int *cstart, const double *pv, const u16 *pc,
-                                                          double *P, const LoopState *st)
+                                                          double *P, const LoopState *st, int pipelined)
 {
     extern __shared__ __attribute__((aligned(16))) double xs[];
     if (st && st->state != 0) return;
@@ -387,9 +438,50 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const
     const int c0 = col0[cb], cn = col0[cb + 1] - c0;
     for (int i = threadIdx.x; i < cn; i += kP1Threads) xs[i] = x[c0 + i];
     __syncthreads();
-    // two entries per lane per step (16-byte value loads), four steps in flight
-    const int k0 = (s & ~1) + 2 * (int)threadIdx.x;
-    constexpr int STEP = 2 * kP1Threads;
+    constexpr int STEP = 2 * kP1Threads, U = kP1U, CH = U * STEP;
+    int k_plain = s & ~1;                                  // where the plain loop starts (pairs at even entries)
+    // ---- whole chunks, software-pipelined against the memory counter (see above)
+    const int a0 = (s + 1) & ~1;
+    const int nch = pipelined ? (e - a0) / CH : 0;         // (workgroup-uniform)
+    if (nch >= 2) {
+        if (threadIdx.x == 0 && s < a0) P[s] = pv[s] * xs[pc[s]];
+        const int t2 = 2 * (int)threadIdx.x;
+        v2d va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+        unsigned ca0, ca1, ca2, ca3, cb0, cb1, cb2, cb3;
+#define CM_P1_LOADS(V0, V1, V2, V3, C0, C1, C2, C3, K)                                              \
+        V0 = p1_load_vals(pv + (K));            C0 = p1_load_u32(pc + (K));                          \
+        V1 = p1_load_vals(pv + (K) + STEP);     C1 = p1_load_u32(pc + (K) + STEP);                   \
+        V2 = p1_load_vals(pv + (K) + 2 * STEP); C2 = p1_load_u32(pc + (K) + 2 * STEP);               \
+        V3 = p1_load_vals(pv + (K) + 3 * STEP); C3 = p1_load_u32(pc + (K) + 3 * STEP);
+#define CM_P1_PROD(O, V, C) O.x = V.x * xs[C & 0xffffu]; O.y = V.y * xs[C >> 16];
+#define CM_P1_STORES(O0, O1, O2, O3, K)                                                             \
+        *(v2d *)(P + (K)) = O0; *(v2d *)(P + (K) + STEP) = O1; *(v2d *)(P + (K) + 2 * STEP) = O2;   \
+        *(v2d *)(P + (K) + 3 * STEP) = O3;
+        int k = a0 + t2;
+        CM_P1_LOADS(va0, va1, va2, va3, ca0, ca1, ca2, ca3, k)
+        p1_wait4<0>(va0, va1, va2, va3, ca0, ca1, ca2, ca3);                  // (first chunk: nothing younger)
+        for (int i = 0; i < nch; i += 2) {
+            v2d o0, o1, o2, o3;
+            // chunk i lives in set A (already waited for)
+            CM_P1_PROD(o0, va0, ca0) CM_P1_PROD(o1, va1, ca1) CM_P1_PROD(o2, va2, ca2) CM_P1_PROD(o3, va3, ca3)
+            if (i + 1 < nch) { CM_P1_LOADS(vb0, vb1, vb2, vb3, cb0, cb1, cb2, cb3, k + CH) }
+            CM_P1_STORES(o0, o1, o2, o3, k)
+            if (i + 1 >= nch) break;
+            p1_wait4<U>(vb0, vb1, vb2, vb3, cb0, cb1, cb2, cb3);              // the U stores above stay in flight
+            CM_P1_PROD(o0, vb0, cb0) CM_P1_PROD(o1, vb1, cb1) CM_P1_PROD(o2, vb2, cb2) CM_P1_PROD(o3, vb3, cb3)
+            if (i + 2 < nch) { CM_P1_LOADS(va0, va1, va2, va3, ca0, ca1, ca2, ca3, k + 2 * CH) }
+            CM_P1_STORES(o0, o1, o2, o3, k + CH)
+            if (i + 2 < nch) p1_wait4<U>(va0, va1, va2, va3, ca0, ca1, ca2, ca3);
+            k += 2 * CH;
+        }
+#undef CM_P1_LOADS
+#undef CM_P1_PROD
+#undef CM_P1_STORES
+        k_plain = a0 + nch * CH;
+    }
+    // ---- the plain loop: two entries per lane per step (16-byte value loads), four steps in flight, every bound checked
+    const int lo = nch >= 2 ? k_plain : s;                 // entries below lo are done
+    const int k0 = k_plain + 2 * (int)threadIdx.x;
     for (int k = k0; k < e; k += 4 * STEP) {
         double2 v[4];
         ushort2 c[4];
@@ -397,7 +489,7 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int kk = k + u * STEP;
-            full[u] = kk >= s && kk + 1 < e;
+            full[u] = kk >= lo && kk + 1 < e;
             if (full[u]) {
                 v[u] = *(const double2 *)(pv + kk);
                 c[u] = *(const ushort2 *)(pc + kk);
@@ -412,8 +504,8 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const
                 o.y = v[u].y * xs[c[u].y];
                 *(double2 *)(P + kk) = o;
             } else {
-                if (kk >= s && kk < e) P[kk] = pv[kk] * xs[pc[kk]];
-                if (kk + 1 >= s && kk + 1 < e) P[kk + 1] = pv[kk + 1] * xs[pc[kk + 1]];
+                if (kk >= lo && kk < e) P[kk] = pv[kk] * xs[pc[kk]];
+                if (kk + 1 >= lo && kk + 1 < e) P[kk + 1] = pv[kk + 1] * xs[pc[kk + 1]];
             }
         }
     }
@@ -663,8 +755,9 @@ int launch_pb_phase1(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int par
         return CUDAMAT_OK;
     }
     CM_TRY(set_max_lds((const void *)k_pb_phase1));
+    static const int pipelined = [] { const char *e = getenv("CUDAMAT_PB_PIPELINE"); return e && e[0] == '1' ? 1 : 0; }();
     hipLaunchKernelGGL(k_pb_phase1, dim3(last - first), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x, p.col0,
-                       part < 0 ? (const int *)nullptr : p.order + first, p.cstart, p.pv, p.pc, p.P, a.loop.st);
+                       part < 0 ? (const int *)nullptr : p.order + first, p.cstart, p.pv, p.pc, p.P, a.loop.st, pipelined);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }
