@@ -737,22 +737,37 @@ def run_bench(args):
                 gbs = b_trsv / (out["trsv_ms_per_apply"] * 1e-3) / 1e9
                 out["trsv_roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_application": b_trsv}
-            # fabric bytes of the dependency-driven launches per application, from the committed counter passes of this
-            # workload (2 * FETCH_SIZE + WRITE_SIZE per launch: an UPPER bound here, the correction factor 2 holds for wide
-            # coalesced loads and these kernels gather 8 bytes per lane); launches per application = groups of L + groups of U
+            # fabric bytes per application of L^-1 U^-1, from the committed counter passes of this workload (2 * FETCH_SIZE +
+            # WRITE_SIZE per launch): the NEAR part (dependency-driven launches, one per group and factor; an UPPER bound: the
+            # correction factor 2 holds for wide coalesced loads and these kernels gather 8 bytes per lane) and the FAR part
+            # (the blocked SpMV phases of groups 1.., streams: 28 B per far entry + x tiles)
             if world == 1 and args.workload == "rand50" and args.rows == 10_000_000 and args.per_row == 50 and precond == cm.PRECOND_ILU0:
                 import glob
                 for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*ilu0", "pmc_fetch_write.json")), reverse=True):
                     pm = json.load(open(f))
-                    k = next((v for name, v in pm.items() if name.startswith("cm::k_trsv_syncfree") and isinstance(v, dict)
-                              and "hbm_bytes_per_launch_corrected" in v), None)
-                    if k is not None:
-                        groups = sum(max(2, min(16, nl // 24)) for nl in (st.n_levels_l, st.n_levels_u))
-                        out["trsv_traffic"] = {"kernel": "k_trsv_syncfree (near entries of every group)", "launches_per_application": groups,
-                                               "bytes_per_launch_upper_bound": k["hbm_bytes_per_launch_corrected"],
-                                               "bytes_per_application_upper_bound": groups * k["hbm_bytes_per_launch_corrected"],
-                                               "avg_launch_us": k["avg_us"], "source": os.path.relpath(f, ROOT),
-                                               "note": "the far entries go through 2 x (groups - 1) blocked SpMVs at 28 B per entry"}
+                    near = next((v for name, v in pm.items() if name.startswith("cm::k_trsv_syncfree") and isinstance(v, dict)
+                                 and "hbm_bytes_per_launch_corrected" in v), None)
+                    far = [v for name, v in pm.items() if name.startswith("cm::k_pb_phase") and "far part" in name and isinstance(v, dict)
+                           and "hbm_bytes_per_launch_corrected" in v]
+                    if near is not None and far:
+                        groups = [max(2, min(16, nl // 17)) for nl in (st.n_levels_l, st.n_levels_u)]      # ilu.hip plan_groups
+                        n_near = sum(groups)
+                        n_far = sum(g - 1 for g in groups)            # blocked SpMVs (phase 1 + phase 2 each) per application
+                        p1 = [v for name, v in pm.items() if name.startswith("cm::k_pb_phase1") and "far part" in name and isinstance(v, dict)]
+                        p2 = [v for name, v in pm.items() if name.startswith("cm::k_pb_phase2") and "far part" in name and isinstance(v, dict)]
+                        wavg = lambda vs, key: sum(v[key] * v["launches"] for v in vs) / max(sum(v["launches"] for v in vs), 1)
+                        far_bytes = n_far * (wavg(p1, "hbm_bytes_per_launch_corrected") + wavg(p2, "hbm_bytes_per_launch_corrected"))
+                        near_bytes = n_near * near["hbm_bytes_per_launch_corrected"]
+                        out["trsv_traffic"] = {
+                            "near": {"kernel": "k_trsv_syncfree (entries inside a group of levels)", "launches_per_application": n_near,
+                                     "bytes_per_launch_upper_bound": near["hbm_bytes_per_launch_corrected"],
+                                     "bytes_per_application_upper_bound": near_bytes, "avg_launch_us": near["avg_us"]},
+                            "far": {"kernel": "k_pb_phase1 + k_pb_phase2 on the entries whose column lies in an earlier group",
+                                    "spmvs_per_application": n_far, "bytes_per_application": far_bytes,
+                                    "avg_launch_us": {"phase1": wavg(p1, "avg_us"), "phase2": wavg(p2, "avg_us")}},
+                            "bytes_per_application": near_bytes + far_bytes,
+                            "vs_algorithmic": (near_bytes + far_bytes) / b_trsv if ms_trsv > 0 else None,
+                            "source": os.path.relpath(f, ROOT)}
                         break
             out["levels"] = [st.n_levels_l, st.n_levels_u]
             # one-off setup (outside the timed region): level analysis of L and U; ILU(0) + factor layout + far/near split

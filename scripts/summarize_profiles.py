@@ -19,9 +19,17 @@ def main(tag):
         # real (non-frozen) launch durations from the kernel trace
         tr = newest(os.path.join(ROOT, "gpurun_out", "prof_%s" % name, "*", "*_kernel_trace.csv"))[0]
         dur = collections.defaultdict(list)
+
+        def klass(k, d):
+            """C5: the blocked kernels serve the loop's own SpMV (>= 0.6 ms per launch) AND the far parts of the triangular
+            solves (shorter launches): keep them apart"""
+            if name == "ilu0" and k.startswith("cm::k_pb_phase"):
+                return k + ("[far part of a triangular solve]" if d < 600000 else "[SpMV of the loop]")
+            return k
+
         for r in csv.DictReader(open(tr)):
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            k = klass(r["Kernel_Name"].split("(")[0].replace("void ", ""), d)
             if (d > (2000 if name == "mat10000" else 20000) or "trsv" in k) and not k.startswith("at::") and "rocclr" not in k:
                 dur[k].append(d)
         out = {"_note": "rocprofv3 --kernel-trace (durations of launches > 20 us: the rest are frozen no-ops past the stopping "
@@ -37,7 +45,7 @@ def main(tag):
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(fs[0])):
                 d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                k = klass(r["Kernel_Name"].split("(")[0].replace("void ", ""), d)
                 if (d > (2000 if name == "mat10000" else 20000) or "trsv" in k) and k in out:
                     acc[k].append(float(r["Counter_Value"]))
             for k, v in acc.items():
@@ -52,4 +60,4 @@ def main(tag):
                 print("  %-28s n=%3d avg %9.1f us  hbm %s" % (k[:28], v["launches"], v["avg_us"],
                       "%.3f GB" % (v["hbm_bytes_per_launch_corrected"] / 1e9) if "hbm_bytes_per_launch_corrected" in v else "-"))
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03")
