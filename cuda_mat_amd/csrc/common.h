@@ -37,6 +37,18 @@ int set_max_lds(const void *fn);
         }                                     \
     } while (0)
 
+// Optional roctx ranges: with CUDAMAT_ROCTX=1 in the environment the phases of a solve (setup,
+// analysis + factorisation, iteration loop, exchanges) are bracketed by roctxRangePush/Pop, bound at run time from
+// librocprofiler-sdk-roctx / libroctx64 -- `rocprofv3 --marker-trace` then shows them.  No-ops otherwise.
+void range_push(const char *name);
+void range_pop();
+struct Range {
+    explicit Range(const char *name) { range_push(name); }
+    ~Range() { range_pop(); }
+    Range(const Range &) = delete;
+    Range &operator=(const Range &) = delete;
+};
+
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 constexpr int kMaxParts = 2048;      // upper bound on partial sums per reduction stage
 constexpr int kVecGridMax = 1024;    // workgroups of a streaming vector kernel

@@ -1,5 +1,6 @@
 // context.hip -- error reporting, context, device memory helpers, timers and the
 // elementary-kernel entry points of the C ABI (include/cudamat.h).
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -41,6 +42,45 @@ int set_max_lds(const void *fn)
     CM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes));
     done.insert({dev, fn});
     return CUDAMAT_OK;
+}
+
+// ---- optional roctx ranges
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = getenv("CUDAMAT_ROCTX");
+        if (!e || e[0] != '1') return;
+        const char *names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+        for (const char *n : names) {
+            void *h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+Roctx &roctx()
+{
+    static Roctx r;
+    return r;
+}
+}  // namespace
+
+void range_push(const char *name)
+{
+    Roctx &r = roctx();
+    if (r.push) r.push(name);
+}
+void range_pop()
+{
+    Roctx &r = roctx();
+    if (r.pop) r.pop();
 }
 
 }  // namespace cm

@@ -1112,6 +1112,7 @@ int ilu0_setup(cudamat_solver *s, bool block)
     CM_ARG(block || !s->sharded, "ILU(0) of the whole matrix is single-GPU only (use the block variant)");
     CM_ARG(s->cols_sorted, "ILU(0) needs every row's column indices strictly increasing (mmio_wrapper.h:123 delivers that)");
     CM_HIP(hipSetDevice(s->ctx->device));
+    Range range_ilu("cudamat: ILU(0) analysis + factorisation + factor layout");
     ilu0_release(s);
     if (int rc0 = select_precond_matrix(s)) {
         char saved[512];

@@ -142,6 +142,7 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
     CM_ARG(base == 0 || base == 1, "base in {0,1}");
     CM_ARG(rowptr && (nnz == 0 || (colidx && val)), "null CSR array");
     CM_HIP(hipSetDevice(ctx->device));
+    Range range_create("cudamat: solver create (copies, validation, CSR plan)");
     const double t_create0 = now_s();
     cudamat_solver *s = new cudamat_solver();
     s->ctx = ctx;
@@ -347,6 +348,7 @@ static void comm_mark_end(cudamat_solver *s, hipStream_t st)
 static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int dot, const double *w,
                       double *parts, LoopArgs la, int check, ScalarSrc half)
 {
+    Range range_spmv(s->sharded ? "cudamat: SpMV + exchange of its input" : "cudamat: SpMV");
     const double *xfull = x_local;
     const bool windowed = s->sharded && s->windowed;
     const bool overlapped = s->sharded && !windowed && s->overlap && s->spmv_mode == 1;
@@ -500,6 +502,7 @@ static int ensure_spmv_mode_inner(cudamat_solver *s);
 static int ensure_spmv_mode(cudamat_solver *s)
 {
     if (s->spmv_mode >= 0) return CUDAMAT_OK;
+    Range range_mode("cudamat: SpMV form (matrix copies, tuning)");
     const double t0 = now_s();
     const int rc = ensure_spmv_mode_inner(s);
     hipStreamSynchronize(s->ctx->stream);
@@ -622,6 +625,7 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
 
 static int allreduce(cudamat_solver *s, double *buf, int count)
 {
+    Range range_ar("cudamat: all-reduce");
     // fault injection for the tests of the failure paths: CUDAMAT_TEST_COMM_FAIL="rank:k" makes the k-th all-reduce
     // of that rank's solver report an error (tests/test_gpu_dist.py: a failing rank must not strand its peers)
     if (const char *inj = getenv("CUDAMAT_TEST_COMM_FAIL")) {
@@ -925,6 +929,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     s->comm_kind.clear();
     s->profiling = profile && sharded;
     struct ProfilingOff { cudamat_solver *s; ~ProfilingOff() { s->profiling = false; } } profiling_off{s};
+    Range range_loop("cudamat: iteration loop (enqueue + lagged checks)");
     const double t_loop0 = now_s();
     if (flags & CUDAMAT_FLAG_X0_ONES) CM_TRY(launch_fill(st, n, 1.0, x));
     // r = A x0 (pbicgstab.cu:67 / :645-646); x may be a caller buffer without pad
