@@ -257,11 +257,19 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
         p.NCB = (int)((n_cols + p.CB - 1) / p.CB);
         p.bpc = p.NCB;
     }
-    // Sub-blocks (one wave each): ~48 entries per (sub-block, column block) segment keeps a wave's
-    // lanes busy, but never fewer than 4096 waves (16 per CU) -- a shard of a row-partitioned matrix
-    // has few entries per column block and would otherwise be latency-bound.
+    // Sub-blocks (one wave each): ~48 entries per (sub-block, column block) segment keeps a wave's lanes busy.  When
+    // that gives fewer than 2560 waves (10 per CU: a shard of a row-partitioned matrix, the far part of a triangular
+    // factor) the waves are kept to >= 2048 with longer segments, and each wave keeps 16 segment loads in flight
+    // instead of 4 -- phase 2 is bound by fabric REQUESTS (~55 G/s: 3.4 per 20-entry segment, 5.8 per 48-entry one), so
+    // longer segments are cheaper per entry as long as the loads in flight make up for the fewer waves.  Measured in
+    // alternation on one box (scripts/ab_env.sh, G = 8 shard of C4, ms per iteration of one rank): 4096 waves x 4 loads
+    // 0.892 / 0.906 / 0.936; 4096 x 8 the same; 2048 x 8 0.852 / 0.874 / 0.873; 2048 x 16 0.808 / 0.847 / 0.848;
+    // 1024 x 16 0.827 / 0.841 / 0.855.  On the full matrix (13.5 K waves) 4 loads in flight stay the best (2.58-2.67 ms
+    // per SpMV against 2.69-2.70 with 8 and 2.68-2.75 with 16).  CUDAMAT_PB_MIN_WAVES / CUDAMAT_PB_DEPTH override.
     double nsub_t = (double)nnz / ((double)p.NCB * 48.0);
-    double min_waves = 4096.0;
+    const bool few = nsub_t < 2560.0;          // (a G = 4 shard, 3390 natural waves, is better off with 4096 x 4: 1.50 / 1.57 / 1.50
+                                               // against 1.53 / 1.60 / 1.59 ms per iteration with 3390 x 16)
+    double min_waves = few ? 2048.0 : 4096.0;
     if (const char *e = getenv("CUDAMAT_PB_MIN_WAVES")) { const double v = atof(e); if (v >= 256.0) min_waves = v; }
     if (nsub_t < min_waves) nsub_t = min_waves;
     if (nsub_t > (double)n / 16.0) nsub_t = (double)n / 16.0;
@@ -281,7 +289,7 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     p.NSUB = p.NRB * p.NW;
     const double seg = (double)nnz / ((double)p.NCB * p.NSUB);      // mean entries per segment
     p.LPS = seg <= 6.0 ? 16 : seg <= 22.0 ? 32 : 64;
-    p.depth = 4;
+    p.depth = few ? 16 : 4;
     if (const char *e = getenv("CUDAMAT_PB_DEPTH")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) p.depth = v; }
     if (p.NRB > kMaxParts || p.CB > 65536 || p.SR > 65536 || (size_t)p.RB * 8 > 150 * 1024 ||
         sizeof(int) * (size_t)kPbBuildWaves * p.NCB > 150 * 1024) {     // the analysis keeps one cursor per column block in LDS
