@@ -266,7 +266,9 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     // 0.892 / 0.906 / 0.936; 4096 x 8 the same; 2048 x 8 0.852 / 0.874 / 0.873; 2048 x 16 0.808 / 0.847 / 0.848;
     // 1024 x 16 0.827 / 0.841 / 0.855.  On the full matrix (13.5 K waves) 4 loads in flight stay the best (2.58-2.67 ms
     // per SpMV against 2.69-2.70 with 8 and 2.68-2.75 with 16).  CUDAMAT_PB_MIN_WAVES / CUDAMAT_PB_DEPTH override.
-    double nsub_t = (double)nnz / ((double)p.NCB * 48.0);
+    double seg_target = 48.0;
+    if (const char *e = getenv("CUDAMAT_PB_SEG")) { const double v = atof(e); if (v >= 8.0 && v <= 512.0) seg_target = v; }
+    double nsub_t = (double)nnz / ((double)p.NCB * seg_target);
     const bool few = nsub_t < 2560.0;          // (a G = 4 shard, 3390 natural waves, is better off with 4096 x 4: 1.50 / 1.57 / 1.50
                                                // against 1.53 / 1.60 / 1.59 ms per iteration with 3390 x 16)
     double min_waves = few ? 2048.0 : 4096.0;
@@ -275,6 +277,7 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     if (nsub_t > (double)n / 16.0) nsub_t = (double)n / 16.0;
     if (nsub_t < 4.0) nsub_t = 4.0;
     p.NW = nsub_t >= 4096.0 ? 16 : nsub_t >= 2048.0 ? 8 : 4;
+    while (p.NW > 4 && ((double)n / nsub_t) * p.NW * 8.0 > 144.0 * 1024.0) p.NW /= 2;     // the row block's y tile must fit the LDS
     int nrb = (int)(nsub_t / p.NW / 256.0 + 0.5) * 256;          // whole rounds of workgroups
     if (nrb < 256) nrb = 256;
     const int nrb_min = (int)(((int64_t)n + kTileMax - 1) / kTileMax);
