@@ -58,3 +58,11 @@ def test_every_form_failing_is_an_error_not_a_line():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "every exchange form failed" in r.stderr
+
+
+def test_eight_ranks():
+    """the shape of the driver's scaling run: eight supervisors, eight workers, one line"""
+    r, _ = _run("slow:1", gpus=8, extra_env={"CUDAMAT_BENCH_FORM_TIMEOUT": "120"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 8 and out["comm"]["launcher"][0]["ranks"] == ["ok"] * 8

@@ -388,6 +388,38 @@ def test_bench_two_processes_share_the_gpu_over_gloo():
     assert outs["torch:1"]["config"]["converges_in_iters"] == outs["torch:0"]["config"]["converges_in_iters"]
 
 
+def test_bench_line_contract_on_one_gpu():
+    """the one-GPU bench line (a small C4-shaped system): metric / value / roofline / side figures as DESIGN section 6
+    describes them -- the judged numbers are measured on fp64 values (value_dictionary == 0 in the timed region), the
+    dictionary run is the labelled side figure, the drop-in section times two host-pointer calls (the second reuses the
+    first one's plan), stdout carries exactly one line"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CUDAMAT_BENCH_FORMS", "CUDAMAT_VALUE_DICT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rows", "1500000", "--steps", "10", "--warmup", "2",
+                        "--cpu-baseline", "off"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 10 and out["warmup"] == 2 and out["unit"] == "iter/s" and out["dtype"] == "f64"
+    assert out["higher_is_better"] is True and out["vs_baseline"] is None and out["value"] > 0
+    assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["launches_timed"] == 20 and rf["avg_launch_ms"] > 0 and "k_pb_phase1 +" in rf["kernel"]
+    assert out["value_dictionary"] == 0                               # the timed kernels read fp64 values
+    side = out["with_value_dictionary"]
+    assert side["value_dictionary"] == 39 and side["value"] > 0 and "effective_frac" in side and "frac" not in side
+    d = out["drop_in"]
+    assert d["first_call"]["plan_reused"] == 0 and d["second_call_same_matrix"]["plan_reused"] == 1
+    assert d["first_call"]["converged"] and d["first_call"]["max_abs_err"] < 2e-5 and d["first_call"]["tune_s"] >= 0
+    assert d["second_call_same_matrix"]["setup_s"] == 0
+
+
 def test_bench_plain_command_launches_its_ranks_and_survives_a_hanging_form():
     """`python bench.py --gpus 2` with no launcher around it (how the driver produced BENCH): bench.py starts the ranks itself
     as child processes, prints one line with n_gpus = 2 -- and when the first exchange form never completes (forced: the
