@@ -399,7 +399,7 @@ def test_bench_line_contract_on_one_gpu():
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CUDAMAT_BENCH_FORMS", "CUDAMAT_VALUE_DICT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rows", "1500000", "--steps", "10", "--warmup", "2",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rows", "3000000", "--steps", "10", "--warmup", "2",
                         "--cpu-baseline", "off"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
