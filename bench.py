@@ -106,7 +106,7 @@ def _free_port():
 def _form_limit(first):
     """seconds a set of workers may take for one exchange form (import, generation, tuning, gate, timed region)"""
     v = os.environ.get("CUDAMAT_BENCH_FORM_TIMEOUT")
-    return float(v) if v else (420.0 if first else 240.0)
+    return float(v) if v else (240.0 if first else 150.0)
 
 
 def _kill_group(proc):
