@@ -123,6 +123,17 @@ def _kill_group(proc):
         pass
 
 
+def _die_with_parent():
+    """(child side, between fork and exec) have the kernel end this process when the supervisor that started it goes --
+    a worker lives in its own session, so nothing else would reach it when a supervisor is killed from outside"""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL))      # PR_SET_PDEATHSIG
+    except OSError:
+        pass
+
+
 def _worker_cmd():
     import shlex
     stub = os.environ.get("CUDAMAT_BENCH_WORKER_CMD")           # tests/test_bench_launch_cpu.py: a stand-in worker, no GPU
@@ -150,7 +161,7 @@ def supervisor(argv):
                    MASTER_PORT=str(box[0]), TORCHELASTIC_USE_AGENT_STORE="False")
         out = tempfile.TemporaryFile(mode="w+")
         t0 = time.time()
-        proc = subprocess.Popen(_worker_cmd() + argv, env=env, stdout=out, start_new_session=True)
+        proc = subprocess.Popen(_worker_cmd() + argv, env=env, stdout=out, start_new_session=True, preexec_fn=_die_with_parent)
         limit = _form_limit(i == 0)
         while True:
             rc = proc.poll()

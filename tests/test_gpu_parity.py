@@ -648,6 +648,11 @@ def test_loop_in_level_major_spaces_matches_the_permuting_loop(cm, ctx, oracle, 
     assert abs(st1.iters - so.iters) <= max(2, 0.1 * so.iters)
     assert np.linalg.norm(x1 - xo) / np.linalg.norm(xo) <= 1e-5
     assert np.linalg.norm(b - oracle.spmv(A, x1)) <= 1e-7 * st1.nrm0
+    # the pipelined loop on the same level-major factors (it permutes around every application of M^-1)
+    xp, sp, hp = oracle.pipelined_bicgstab(A, b, x0=x0, vm=oracle.ilu0(A), maxit=500, tol=1e-8, want_hist=True)
+    x2, st2, h2 = _solve_dev(cm, ctx, A, b, x0=x0, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PIPELINED, maxit=500, tol=1e-8)
+    assert st2.converged and st2.restarts == 0 and abs(st2.iters - sp.iters) <= max(2, 0.1 * sp.iters)
+    assert np.linalg.norm(x2 - xp) / np.linalg.norm(xp) <= 1e-6 and np.linalg.norm(x2 - x1) / np.linalg.norm(x1) <= 1e-5
 
 
 def _chain_matrix(oracle, n, width, seed):
