@@ -308,26 +308,35 @@ def cpu_baseline(args):
 
 
 def hbm_ceiling(ctx):
-    """measured streaming ceiling of this GPU: the in-repo y += a*x kernel (2 reads + 1 write per
-    element, triad-shaped) on 2^26 doubles per vector (1 GiB of operands, far beyond the 256 MB Infinity Cache),
-    HIP-event timed, median of 7"""
+    """measured streaming ceilings of this GPU, in-repo kernels on 2^26 doubles per vector (512 MiB each, far
+    beyond the 256 MB Infinity Cache), HIP-event timed, median of 7: `gbs` = y += a*x (2 reads + 1 write per element,
+    triad-shaped: the ceiling of a read/write mix), `read_gbs` = sum x*y (2 reads: the ceiling of a read-only stream)"""
+    from cuda_mat_amd import _lib
     n = 1 << 26
     x, y = ctx.empty(n), ctx.empty(n)
     x.zero()
     y.zero()
     t = ctx.timer()
-    times = []
-    for i in range(9):
-        t.start()
-        ctx.axpy(n, 0.5, x, y)
-        t.stop()
-        if i >= 2:
-            times.append(t.elapsed_ms())
+
+    def med(fn):
+        times = []
+        for i in range(9):
+            t.start()
+            fn()
+            t.stop()
+            if i >= 2:
+                times.append(t.elapsed_ms())
+        return sorted(times)[len(times) // 2]
+
+    ms = med(lambda: ctx.axpy(n, 0.5, x, y))
+    out = ctx.empty(1)
+    ms_r = med(lambda: _lib.check(_lib.lib().cudamat_dot(ctx.h, n, x.ptr, y.ptr, out.ptr)))
     t.close()
+    out.free()
     x.free()
     y.free()
-    ms = sorted(times)[len(times) // 2]
-    return {"kernel": "k_axpy, 2 reads + 1 write, 3 x 512 MiB", "gbs": 24.0 * n / ms / 1e6}
+    return {"kernel": "k_axpy, 2 reads + 1 write, 3 x 512 MiB", "gbs": 24.0 * n / ms / 1e6,
+            "read_kernel": "k_dot, 2 reads, 2 x 512 MiB", "read_gbs": 16.0 * n / ms_r / 1e6}
 
 
 def main():
@@ -664,7 +673,7 @@ def run_bench(args):
         kernel += " (L2-resident, launch-latency-bound: per-launch timing off, no roofline quoted)"
     # HBM bytes per SpMV launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     # FETCH_SIZE doubled per the gfx950 calibration); only for the exact workload they were taken on
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_parts = None, None, None
     if world == 1 and args.workload == "rand50" and args.rows == 10_000_000 and args.per_row == 50:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_fetch_write.json")), reverse=True):
@@ -676,6 +685,7 @@ def run_bench(args):
                          and "hbm_bytes_per_launch_corrected" in v), None) for w in want]
             if all(g is not None for g in got):
                 traffic = sum(g["hbm_bytes_per_launch_corrected"] for g in got)
+                traffic_parts = [g["hbm_bytes_per_launch_corrected"] for g in got]
                 traffic_src = os.path.relpath(f, ROOT)
                 break
     out = None
@@ -787,6 +797,13 @@ def run_bench(args):
             ceil = hbm_ceiling(ctx)
             out["roofline"]["measured_stream_ceiling"] = ceil
             out["roofline"]["frac_of_measured_ceiling"] = achieved / ceil["gbs"]
+            if blocked and traffic_parts is not None:
+                # what this SpMV's own traffic would take at the two measured ceilings: phase 1 is a read/write mix
+                # (10 B read : 8 B written per entry), phase 2 reads only
+                t_floor = (traffic_parts[0] / ceil["gbs"] + traffic_parts[1] / ceil["read_gbs"]) / 1e6
+                out["roofline"]["ms_at_measured_ceilings"] = t_floor
+                out["roofline"]["note_ceilings"] = ("counter bytes of phase 1 / triad ceiling + counter bytes of phase 2 / read ceiling: "
+                                                    "the launch pair runs at %.2f of that" % (t_floor / spmv_ms if spmv_ms > 0 else 0.0))
         if world == 1 and args.cpu_baseline != "off":
             out["cpu_baseline"] = cpu_baseline(args)
     solver.close()
