@@ -10,7 +10,7 @@ synthetic random CSR, 1e7 x 1e7, 50 nnz/row, fp64 values / int32 indices, genera
 the matrix is fixed, each rank owns n/N rows).  A "step" is one BiCGSTAB iteration = both
 half steps = 2 SpMV + 3 fused vector kernels (+ 2 all-gathers, 3 all-reduces when N > 1).
 The stopping tests are evaluated every step but not taken (CUDAMAT_FLAG_NO_EXIT), and the
-solve restarts from x0 = 1 every 25 steps so the residual stays far from underflow; each
+solve restarts from x0 = 1 every 50 steps so the residual stays far from underflow; each
 restart's extra SpMV is inside the timed region and not counted as a step.
 
 Output: ONE JSON line on rank 0 (see DESIGN.md "Measurement").
@@ -45,7 +45,8 @@ def cpu_quota():
 
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-CHUNK = 25              # steps per restart (fast-converging synthetic systems: the residual underflows soon after)
+CHUNK = 50              # steps per restart: the synthetic systems converge by ~0.025 per iteration, so ||r||^2 reaches 1e-160
+                        # after 50 steps and would underflow after ~95 -- restart from x0 well before that
 CHUNK_SMALL = 100       # ... of the latency-bound small Poisson-type systems (C2 needs ~190 iterations to 1e-8)
 
 

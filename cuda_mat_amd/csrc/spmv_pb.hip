@@ -439,13 +439,22 @@ constexpr int kP1U = 4;                // steps per chunk of the pipelined loop 
 
 __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const int *col0, const int *list,
                                                           const int *cstart, const double *pv, const u16 *pc,
-                                                          double *P, const LoopState *st, int pipelined)
+                                                          double *P, const LoopState *st, int pipelined, int split)
 {
     extern __shared__ __attribute__((aligned(16))) double xs[];
     if (st && st->state != 0) return;
-    const int cb = list ? list[blockIdx.x] : (int)blockIdx.x;
-    const int s = cstart[cb], e = cstart[cb + 1];
-    if (s == e) return;                                    // (block-uniform) nothing stored in this block
+    // split > 1: `split` workgroups share a column block (each stages the x tile and streams one slice of the block's
+    // entries): a finer grain for the dispatcher at the end of the launch
+    const int bi = (int)blockIdx.x / split, part = (int)blockIdx.x - bi * split;
+    const int cb = list ? list[bi] : bi;
+    int s = cstart[cb], e = cstart[cb + 1];
+    if (split > 1) {
+        const int len = e - s, per = ((len + split - 1) / split + 1) & ~1;
+        const int s1 = s + part * per;
+        e = s1 + per < e ? s1 + per : e;
+        s = s1;
+    }
+    if (s >= e) return;                                    // (block-uniform) nothing stored in this block / slice
     const int c0 = col0[cb], cn = col0[cb + 1] - c0;
     for (int i = threadIdx.x; i < cn; i += kP1Threads) xs[i] = x[c0 + i];
     __syncthreads();
@@ -767,8 +776,9 @@ int launch_pb_phase1(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int par
     }
     CM_TRY(set_max_lds((const void *)k_pb_phase1));
     static const int pipelined = [] { const char *e = getenv("CUDAMAT_PB_PIPELINE"); return e && e[0] == '1' ? 1 : 0; }();
-    hipLaunchKernelGGL(k_pb_phase1, dim3(last - first), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x, p.col0,
-                       part < 0 ? (const int *)nullptr : p.order + first, p.cstart, p.pv, p.pc, p.P, a.loop.st, pipelined);
+    static const int split = [] { const char *e = getenv("CUDAMAT_PB_SPLIT"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+    hipLaunchKernelGGL(k_pb_phase1, dim3((last - first) * split), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x, p.col0,
+                       part < 0 ? (const int *)nullptr : p.order + first, p.cstart, p.pv, p.pc, p.P, a.loop.st, pipelined, split);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }
