@@ -269,7 +269,9 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     double seg_target = 48.0;
     if (const char *e = getenv("CUDAMAT_PB_SEG")) { const double v = atof(e); if (v >= 8.0 && v <= 512.0) seg_target = v; }
     double nsub_t = (double)nnz / ((double)p.NCB * seg_target);
-    const bool few = nsub_t < 2560.0;          // (a G = 4 shard, 3390 natural waves, is better off with 4096 x 4: 1.50 / 1.57 / 1.50
+    // (the 2048-wave plan needs 8 waves per row block whose y tiles fit the LDS: up to 4.7 M rows; a 1e7-row matrix with few
+    // entries per row keeps the 4096-wave rule -- with 4-wave row blocks its phase 2 took 0.50 ms instead of 0.23)
+    const bool few = nsub_t < 2560.0 && (double)n / 2048.0 * 8.0 * 8.0 <= 144.0 * 1024.0;          // (a G = 4 shard, 3390 natural waves, is better off with 4096 x 4: 1.50 / 1.57 / 1.50
                                                // against 1.53 / 1.60 / 1.59 ms per iteration with 3390 x 16)
     double min_waves = few ? 2048.0 : 4096.0;
     if (const char *e = getenv("CUDAMAT_PB_MIN_WAVES")) { const double v = atof(e); if (v >= 256.0) min_waves = v; }
