@@ -279,7 +279,6 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     if (nsub_t > (double)n / 16.0) nsub_t = (double)n / 16.0;
     if (nsub_t < 4.0) nsub_t = 4.0;
     p.NW = nsub_t >= 4096.0 ? 16 : nsub_t >= 2048.0 ? 8 : 4;
-    while (p.NW > 4 && ((double)n / nsub_t) * p.NW * 8.0 > 144.0 * 1024.0) p.NW /= 2;     // the row block's y tile must fit the LDS
     int nrb = (int)(nsub_t / p.NW / 256.0 + 0.5) * 256;          // whole rounds of workgroups
     if (nrb < 256) nrb = 256;
     const int nrb_min = (int)(((int64_t)n + kTileMax - 1) / kTileMax);
