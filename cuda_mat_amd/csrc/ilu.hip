@@ -619,7 +619,6 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
     std::vector<PbPlan> far;               // far[g]: rows of group g x columns of groups < g
     double *far_buf = nullptr;             // n doubles in level-major row order: far_g . out
     std::vector<int> lev_host;             // level of every original row (kept until the split)
-    std::vector<int> row_of_host;          // original row of every level-major position (kept until the permuted matrix is built)
     bool want_hybrid = false;              // this factor alone would take the hybrid solve (the two factors decide together)
     bool syncfree = false;                 // one dependency-driven launch per group instead of one launch per level
     int spin_limit = kSpinLimit;
@@ -639,7 +638,6 @@ struct IluPlans {
     // matrix, solver.hip ensure_perm_matrix), scratch vectors of the original-space wrapper (precond_apply_any)
     int *posU = nullptr;
     double *perm_a = nullptr, *perm_b = nullptr;
-    std::vector<int> h_rp;                         // host copy of the matrix row pointers (until the permuted matrix is built)
 };
 
 static IluPlans *plans_of(cudamat_solver *s, bool create)
@@ -782,7 +780,6 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
     if (n) CM_HIP(hipMemcpy(F.row_of, row_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     F.rhs_of = F.out_of = F.row_of;            // original index space (until both factors go level-major, ilu0_setup)
     F.lm = false;
-    H.row_of_host.swap(row_of);
     CM_TRY(dalloc(&H.level_ptr_dev, (size_t)nlev + 1));
     CM_HIP(hipMemcpy(H.level_ptr_dev, F.level_ptr.data(), sizeof(int) * ((size_t)nlev + 1), hipMemcpyHostToDevice));
     CM_STAMP("factor arrays alloc + upload");
@@ -836,6 +833,87 @@ static void plan_groups(const TriFactor &F, TriHost &H, bool hybrid)
             l = e;
         }
     }
+}
+
+// ---- exclusive prefix sums of n ints on the device (out has n + 1 entries, out[n] = total): tiles of 4096 elements
+// scanned by one workgroup each, one workgroup over the tile totals, tile offsets added.  (Round 3: the host loops over
+// 1e7 counts -- two device-to-host copies, a serial scan, two uploads per factor -- were ~40 ms each at C5.)
+constexpr int kScanTile = 4096;
+
+__device__ __forceinline__ int wg_exclusive_scan(int v, int *lds_waves, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds_waves[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < kBlock / 64; w++) {
+        const int t = lds_waves[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(int n, const int *in, int *out, int *tile_sum)
+{
+    __shared__ int lds_waves[kBlock / 64];
+    const long long t0 = (long long)blockIdx.x * kScanTile;
+    int run = 0;
+    for (int c = 0; c < kScanTile; c += kBlock) {
+        const long long i = t0 + c + threadIdx.x;
+        const int v = i < n ? in[i] : 0;
+        int total;
+        const int ex = wg_exclusive_scan(v, lds_waves, &total);
+        if (i < n) out[i] = run + ex;
+        run += total;
+    }
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = run;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_tile_sums(int ntiles, int *tile_sum, int n, int *out)
+{
+    __shared__ int lds_waves[kBlock / 64];
+    int run = 0;
+    for (int c = 0; c < ntiles; c += kBlock) {
+        const int i = c + threadIdx.x;
+        const int v = i < ntiles ? tile_sum[i] : 0;
+        int total;
+        const int ex = wg_exclusive_scan(v, lds_waves, &total);
+        if (i < ntiles) tile_sum[i] = run + ex;
+        run += total;
+    }
+    if (threadIdx.x == 0) out[n] = run;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_add(int n, const int *tile_sum, int *out)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] += tile_sum[i / kScanTile];
+}
+
+// out[0..n] = exclusive prefix sums of in[0..n); in and out may not alias
+static int device_exclusive_scan(hipStream_t st, int n, const int *in, int *out)
+{
+    if (n <= 0) { CM_HIP(hipMemsetAsync(out, 0, sizeof(int), st)); return CUDAMAT_OK; }
+    const int ntiles = (n + kScanTile - 1) / kScanTile;
+    int *tile_sum = nullptr;
+    CM_TRY(dalloc(&tile_sum, (size_t)ntiles));
+    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kBlock), 0, st, n, in, out, tile_sum);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kBlock), 0, st, ntiles, tile_sum, n, out);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)(((long long)n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, tile_sum, out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(tile_sum);
+    CM_HIP(e);
+    return CUDAMAT_OK;
 }
 
 // ---- hybrid split of a level-major factor into near (same group) and far (earlier groups) entries
@@ -953,24 +1031,25 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
         if (hipMemcpy(d_grp, hg.data(), (size_t)n, hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
         const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(k_split_count, dim3(grid), dim3(kBlock), 0, st, n, F.rp, F.ci, F.row_of, d_grp, d_cn, d_cf);
-        std::vector<int> cn((size_t)n), cf((size_t)n), hn((size_t)n + 1, 0), hf((size_t)n + 1, 0);
-        if (hipMemcpyAsync(cn.data(), d_cn, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(cf.data(), d_cf, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("factor split count failed"); break; }
-        for (int i = 0; i < n; i++) {
-            hn[(size_t)i + 1] = hn[(size_t)i] + cn[(size_t)i];
-            hf[(size_t)i + 1] = hf[(size_t)i] + cf[(size_t)i];
-        }
-        const int64_t nnz_near = hn[(size_t)n], nnz_far = hf[(size_t)n];
-        CM_STAMP("split count + host scan");
+        // row pointers of the near and the far part: prefix sums on the device; the host needs the two totals and the far
+        // pointer at the group boundaries only
         if ((rc = dalloc(&nrp, (size_t)n + 1))) break;
         if ((rc = dalloc(&qrp, (size_t)n + 1))) break;
+        if ((rc = device_exclusive_scan(st, n, d_cn, nrp))) break;
+        if ((rc = device_exclusive_scan(st, n, d_cf, qrp))) break;
+        int tot_near = 0, tot_far = 0;
+        std::vector<int> hf_grp((size_t)K + 1, 0);
+        bool copied = hipMemcpy(&tot_near, nrp + n, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess &&
+                      hipMemcpy(&tot_far, qrp + n, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+        for (int g = 0; g <= K && copied; g++)
+            copied = hipMemcpy(&hf_grp[(size_t)g], qrp + F.level_ptr[(size_t)H.grp_level[(size_t)g]], sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+        if (!copied) { rc = CUDAMAT_ERR_HIP; set_error("factor split scan failed"); break; }
+        const int64_t nnz_near = tot_near, nnz_far = tot_far;
+        CM_STAMP("split count + device scan");
         if ((rc = dalloc(&nci, (size_t)nnz_near))) break;
         if ((rc = dalloc(&nval, (size_t)nnz_near))) break;
         if ((rc = dalloc(&qci, (size_t)nnz_far))) break;
         if ((rc = dalloc(&qval, (size_t)nnz_far))) break;
-        if (hipMemcpy(nrp, hn.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(qrp, hf.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
         hipLaunchKernelGGL(k_split_fill, dim3(grid), dim3(kBlock), 0, st, n, F.rp, F.ci, F.val, F.row_of, d_grp, pos, nrp, nci,
                            nval, qrp, qci, qval);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("factor split failed"); break; }
@@ -986,7 +1065,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
         H.far.assign((size_t)K, PbPlan());
         for (int g = 1; g < K && !rc; g++) {
             const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)g]], r1 = F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]];
-            const int64_t cnt = (int64_t)hf[(size_t)r1] - hf[(size_t)r0];
+            const int64_t cnt = (int64_t)hf_grp[(size_t)g + 1] - hf_grp[(size_t)g];
             if (r1 <= r0 || cnt <= 0) continue;
             rc = pb_build(st, r1 - r0, r0, cnt, qrp + r0, qci2, qval2, &H.far[(size_t)g]);
         }
@@ -1252,12 +1331,9 @@ int ilu0_setup(cudamat_solver *s, bool block)
             s->U.out_of = nullptr;
             if ((rc = dalloc(&pl->perm_a, (size_t)n))) break;
             if ((rc = dalloc(&pl->perm_b, (size_t)n))) break;
-            pl->h_rp = h_rp;                           // for the permuted matrix of the preconditioned loop (built at its first use)
         } else {
-            pl->L.row_of_host.clear(); pl->L.row_of_host.shrink_to_fit();
             pl->L.lev_host.clear(); pl->L.lev_host.shrink_to_fit();
         }
-        pl->U.row_of_host.clear(); pl->U.row_of_host.shrink_to_fit();
         pl->U.lev_host.clear(); pl->U.lev_host.shrink_to_fit();
         s->t_factor = now_s() - t1;
         // solve form: one dependency-driven launch per group (default whenever there is more than one level
@@ -1540,6 +1616,12 @@ int precond_apply_original(cudamat_solver *s, const double *in, double *tmp, dou
     return perm_from_space(s, true, pl->perm_b, out);
 }
 
+__global__ __launch_bounds__(kBlock) void k_perm_row_len(int n, const int *rp, const int *row_of, int *len)
+{
+    const int pr = blockIdx.x * kBlock + threadIdx.x;
+    if (pr < n) { const int r = row_of[pr]; len[pr] = rp[r + 1] - rp[r]; }
+}
+
 // The solver's matrix for the loop that runs IN the level-major spaces (solver.hip, "permuted loop"): rows in L's
 // order (the residual-side vectors r, p, v, t live there), columns in U's positions (the SpMV inputs M^-1 p, M^-1 r and
 // the iterate x live there), as a blocked two-phase copy.  Built once, at the first preconditioned solve.
@@ -1547,7 +1629,7 @@ int ilu_perm_matrix(cudamat_solver *s)
 {
     if (s->perm_ready) return CUDAMAT_OK;
     IluPlans *pl = plans_of(s, false);
-    if (!pl || !s->L.lm || !s->U.lm || !pl->posU || pl->h_rp.empty() || pl->L.row_of_host.empty()) {
+    if (!pl || !s->L.lm || !s->U.lm || !pl->posU) {
         set_error("level-major index spaces are not available");
         return CUDAMAT_ERR_ARG;
     }
@@ -1555,19 +1637,17 @@ int ilu_perm_matrix(cudamat_solver *s)
     const int n = s->n;
     const int64_t nnz = s->pm_nnz;
     const double t0 = now_s();
-    std::vector<int> nrp((size_t)n + 1, 0);
-    for (int pr = 0; pr < n; pr++) {
-        const int r = pl->L.row_of_host[(size_t)pr];
-        nrp[(size_t)pr + 1] = nrp[(size_t)pr] + (pl->h_rp[(size_t)r + 1] - pl->h_rp[(size_t)r]);
-    }
-    int *d_rp = nullptr, *d_ci = nullptr;
+    int *d_rp = nullptr, *d_ci = nullptr, *d_len = nullptr;
     double *d_val = nullptr;
     int rc = CUDAMAT_OK;
     do {
         if ((rc = dalloc(&d_rp, (size_t)n + 1))) break;
+        if ((rc = dalloc(&d_len, (size_t)n))) break;
         if ((rc = dalloc(&d_ci, (size_t)nnz))) break;
         if ((rc = dalloc(&d_val, (size_t)nnz))) break;
-        if (hipMemcpy(d_rp, nrp.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("row pointer upload failed"); break; }
+        // row pointers of the permuted matrix: lengths of the rows in L's order, prefix sums on the device
+        hipLaunchKernelGGL(k_perm_row_len, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, s->pm_rp, s->L.row_of, d_len);
+        if ((rc = device_exclusive_scan(st, n, d_len, d_rp))) break;
         if ((rc = launch_sort_rows(st, n, s->pm_rp, s->L.row_of, d_rp, s->pm_ci, s->pm_val, pl->posU, d_ci, d_val))) break;
         if (nnz >= (1 << 20)) {
             if ((rc = valdict_build(st, nnz, d_val, &s->vd_perm))) break;       // (n == 0 afterwards: no dictionary, fp64 values)
@@ -1577,7 +1657,7 @@ int ilu_perm_matrix(cudamat_solver *s)
         if (!s->b_perm && (rc = dalloc(&s->b_perm, (size_t)(s->n_pad > n ? s->n_pad : n)))) break;
         if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("permuted matrix build failed"); break; }
     } while (0);
-    void *tmp[] = {d_rp, d_ci, d_val};
+    void *tmp[] = {d_rp, d_ci, d_val, d_len};
     for (void *q : tmp)
         if (q) hipFree(q);
     if (rc) {
@@ -1585,8 +1665,6 @@ int ilu_perm_matrix(cudamat_solver *s)
         return rc;
     }
     s->perm_ready = true;
-    pl->h_rp.clear(); pl->h_rp.shrink_to_fit();
-    pl->L.row_of_host.clear(); pl->L.row_of_host.shrink_to_fit();
     hipFree(pl->posU);
     pl->posU = nullptr;
     s->t_perm_matrix = now_s() - t0;
