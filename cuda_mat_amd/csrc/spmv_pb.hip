@@ -632,7 +632,48 @@ struct Pb2Args {
     const double *w;
     double *parts;
     const LoopState *st;
+    int strict;      // 1: a row's products of one wave instruction are added by SEPARATE instructions, rank by rank
 };
+
+// One wave instruction's worth of products into the wave's y tile.  Equal rows sit in ADJACENT active lanes (a segment is
+// sorted by row, then column), and a row must receive its products in column order, one rounding per addition.
+//  * default: one ds_add_f64 instruction, relying on the OBSERVED property that the LDS serves equal addresses of one
+//    instruction in lane order.
+//  * strict (CUDAMAT_PB_STRICT=1; round 3): lanes are ranked inside their run of equal rows and every rank is its own
+//    instruction -- within an instruction all addresses are distinct, and a wave's LDS instructions execute in issue
+//    order, so the order of the additions is ARCHITECTED.  Bit-identical results on gfx950 (the guard test runs both
+//    against the oracle) at a price: +10 % per C4 SpMV (2.70 -> 2.97 ms), +25 % per iteration of a G = 8 rank -- phase 2
+//    feels every extra LDS-pipe instruction (two lane shifts, a ballot and a second add per segment step).  Hence an
+//    option: the form to switch to should a future part serve equal addresses in another order.
+// `group_first`: first lane of this lane's segment inside the instruction (0 when one segment fills the wave).
+__device__ __forceinline__ void pb_seg_add(double *my, int r, double p, bool on, int lane, int group_first, bool strict)
+{
+    if (!strict) {
+        if (on) unsafeAtomicAdd(&my[r], p);
+        return;
+    }
+    // (the lane below through ds_bpermute; a DPP wave_shr:1 move was tried instead: wrong neighbours across the 16-lane
+    // rows on gfx950 and no faster)
+    const int r_prev = __shfl_up(r, 1, 64);
+    const int on_prev = __shfl_up((int)on, 1, 64);
+    const bool d1 = on && lane > group_first && on_prev && r_prev == r;      // same row as the lane before
+    if (on && !d1) unsafeAtomicAdd(&my[r], p);                               // rank 0: distinct addresses
+    if (__ballot(d1) == 0) return;
+    const bool d2 = d1 && __shfl_up((int)d1, 1, 64) != 0;                    // ... and as the lane before that: rank >= 2
+    if (d1 && !d2) unsafeAtomicAdd(&my[r], p);                               // rank 1
+    if (__ballot(d2) == 0) return;
+    // longer runs (few column blocks, or clustered columns): rank = lane - first lane of the run (max-scan of the run
+    // heads), then one instruction per rank
+    int head = d1 ? 0 : lane;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(head, o, 64);
+        if (lane >= o) head = t > head ? t : head;
+    }
+    const int rank = on ? lane - head : 0;
+    for (int q = 2; __ballot(on && rank >= q); q++)
+        if (on && rank == q) unsafeAtomicAdd(&my[r], p);
+}
 
 // DEPTH: segment loads a wave issues before it consumes the first (4; 8 / 16 when few waves are resident: shards)
 template <int NW, int LPS, int DEPTH>
@@ -677,9 +718,14 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
                 }
 #pragma unroll
                 for (int u = 0; u < DEPTH; u++) {
-                    if (lane < l[u]) unsafeAtomicAdd(&my[r4[u]], pv4[u]);
-                    for (int off = 64 + lane; off < l[u]; off += 64)        // segments longer than a wave
-                        unsafeAtomicAdd(&my[a.pr[s[u] + off]], a.P[s[u] + off]);
+                    pb_seg_add(my, r4[u], pv4[u], lane < l[u], lane, 0, a.strict != 0);
+                    for (int off0 = 64; off0 < l[u]; off0 += 64) {         // segments longer than a wave (uniform trip count)
+                        const int off = off0 + lane;
+                        const bool on = off < l[u];
+                        // (a run of equal rows that crosses the 64-entry cut continues in the next instruction: later in
+                        // program order, hence after it)
+                        pb_seg_add(my, on ? (int)a.pr[s[u] + off] : 0, on ? a.P[s[u] + off] : 0.0, on, lane, 0, a.strict != 0);
+                    }
                 }
             }
         } else {
@@ -702,8 +748,17 @@ __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)
                     r4[u] = on ? (int)a.pr[s[u] + li] : 0;
                 }
 #pragma unroll
-                for (int u = 0; u < DEPTH; u++)
-                    if (li < l[u]) unsafeAtomicAdd(&my[r4[u]], pv4[u]);
+                for (int u = 0; u < DEPTH; u++) {
+                    if (!a.strict) {
+                        if (li < l[u]) unsafeAtomicAdd(&my[r4[u]], pv4[u]);
+                    } else {
+                        // strict: the lane groups (= consecutive column blocks) one after the other, each ranked by itself --
+                        // a row that occurs in two groups gets the lower column block's product first by program order
+#pragma unroll
+                        for (int gg = 0; gg < G; gg++)
+                            pb_seg_add(my, r4[u], pv4[u], g == gg && li < l[u], lane, gg * LPS, true);
+                    }
+                }
             }
         }
     }
@@ -801,6 +856,10 @@ int launch_pb_phase2(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
     b.alpha = a.alpha; b.beta = a.beta;
     b.y = a.y; b.dot = a.dot; b.w = a.w; b.parts = a.parts;
     b.st = a.loop.st;
+    {
+        const char *e = getenv("CUDAMAT_PB_STRICT");          // (read per launch: the guard test switches it inside one process)
+        b.strict = e && e[0] == '1' ? 1 : 0;
+    }
     const size_t lds = sizeof(double) * ((size_t)p.NW * p.SR + 2 * (size_t)p.NW);
 #define CM_P2D(NWV, LPSV, DV)                                                                             \
     do {                                                                                                  \

@@ -476,9 +476,15 @@ def test_blocked_spmv_is_bit_exact(cm, ctx, oracle, case, monkeypatch):
         S.sort_indices()
         A = oracle.Csr(n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), n)
     x = rng.standard_normal(A.n)
-    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
-    d = rng.standard_normal(A.n)
-    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
+    # default: one ds_add_f64 instruction per segment step, relying on the observed lane order of equal addresses;
+    # CUDAMAT_PB_STRICT=1: every rank of a run of equal rows is its own instruction -- the order of a row's additions is
+    # architected.  Both must reproduce the reference loop bit for bit (the 20000-column cases have runs of ~25 equal rows
+    # per step, the dense row of `ragged` runs that cross the 64-entry cut): this is the guard of the observed property.
+    for strict in ("0", "1"):
+        monkeypatch.setenv("CUDAMAT_PB_STRICT", strict)
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
+        d = rng.standard_normal(A.n)
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
 
 
 def test_blocked_spmv_in_the_solver_loop(cm, ctx, oracle, golden_dir, monkeypatch):
@@ -1262,9 +1268,15 @@ def test_sell_spmv_is_bit_exact(cm, ctx, oracle, case, monkeypatch):
         A = _skewed_matrix(oracle, case, rng)
     A.val[:] = rng.standard_normal(A.nnz)
     x = rng.standard_normal(A.n)
-    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
-    d = rng.standard_normal(A.n)
-    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
+    # default: one ds_add_f64 instruction per segment step, relying on the observed lane order of equal addresses;
+    # CUDAMAT_PB_STRICT=1: every rank of a run of equal rows is its own instruction -- the order of a row's additions is
+    # architected.  Both must reproduce the reference loop bit for bit (the 20000-column cases have runs of ~25 equal rows
+    # per step, the dense row of `ragged` runs that cross the 64-entry cut): this is the guard of the observed property.
+    for strict in ("0", "1"):
+        monkeypatch.setenv("CUDAMAT_PB_STRICT", strict)
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
+        d = rng.standard_normal(A.n)
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
     # non-finite input: only the rows that hold column 3 see it
     x2 = x.copy()
     x2[3] = np.inf
