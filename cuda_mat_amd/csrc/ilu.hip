@@ -626,6 +626,12 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
     int occ = 8;                           // workgroups per CU the dependency-driven launch may keep resident
     bool lds = false;                      // n <= 16384, narrow levels: the whole solve in one workgroup, x in LDS
     unsigned *tickets = nullptr;           // device: one chunk-ticket counter per dependency-driven launch (group)
+    // far phase 1 beside the previous group's near launch (round 3): the column blocks of far[g] whose positions lie in
+    // groups <= g-2 are final one group earlier; they run on `side` while group g-1 is solved
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_near, ev_p1a;
+    std::vector<int> ready_blocks;         // per group: leading column blocks of its far plan that may run early
+    size_t p1_lds = 0;                     // largest dynamic LDS request of the far plans' phase 1
 };
 
 }  // namespace cm
@@ -688,6 +694,9 @@ int ilu0_release(cudamat_solver *s)
             for (PbPlan &fp : h->far) pb_free(&fp);
             if (h->far_buf) hipFree(h->far_buf);
             if (h->tickets) hipFree(h->tickets);
+            for (hipEvent_t e : h->ev_near) if (e) hipEventDestroy(e);
+            for (hipEvent_t e : h->ev_p1a) if (e) hipEventDestroy(e);
+            if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
         }
         if (pl->err_host) hipHostFree(pl->err_host);
         if (pl->posU) hipFree(pl->posU);
@@ -1375,6 +1384,42 @@ int ilu0_setup(cudamat_solver *s, bool block)
                 if (!h->tickets && (rc = dalloc(&h->tickets, k))) break;
             }
             if (rc) break;
+            // far phase 1 beside the near launches (level-major factors, dependency-driven solves): which blocks of every
+            // far plan are final one group early, a side stream, one event pair per group.  Built and measured in round 3
+            // (alternating A/B at C5): 4.95 ms per L^-1 U^-1 with the overlap against 4.78 without -- the streaming
+            // phase 1 and the gathering near launch compete for the same fabric requests, and the near launch loses its
+            // one-workgroup-per-CU residency.  So it is OFF unless CUDAMAT_TRSV_OVERLAP=1.
+            {
+                const char *ov = getenv("CUDAMAT_TRSV_OVERLAP");
+                const bool want_ov = ov && ov[0] == '1';
+                for (int f = 0; f < 2 && want_ov; f++) {
+                    TriHost *h = f ? &pl->U : &pl->L;
+                    const TriFactor &F = f ? s->U : s->L;
+                    if (!h->hybrid || !h->syncfree || !F.lm) continue;
+                    const int K = (int)h->grp_level.size() - 1;
+                    h->ready_blocks.assign((size_t)K, 0);
+                    bool any = false;
+                    for (int g = 2; g < K; g++) {
+                        const PbPlan &fp = h->far[(size_t)g];
+                        if (fp.nnz <= 0 || fp.CB <= 0) continue;
+                        const long long start_prev = F.level_ptr[(size_t)h->grp_level[(size_t)g - 1]];     // first position of group g-1
+                        int rb = (int)(start_prev / fp.CB);
+                        if (rb > fp.NCB) rb = fp.NCB;
+                        h->ready_blocks[(size_t)g] = rb;
+                        any = any || rb > 0;
+                        const size_t need = pb_phase1_lds_bytes(fp);
+                        h->p1_lds = need > h->p1_lds ? need : h->p1_lds;
+                    }
+                    if (!any) { h->ready_blocks.clear(); continue; }
+                    bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
+                    h->ev_near.assign((size_t)K, nullptr);
+                    h->ev_p1a.assign((size_t)K, nullptr);
+                    for (int g = 0; g < K && ok; g++)
+                        ok = hipEventCreateWithFlags(&h->ev_near[(size_t)g], hipEventDisableTiming) == hipSuccess &&
+                             hipEventCreateWithFlags(&h->ev_p1a[(size_t)g], hipEventDisableTiming) == hipSuccess;
+                    if (!ok) h->ready_blocks.clear();            // (no overlap: everything on the solver's stream)
+                }
+            }
         }
         s->has_ilu = true;
     } while (0);
@@ -1387,6 +1432,22 @@ int ilu0_setup(cudamat_solver *s, bool block)
         set_error("%s", saved);
     }
     return rc;
+}
+
+static SpmvArgs far_args(const TriFactor &F, const TriHost &H, int grp, const double *out)
+{
+    const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)grp]];
+    SpmvArgs a{};
+    a.n = H.far[(size_t)grp].n;
+    a.x = out;
+    a.alpha = 1.0;
+    a.beta = 0.0;
+    a.y = H.far_buf + r0;
+    a.dot = 0;
+    a.loop = LoopArgs{nullptr, nullptr, 0, 0, 0};
+    a.check = CHECK_NONE;
+    a.half = ScalarSrc{nullptr, 0, 1};
+    return a;
 }
 
 // the far SpMV of one group: far_buf[rows of the group] = far_g . out
@@ -1446,13 +1507,32 @@ static int launch_trsv_syncfree_b(hipStream_t st, const TriFactor &F, const TriH
                        (unsigned long long *)out);
     const int K = (int)H.grp_level.size() - 1;
     CM_HIP(hipMemsetAsync(H.tickets, 0, sizeof(unsigned) * (size_t)(K > 0 ? K : 1), st));     // one ticket counter per launch
+    // Far phase 1 beside the near launches: the blocks of far[g + 1] whose positions lie in groups <= g - 1 are final as
+    // soon as group g - 1 is solved, so they are issued on the side stream (behind group g - 1's event) right before
+    // group g's own launches go to the solver's stream -- the streaming phase 1 then runs while group g's far rest, its
+    // phase 2 and its dependency-driven launch (whose waves spend much of their time waiting) occupy the solver's stream.
+    const bool ov = !H.ready_blocks.empty() && H.side != nullptr;
     for (int g = 0; g < K; g++) {
         const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)g]], r1 = F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]];
         if (r1 <= r0) continue;
         const double *far = nullptr;
         if (H.hybrid && g > 0 && H.far[(size_t)g].nnz > 0) {
-            CM_TRY(launch_far(st, F, H, g, out));
+            const int early = ov ? H.ready_blocks[(size_t)g] : 0;
+            if (early > 0) {
+                const SpmvArgs a = far_args(F, H, g, out);
+                CM_HIP(hipStreamWaitEvent(st, H.ev_p1a[(size_t)g], 0));                    // the early blocks (side stream)
+                CM_TRY(launch_pb_phase1_range(st, H.far[(size_t)g], a, early, H.far[(size_t)g].NCB));
+                CM_TRY(launch_pb_phase2(st, H.far[(size_t)g], a));
+            } else {
+                CM_TRY(launch_far(st, F, H, g, out));
+            }
             far = H.far_buf;
+        }
+        if (ov && g + 1 < K && g >= 1 && H.ready_blocks[(size_t)g + 1] > 0 && H.far[(size_t)g + 1].nnz > 0) {
+            const SpmvArgs a1 = far_args(F, H, g + 1, out);
+            CM_HIP(hipStreamWaitEvent(H.side, H.ev_near[(size_t)g - 1], 0));               // groups <= g - 1 are final
+            CM_TRY(launch_pb_phase1_range(H.side, H.far[(size_t)g + 1], a1, 0, H.ready_blocks[(size_t)g + 1]));
+            CM_HIP(hipEventRecord(H.ev_p1a[(size_t)g + 1], H.side));
         }
         // A ticket = `steps` consecutive sub-chunks of RPB rows: at least 256 rows, so that the one counter sees an
         // atomic per 256 rows at most (far below what one address sustains).  The rows in flight are
@@ -1466,11 +1546,18 @@ static int launch_trsv_syncfree_b(hipStream_t st, const TriFactor &F, const TriH
         // no more workgroups than can be resident; more would only queue behind the persistent ones
         const long long cap = (long long)per_cu * 256;
         const unsigned grid = (unsigned)(ntick < cap ? ntick : cap);
-        // residency is pinned with an (unused) dynamic LDS request: fewer waiting workgroups, fewer pollers
-        const size_t lds_pad = (size_t)(152 * 1024) / (size_t)per_cu;
+        // residency is pinned with an (unused) dynamic LDS request: fewer waiting workgroups, fewer pollers; with the far
+        // phase 1 running beside it, room is left for one of its workgroups (x tile) per compute unit
+        size_t lds_pad = (size_t)(152 * 1024) / (size_t)per_cu;
+        if (ov && per_cu == 1) {
+            const size_t room = (size_t)160 * 1024 - 2048;
+            lds_pad = room > H.p1_lds ? room - H.p1_lds : 0;
+            if (lds_pad > (size_t)(152 * 1024)) lds_pad = (size_t)(152 * 1024);
+        }
         CM_TRY(set_max_lds((const void *)k_trsv_syncfree<LANES, BLOCK>));
         hipLaunchKernelGGL((k_trsv_syncfree<LANES, BLOCK>), dim3(grid), dim3(BLOCK), lds_pad, st, r0, r1, F.rp, F.ci, F.val,
                            F.rhs_of, F.out_of, F.dinv, far, rhs, out, err, H.spin_limit, H.nap, H.tickets + g, steps);
+        if (ov) CM_HIP(hipEventRecord(H.ev_near[(size_t)g], st));
     }
     return CUDAMAT_OK;
 }

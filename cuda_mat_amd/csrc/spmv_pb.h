@@ -66,5 +66,8 @@ int launch_spmv_pb(hipStream_t st, const PbPlan &plan, const SpmvArgs &a);
 int launch_pb_check(hipStream_t st, const SpmvArgs &a);
 int launch_pb_phase1(hipStream_t st, const PbPlan &plan, const SpmvArgs &a, int part);
 int launch_pb_phase2(hipStream_t st, const PbPlan &plan, const SpmvArgs &a);
+// phase 1 of the column blocks [b0, b1) in index order; dynamic LDS of a phase-1 workgroup
+int launch_pb_phase1_range(hipStream_t st, const PbPlan &plan, const SpmvArgs &a, int b0, int b1);
+size_t pb_phase1_lds_bytes(const PbPlan &plan);
 
 }  // namespace cm

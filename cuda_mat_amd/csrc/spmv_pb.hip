@@ -440,14 +440,14 @@ constexpr int kP1U = 4;                // steps per chunk of the pipelined loop 
 
 __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const int *col0, const int *list,
                                                           const int *cstart, const double *pv, const u16 *pc,
-                                                          double *P, const LoopState *st, int pipelined, int split)
+                                                          double *P, const LoopState *st, int pipelined, int split, int cb0)
 {
     extern __shared__ __attribute__((aligned(16))) double xs[];
     if (st && st->state != 0) return;
     // split > 1: `split` workgroups share a column block (each stages the x tile and streams one slice of the block's
     // entries): a finer grain for the dispatcher at the end of the launch
     const int bi = (int)blockIdx.x / split, part = (int)blockIdx.x - bi * split;
-    const int cb = list ? list[bi] : bi;
+    const int cb = list ? list[bi] : bi + cb0;
     int s = cstart[cb], e = cstart[cb + 1];
     if (split > 1) {
         const int len = e - s, per = ((len + split - 1) / split + 1) & ~1;
@@ -550,11 +550,11 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const
 __global__ __launch_bounds__(kP1Threads) void k_pb_phase1_dict(const double *x, const int *col0, const int *list,
                                                                const int *cstart, const unsigned char *pvi, const u16 *pc,
                                                                const double *dict, int cb_doubles, double *P,
-                                                               const LoopState *st)
+                                                               const LoopState *st, int cb0)
 {
     extern __shared__ __attribute__((aligned(16))) double xs[];
     if (st && st->state != 0) return;
-    const int cb = list ? list[blockIdx.x] : (int)blockIdx.x;
+    const int cb = list ? list[blockIdx.x] : (int)blockIdx.x + cb0;
     const int s = cstart[cb], e = cstart[cb + 1];
     if (s == e) return;                                    // (block-uniform) nothing stored in this block
     double *dv = xs + cb_doubles;
@@ -816,17 +816,16 @@ int launch_pb_check(hipStream_t st, const SpmvArgs &a)
     return CUDAMAT_OK;
 }
 
-int launch_pb_phase1(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int part)
+// phase 1 of the column blocks [first, last) in index order (list == nullptr) or of order[first .. last)
+static int launch_pb_phase1_blocks(hipStream_t st, const PbPlan &p, const SpmvArgs &a, const int *list, int first, int last)
 {
-    // part < 0: every block in index order; otherwise the blocks of one launch part (PbPlan::order)
-    const int first = part < 0 ? 0 : p.part_off[part], last = part < 0 ? p.NCB : p.part_off[part + 1];
     if (last <= first) return CUDAMAT_OK;
     if (p.pvi) {
         CM_TRY(set_max_lds((const void *)k_pb_phase1_dict));
         const int cbd = (p.CB + 1) & ~1;                     // the dictionary starts 16-byte aligned behind the x tile
         hipLaunchKernelGGL(k_pb_phase1_dict, dim3(last - first), dim3(kP1Threads), sizeof(double) * (size_t)(cbd + kDictMax), st, a.x,
-                           p.col0, part < 0 ? (const int *)nullptr : p.order + first, p.cstart, p.pvi, p.pc, p.dict, cbd, p.P,
-                           a.loop.st);
+                           p.col0, list ? list + first : (const int *)nullptr, p.cstart, p.pvi, p.pc, p.dict, cbd, p.P, a.loop.st,
+                           list ? 0 : first);
         CM_HIP(hipGetLastError());
         return CUDAMAT_OK;
     }
@@ -834,9 +833,28 @@ int launch_pb_phase1(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int par
     static const int pipelined = [] { const char *e = getenv("CUDAMAT_PB_PIPELINE"); return e && e[0] == '1' ? 1 : 0; }();
     static const int split = [] { const char *e = getenv("CUDAMAT_PB_SPLIT"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
     hipLaunchKernelGGL(k_pb_phase1, dim3((last - first) * split), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x, p.col0,
-                       part < 0 ? (const int *)nullptr : p.order + first, p.cstart, p.pv, p.pc, p.P, a.loop.st, pipelined, split);
+                       list ? list + first : (const int *)nullptr, p.cstart, p.pv, p.pc, p.P, a.loop.st, pipelined, split, list ? 0 : first);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
+}
+
+int launch_pb_phase1(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int part)
+{
+    // part < 0: every block in index order; otherwise the blocks of one launch part (PbPlan::order)
+    if (part < 0) return launch_pb_phase1_blocks(st, p, a, nullptr, 0, p.NCB);
+    return launch_pb_phase1_blocks(st, p, a, p.order, p.part_off[part], p.part_off[part + 1]);
+}
+
+// phase 1 of the column blocks [b0, b1) only (the triangular solves run the blocks whose columns are final early)
+int launch_pb_phase1_range(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int b0, int b1)
+{
+    return launch_pb_phase1_blocks(st, p, a, nullptr, b0 < 0 ? 0 : b0, b1 > p.NCB ? p.NCB : b1);
+}
+
+// bytes of dynamic LDS a phase-1 workgroup of this plan asks for (what a co-resident kernel must leave free)
+size_t pb_phase1_lds_bytes(const PbPlan &p)
+{
+    return p.pvi ? sizeof(double) * (size_t)(((p.CB + 1) & ~1) + kDictMax) : sizeof(double) * (size_t)p.CB;
 }
 
 int launch_spmv_pb(hipStream_t st, const PbPlan &p, const SpmvArgs &a)

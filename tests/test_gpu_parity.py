@@ -690,6 +690,11 @@ def test_dependency_driven_trsv_equals_level_solve(cm, ctx, oracle, golden_dir, 
     else:
         A = _load(oracle, golden_dir, name)
     monkeypatch.setenv("CUDAMAT_TRSV_HYBRID", "1" if name.endswith("hybrid") else "0")
+    if name.endswith("hybrid"):
+        # (also the optional form that runs the early column blocks of a group's far phase 1 on a side stream, beside the
+        # previous group's dependency-driven launch: same data, same order of additions => the same bits)
+        monkeypatch.setenv("CUDAMAT_TRSV_OVERLAP", "1")
+        monkeypatch.setenv("CUDAMAT_TRSV_GROUPS", "5")
     rng = np.random.default_rng(4)
     rhs = [rng.standard_normal(A.n) for _ in range(3)]
     got = {}
