@@ -208,5 +208,27 @@ def test_full_size_ilu0_c5(cm, monkeypatch):
     np.testing.assert_allclose(x.download(), xs.download(), rtol=1e-6)
     s.spmv(x, ax)
     assert np.linalg.norm(b.download() - ax.download()) <= 1e-7 * st.nrm0
+    # the loop in the level-major spaces (default, used above) and the one that permutes around every application of M^-1
+    # return the same solution; and the optional form with the early far blocks on a side stream gives the same bits as
+    # the default triangular solves
+    x_perm = x.download()
+    monkeypatch.setenv("CUDAMAT_TRSV_PERM", "0")
+    st0 = s.solve(b, x, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PBICGSTAB, maxit=100, tol=1e-8, flags=cm.FLAG_X0_ONES)
+    monkeypatch.delenv("CUDAMAT_TRSV_PERM")
+    assert st0.converged and abs(st0.iters - st.iters) <= 1
+    np.testing.assert_allclose(x.download(), x_perm, rtol=1e-8)
+    s.precond_apply(rhs, out1)
+    h_default = out1.download()
+    np.testing.assert_array_equal(h_default, h_out)               # level-major storage, same bits as at the top
     s.close()
+    monkeypatch.setenv("CUDAMAT_TRSV_OVERLAP", "1")
+    nnz2, rp, ci, va = _system(cm, ctx, "rand50")
+    s2 = cm.Solver(ctx, N, N, nnz2, rp, ci, va, 0)
+    for t in (rp, ci, va):
+        t.free()
+    s2.ilu0()
+    s2.precond_apply(rhs, out0)
+    np.testing.assert_array_equal(out0.download(), h_default)
+    s2.close()
+    monkeypatch.delenv("CUDAMAT_TRSV_OVERLAP")
     ctx.close()
