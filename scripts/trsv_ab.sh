@@ -1,0 +1,10 @@
+#!/bin/bash
+# GPU box: C5 per-application time of L^-1 U^-1, alternating env configurations R times
+# usage: scripts/trsv_ab.sh R "ENV=.. ENV=.." "ENV=.." ...
+R=$1; shift
+for r in $(seq $R); do for cfg in "$@"; do
+  out=$(env $cfg timeout -k 10 300 python bench.py --precond ilu0 --steps 10 --warmup 2 --cpu-baseline off --drop-in off 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.3f ms per apply  %.2f it/s' % (d['trsv_ms_per_apply'], d['value']))")
+  echo "run $r [$cfg] $out"
+done; done
