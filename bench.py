@@ -669,8 +669,7 @@ def run_bench(args):
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     vec_bytes = 144.0 * nloc
     blocked = solver.spmv_mode() == 1
-    kernel = ("%s + k_pb_phase2 (one SpMV = the pair)" % ("k_pb_phase1_dict" if solver.value_dict() > 0 else "k_pb_phase1")
-              if blocked else "k_spmv_sell" if solver.spmv_mode() == 2 else "k_spmv")
+    kernel = solver.spmv_kernel() + (" (one SpMV = the pair)" if blocked else "")
     if n_spmv == 0:
         kernel += " (L2-resident, launch-latency-bound: per-launch timing off, no roofline quoted)"
     # HBM bytes per SpMV launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,

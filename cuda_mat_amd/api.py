@@ -323,6 +323,12 @@ class Solver:
         check(_lib.lib().cudamat_solver_spmv_mode(self.h, C.byref(m)))
         return m.value
 
+    def spmv_kernel(self):
+        """name(s) of the kernel(s) one SpMV launch runs, as a kernel trace shows them"""
+        buf = C.create_string_buffer(96)
+        check(_lib.lib().cudamat_solver_spmv_kernel(self.h, buf, 96))
+        return buf.value.decode()
+
     def value_dict(self):
         """distinct values when the selected SpMV form reads 8-bit indices into a value dictionary, else 0"""
         m = C.c_int()

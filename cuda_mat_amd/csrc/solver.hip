@@ -803,6 +803,22 @@ extern "C" int cudamat_solver_value_dict(cudamat_solver *s, int *distinct)
     return CUDAMAT_OK;
 }
 
+extern "C" int cudamat_solver_spmv_kernel(cudamat_solver *s, char *name, int cap)
+{
+    CM_ARG(s && name && cap > 0, "null pointer");
+    CM_HIP(hipSetDevice(s->ctx->device));
+    CM_TRY(ensure_work(s));
+    CM_TRY(ensure_spmv_mode(s));
+    const SpmvPlan &p = s->plan;
+    if (s->spmv_mode == 1) snprintf(name, (size_t)cap, "%s + k_pb_phase2", s->pb.pvi ? "k_pb_phase1_dict" : "k_pb_phase1");
+    else if (s->spmv_mode == 2) snprintf(name, (size_t)cap, "k_spmv_sell");
+    else if (p.tiles > 0) snprintf(name, (size_t)cap, "k_spmv_tiles");
+    else if (p.stream_rows && p.c_off16) snprintf(name, (size_t)cap, "%s<%d>", p.d_pbase ? "k_spmv_stream_d" : "k_spmv_stream_c", p.stream_rows);
+    else if (p.stream_rows) snprintf(name, (size_t)cap, "k_spmv_stream<%d>", p.stream_rows);
+    else snprintf(name, (size_t)cap, "k_spmv<%d>", p.lanes);
+    return CUDAMAT_OK;
+}
+
 extern "C" int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, double *y_local)
 {
     CM_ARG(s && x_local && y_local, "null pointer");

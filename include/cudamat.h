@@ -281,6 +281,9 @@ int cudamat_solver_spmv_mode(cudamat_solver *s, int *mode);
  * values; results are bit-identical, HBM traffic drops by 7 bytes per entry), 0 when it reads the values themselves.
  * CUDAMAT_VALUE_DICT=0 in the environment disables the dictionary.                                                  */
 int cudamat_solver_value_dict(cudamat_solver *s, int *distinct);
+/* name(s) of the HIP kernel(s) one SpMV launch of this solver runs (e.g. "k_pb_phase1 + k_pb_phase2", "k_spmv_stream_c<256>",
+ * "k_spmv<32>"): what a rocprofv3 kernel trace of the loop shows, for the bench line's `roofline.kernel`            */
+int cudamat_solver_spmv_kernel(cudamat_solver *s, char *name, int cap);
 /* y_local = (A + diag(d)) x ; x is the LOCAL slice, gathered through comm if sharded  */
 int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, double *y_local);
 /* Solve.  b, x: device vectors of n_local doubles; x holds the initial guess on entry

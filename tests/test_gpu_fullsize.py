@@ -42,6 +42,8 @@ def test_full_size_spmv_properties(cm, kind, monkeypatch):
         monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
         s = cm.Solver(ctx, N, N, nnz, rp, ci, va, 0)
         assert s.spmv_mode() == (1 if mode == "pb" else 0)
+        # the name the bench line's roofline.kernel carries = the kernel(s) a trace of this SpMV shows
+        assert s.spmv_kernel().startswith("k_pb_phase1" if mode == "pb" else "k_spmv_stream" if kind == "poisson5" else "k_spmv<")
         y1, y2, y3 = ctx.empty(N), ctx.empty(N), ctx.empty(N)
         s.spmv(xs, y1)
         s.spmv(x2, y2)

@@ -1320,6 +1320,7 @@ def test_sell_in_the_solver_loop_and_auto_selection(cm, ctx, oracle, monkeypatch
             monkeypatch.delenv("CUDAMAT_SPMV_MODE")
         s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
         chosen = s.spmv_mode()
+        assert s.spmv_kernel() == "k_spmv_sell" if chosen == 2 else s.spmv_kernel().startswith("k_spmv")
         db, dx = ctx.array(b), ctx.array(np.ones(n))
         st = s.solve(db, dx, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-8)
         res[mode] = (dx.download(), st.iters, chosen)
