@@ -900,6 +900,13 @@ static void plan_groups(const TriFactor &F, TriHost &H, bool hybrid)
     H.hybrid = K > 1;
     H.grp_level.assign((size_t)K + 1, 0);
     for (int g = 0; g <= K; g++) H.grp_level[(size_t)g] = (int)((long long)nlev * g / K);
+    if (getenv("CUDAMAT_VERBOSE") && K > 1) {
+        fprintf(stderr, "cudamat: trsv groups (levels:rows)");
+        for (int g = 0; g < K; g++)
+            fprintf(stderr, " %d:%d", H.grp_level[(size_t)g + 1] - H.grp_level[(size_t)g],
+                    F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]] - F.level_ptr[(size_t)H.grp_level[(size_t)g]]);
+        fprintf(stderr, "\n");
+    }
     // launch plan: a big level is its own segment; consecutive small levels are merged (inside a group)
     H.seg_begin.clear();
     H.seg_end.clear();
