@@ -184,13 +184,13 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *lds_waves, int *
     return before + inc - v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_pb_colscan(int NCB, const int *colsum, int *cstart)
+__global__ __launch_bounds__(kBlock) void k_pb_colscan(int NCB, const int *colsum, int *cstart, int align)
 {
     __shared__ int lds_waves[kBlock / 64];
     int run = 0;
     for (int c0 = 0; c0 < NCB; c0 += kBlock) {
         const int c = c0 + threadIdx.x;
-        const int v = c < NCB ? colsum[c] : 0;
+        const int v = c < NCB ? (colsum[c] + align - 1) / align * align : 0;     // every block starts on an `align` boundary
         int total;
         const int ex = block_exclusive_scan(v, lds_waves, &total);
         if (c < NCB) cstart[c] = run + ex;
@@ -305,14 +305,25 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     int rc = CUDAMAT_OK;
     do {
         if ((rc = dalloc(&bins, nbins))) break;
+        // Every column block's entries start on a 64-entry boundary (round 3): the 1 KB product stores, the 1 KB value loads
+        // and the 256-byte column loads of a wave in phase 1 then cover whole 128-byte lines (the blocks hold ~650 K entries
+        // at C4: <= 63 idle slots each, zero value x column 0, never read by phase 2).  CUDAMAT_PB_ALIGN=1 packs them.
+        int align = 64;
+        if (const char *e = getenv("CUDAMAT_PB_ALIGN")) { const int v = atoi(e); if (v == 1 || v == 16 || v == 64 || v == 128) align = v; }
+        const size_t cap = (size_t)nnz + (size_t)(align - 1) * (size_t)p.NCB + 16;
         if (vd && vd->n > 0) {
-            if ((rc = dalloc(&p.pvi, (size_t)nnz + 16))) break;
+            if ((rc = dalloc(&p.pvi, cap))) break;
+            if (align > 1 && hipMemsetAsync(p.pvi, 0, cap, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
             p.dict = vd->dict;
             p.ndict = vd->n;
-        } else if ((rc = dalloc(&p.pv, (size_t)nnz))) break;
-        if ((rc = dalloc(&p.pc, (size_t)nnz + 8))) break;
-        if ((rc = dalloc(&p.pr, (size_t)nnz + 8))) break;
-        if ((rc = dalloc(&p.P, (size_t)nnz + 8))) break;
+        } else {
+            if ((rc = dalloc(&p.pv, cap))) break;
+            if (align > 1 && hipMemsetAsync(p.pv, 0, sizeof(double) * cap, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        }
+        if ((rc = dalloc(&p.pc, cap))) break;
+        if (align > 1 && hipMemsetAsync(p.pc, 0, sizeof(u16) * cap, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        if ((rc = dalloc(&p.pr, cap))) break;
+        if ((rc = dalloc(&p.P, cap))) break;
         if ((rc = dalloc(&p.cstart, (size_t)p.NCB + 1))) break;
         if ((rc = dalloc(&p.col0, (size_t)p.NCB + 1))) break;
         if ((rc = dalloc(&p.order, (size_t)p.NCB))) break;
@@ -363,13 +374,15 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
                            p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr, (const unsigned char *)nullptr, (unsigned char *)nullptr);
         if (hipGetLastError() != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb count launch failed"); break; }
         hipLaunchKernelGGL(k_pb_colsum, dim3(p.NCB), dim3(kBlock), 0, st, p.NSUB, bins, p.cstart);   // cstart doubles as scratch
-        hipLaunchKernelGGL(k_pb_colscan, dim3(1), dim3(kBlock), 0, st, p.NCB, p.cstart, p.cstart);
+        hipLaunchKernelGGL(k_pb_colscan, dim3(1), dim3(kBlock), 0, st, p.NCB, p.cstart, p.cstart, align);
         hipLaunchKernelGGL(k_pb_segscan, dim3(p.NCB), dim3(kBlock), 0, st, p.NCB, p.NSUB, p.cstart, bins, p.sstart, p.slen);
         int counted = -1;
         if (hipGetLastError() != hipSuccess ||
             hipMemcpyAsync(&counted, p.cstart + p.NCB, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb scan failed"); break; }
-        if ((int64_t)counted != nnz) { rc = CUDAMAT_ERR_ARG; set_error("pb_build: counted %d entries, expected %lld", counted, (long long)nnz); break; }
+        if ((int64_t)counted < nnz || (int64_t)counted > nnz + (int64_t)(align - 1) * p.NCB) {
+            rc = CUDAMAT_ERR_ARG; set_error("pb_build: counted %d entries, expected %lld", counted, (long long)nnz); break;
+        }
         hipLaunchKernelGGL(k_pb_rows<true>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, cut, p.col0,
                            p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr, p.pvi ? vd->idx : (const unsigned char *)nullptr, p.pvi);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
