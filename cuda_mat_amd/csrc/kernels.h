@@ -34,6 +34,11 @@ struct SpmvPlan {
     short *c_off16 = nullptr;
     unsigned char *c_len8 = nullptr;
     int *c_tile_base = nullptr;
+    // line-aligned copies for the compressed stream kernel (plan_spmv_align, round 3): every tile's entries start on a
+    // 64-entry boundary, so each wave's 512-byte value load and 128-byte offset load covers whole 128-byte lines
+    int *a_base = nullptr;              // ntiles + 1: first entry slot of every tile
+    short *a_off16 = nullptr;
+    double *a_val = nullptr;
     // the matrix's value dictionary (valdict.h; 256 doubles on the device, not owned) when the copies below exist
     const double *c_dict = nullptr;
     // dictionary form of the compressed stream kernel (plan_spmv_dict): per tile, the entries' 16-bit offsets and 8-bit
@@ -106,6 +111,7 @@ int launch_fused_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, co
 int plan_spmv_compress(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const int *ci, SpmvPlan *plan);
 // compressed stream plans of a matrix with a value dictionary (valdict.h): vidx = 8-bit value index per entry in CSR
 // order, dict = 256 doubles on the device (not owned); no-op when the plan has no compressed copy
+int plan_spmv_align(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const double *val, SpmvPlan *plan);
 int plan_spmv_dict(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const unsigned char *vidx, const double *dict,
                    SpmvPlan *plan);
 

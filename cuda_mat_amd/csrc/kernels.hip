@@ -425,7 +425,7 @@ __device__ __forceinline__ int block_scan_int(int v, int *lds_waves, int *total)
 
 template <int R>
 __global__ __launch_bounds__(kBlock) void k_spmv_stream_c(SpmvArgs a, int tiles_per_block, const int *tile_base,
-                                                          const short *off16, const unsigned char *len8)
+                                                          const short *off16, const unsigned char *len8, const double *vals)
 {
     __shared__ double prod[kStreamNnz];
     __shared__ int srp[R + 1];
@@ -452,14 +452,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream_c(SpmvArgs a, int tiles_
         if (r0l >= a.n) continue;
         const int r0 = (int)r0l;
         const int nr = a.n - r0 < R ? a.n - r0 : R;
-        const int base = tile_base[tile], cnt = tile_base[tile + 1] - base;
+        const int base = tile_base[tile];                 // (tiles may be padded: the count comes from the row lengths)
         const int len = tid < nr ? (int)len8[r0 + tid] : 0;
-        int total;
-        const int start = block_scan_int(len, scan_w, &total);
+        int cnt;
+        const int start = block_scan_int(len, scan_w, &cnt);
         if (tid < nr) srp[tid] = start;
-        if (tid == 0) srp[nr] = total;
+        if (tid == 0) srp[nr] = cnt;
         for (int k = tid; k < cnt; k += kBlock)
-            prod[k] = __builtin_nontemporal_load(a.val + base + k) * a.x[r0 + (int)__builtin_nontemporal_load(off16 + base + k)];
+            prod[k] = __builtin_nontemporal_load(vals + base + k) * a.x[r0 + (int)__builtin_nontemporal_load(off16 + base + k)];
         __syncthreads();
         if (tid < nr) {
             const int row = r0 + tid;
@@ -631,7 +631,7 @@ int plan_spmv_compress(hipStream_t s, int n_rows, int64_t nnz, const int *rp, co
 
 // ---- padded per-tile copies for the dictionary form
 // one workgroup: exclusive scan of the tiles' entry counts rounded up to 8 -> pbase[0..ntiles]
-__global__ __launch_bounds__(kBlock) void k_tile_pad_scan(int n, int R, int ntiles, const int *rp, int *pbase)
+__global__ __launch_bounds__(kBlock) void k_tile_pad_scan(int n, int R, int ntiles, const int *rp, int *pbase, int round_to)
 {
     __shared__ int scan_w[kBlock / 64];
     int run = 0;
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_pad_scan(int n, int R, int ntil
         if (t < ntiles) {
             const long long r1 = (long long)(t + 1) * R;
             const int cnt = rp[r1 < n ? r1 : n] - rp[(long long)t * R];
-            padded = (cnt + 7) & ~7;
+            padded = (cnt + round_to - 1) / round_to * round_to;
         }
         int total;
         const int ex = block_scan_int(padded, scan_w, &total);
@@ -668,6 +668,63 @@ __global__ __launch_bounds__(kBlock) void k_tile_pad_fill(int n, int R, const in
     }
 }
 
+// an 8-lane team per row copies the row's offsets and values to their places in the aligned copies
+__global__ __launch_bounds__(kBlock) void k_tile_align_fill(int n, int R, const int *rp, const short *off16, const double *val,
+                                                            const int *abase, short *off16a, double *vala)
+{
+    constexpr int L = 8;
+    const long long row = ((long long)blockIdx.x * kBlock + threadIdx.x) / L;
+    if (row >= n) return;
+    const int lane = threadIdx.x & (L - 1);
+    const int t = (int)(row / R);
+    const int s = rp[row], e = rp[row + 1], first = rp[(long long)t * R];
+    const int dst = abase[t] + (s - first);
+    for (int k = s + lane; k < e; k += L) {
+        off16a[dst + (k - s)] = off16[k - rp[0]];
+        vala[dst + (k - s)] = val[k - rp[0]];
+    }
+}
+
+// Line-aligned copies of the compressed stream kernel's two entry streams (round 3).  The kernel is held by the rate of
+// L1 -> L2 requests, and a request moves at most one 128-byte line: with a tile's entries starting
+// anywhere, a wave's 512-byte value load touches five lines and its 128-byte offset load two; with every tile starting on
+// a 64-entry boundary they touch four and one.  Costs <= 63 idle slots per tile (2.5 % at 5 entries per row) and a second
+// copy of the values in HBM.  CUDAMAT_SPMV_ALIGN=0 keeps the packed arrays.
+int plan_spmv_align(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const double *val, SpmvPlan *plan)
+{
+    const char *env = getenv("CUDAMAT_SPMV_ALIGN");
+    if (!plan->stream_rows || !plan->c_off16 || nnz <= 0 || (env && env[0] == '0')) return CUDAMAT_OK;
+    const int R = plan->stream_rows;
+    const int ntiles = (int)(((long long)n_rows + R - 1) / R);
+    if (nnz + 63LL * ntiles > 0x7fffffffLL) return CUDAMAT_OK;
+    int total = 0, rc = CUDAMAT_OK;
+    do {
+        if (hipMalloc((void **)&plan->a_base, sizeof(int) * ((size_t)ntiles + 1)) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
+        hipLaunchKernelGGL(k_tile_pad_scan, dim3(1), dim3(kBlock), 0, s, n_rows, R, ntiles, rp, plan->a_base, 64);
+        if (hipMemcpyAsync(&total, plan->a_base + ntiles, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        if (total < nnz || (int64_t)total > nnz + 64LL * ntiles) { rc = CUDAMAT_ERR_HIP; break; }
+        if (hipMalloc((void **)&plan->a_off16, sizeof(short) * (size_t)total + 256) != hipSuccess ||
+            hipMalloc((void **)&plan->a_val, sizeof(double) * (size_t)total + 256) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
+        hipMemsetAsync(plan->a_off16, 0, sizeof(short) * (size_t)total + 256, s);      // idle slots: offset 0, value 0
+        hipMemsetAsync(plan->a_val, 0, sizeof(double) * (size_t)total + 256, s);
+        const long long threads = (long long)n_rows * 8;
+        hipLaunchKernelGGL(k_tile_align_fill, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, R, rp,
+                           plan->c_off16, val, plan->a_base, plan->a_off16, plan->a_val);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+    } while (0);
+    if (rc) {                                         // no memory / failure: the packed arrays stay
+        void *ptrs[] = {plan->a_base, plan->a_off16, plan->a_val};
+        for (void *q : ptrs)
+            if (q) hipFree(q);
+        plan->a_base = nullptr;
+        plan->a_off16 = nullptr;
+        plan->a_val = nullptr;
+        if (rc == CUDAMAT_ERR_HIP) return fail_hip(hipGetLastError(), "aligned stream copies", __FILE__, __LINE__);
+    }
+    return CUDAMAT_OK;
+}
+
 int plan_spmv_dict(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const unsigned char *vidx, const double *dict,
                    SpmvPlan *plan)
 {
@@ -677,7 +734,7 @@ int plan_spmv_dict(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const 
     int total = 0, rc = CUDAMAT_OK;
     do {
         if (hipMalloc((void **)&plan->d_pbase, sizeof(int) * ((size_t)ntiles + 1)) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
-        hipLaunchKernelGGL(k_tile_pad_scan, dim3(1), dim3(kBlock), 0, s, n_rows, R, ntiles, rp, plan->d_pbase);
+        hipLaunchKernelGGL(k_tile_pad_scan, dim3(1), dim3(kBlock), 0, s, n_rows, R, ntiles, rp, plan->d_pbase, 8);
         if (hipMemcpyAsync(&total, plan->d_pbase + ntiles, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
         if (total < nnz || (int64_t)total > nnz + 8LL * ntiles) { rc = CUDAMAT_ERR_HIP; break; }
@@ -927,7 +984,10 @@ __global__ __launch_bounds__(kBlock) void k_lane_cost(int n, const int *rp, int 
 void plan_spmv_free(SpmvPlan *plan)
 {
     void *ptrs[] = {plan->tile_S, plan->tile_span, plan->tile_heads, plan->tile_tails, plan->c_off16, plan->c_len8,
-                    plan->c_tile_base, plan->d_pbase, plan->d_off16, plan->d_val8};
+                    plan->c_tile_base, plan->d_pbase, plan->d_off16, plan->d_val8, plan->a_base, plan->a_off16, plan->a_val};
+    plan->a_base = nullptr;
+    plan->a_off16 = nullptr;
+    plan->a_val = nullptr;
     plan->d_pbase = nullptr;
     plan->d_off16 = nullptr;
     plan->d_val8 = nullptr;
@@ -1081,8 +1141,9 @@ int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a)
             hipLaunchKernelGGL(k_spmv_stream_d<RV>, g, b, 0, s, a, plan.rows_per_block, plan.d_pbase, plan.d_off16, plan.d_val8, \
                                plan.c_len8, plan.c_dict);                                                                 \
         else                                                                                                               \
-            hipLaunchKernelGGL(k_spmv_stream_c<RV>, g, b, 0, s, a, plan.rows_per_block, plan.c_tile_base, plan.c_off16,   \
-                               plan.c_len8);                                                                               \
+            hipLaunchKernelGGL(k_spmv_stream_c<RV>, g, b, 0, s, a, plan.rows_per_block,                                    \
+                               plan.a_base ? plan.a_base : plan.c_tile_base, plan.a_base ? plan.a_off16 : plan.c_off16,   \
+                               plan.c_len8, plan.a_base ? plan.a_val : a.val);                                             \
     } while (0)
         case 64:  CM_SC(64); break;
         case 128: CM_SC(128); break;

@@ -219,6 +219,12 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
                 return rc5;
             }
         }
+        if (!s->plan.d_pbase) {     // fp64 values: line-aligned copies of the two entry streams
+            if (int rc6 = plan_spmv_align(st, n_local, nnz, s->rp, s->val, &s->plan)) {
+                cudamat_solver_destroy(s);
+                return rc6;
+            }
+        }
     }
     s->t_create = now_s() - t_create0;
     *out = s;
