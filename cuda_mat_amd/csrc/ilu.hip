@@ -733,7 +733,11 @@ static void parallel_ranges(int n, int T, Fn fn)
     for (int t = 1; t < T; t++) {
         int lo, hi;
         range(t, lo, hi);
-        th.emplace_back([=] { fn(t, lo, hi); });
+        try {
+            th.emplace_back([=] { fn(t, lo, hi); });
+        } catch (...) {                    // no thread to be had: this range runs here
+            fn(t, lo, hi);
+        }
     }
     int lo, hi;
     range(0, lo, hi);
