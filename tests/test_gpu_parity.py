@@ -485,6 +485,10 @@ def test_blocked_spmv_is_bit_exact(cm, ctx, oracle, case, monkeypatch):
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
         d = rng.standard_normal(A.n)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
+    # the layout with the column blocks packed back to back (default: every block starts on a 128-byte line boundary)
+    monkeypatch.setenv("CUDAMAT_PB_STRICT", "0")
+    monkeypatch.setenv("CUDAMAT_PB_ALIGN", "1")
+    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
 
 
 def test_blocked_spmv_in_the_solver_loop(cm, ctx, oracle, golden_dir, monkeypatch):
@@ -1015,10 +1019,16 @@ def test_stream_spmv_with_compressed_indices(cm, ctx, oracle, case, monkeypatch)
     d = rng.integers(-2, 3, A.n).astype(np.float64)
     want = oracle.spmv(A, x)
     got = {}
-    for comp in ("0", "1"):
+    # plain stream kernel; compressed indices + value dictionary (k_spmv_stream_d); compressed indices on the fp64 values
+    # with the line-aligned copies of the two entry streams (k_spmv_stream_c, plan_spmv_align) and with the packed arrays
+    for comp, vdict, align in (("0", "1", "1"), ("1", "1", "1"), ("1", "0", "1"), ("1", "0", "0")):
         monkeypatch.setenv("CUDAMAT_SPMV_COMPRESS", comp)
+        monkeypatch.setenv("CUDAMAT_VALUE_DICT", vdict)
+        monkeypatch.setenv("CUDAMAT_SPMV_ALIGN", align)
         monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
-        got[comp] = (_spmv_via_solver(cm, ctx, A, x), _spmv_via_solver(cm, ctx, A, x, d=d))
+        got[comp + vdict + align] = (_spmv_via_solver(cm, ctx, A, x), _spmv_via_solver(cm, ctx, A, x, d=d))
+    monkeypatch.delenv("CUDAMAT_VALUE_DICT")
+    monkeypatch.delenv("CUDAMAT_SPMV_ALIGN")
     for comp in got:
         np.testing.assert_array_equal(got[comp][0], want)
         np.testing.assert_array_equal(got[comp][1], want + d * x)
