@@ -128,13 +128,15 @@ int launch_init_finish(hipStream_t s, LoopState *st, ScalarSrc init, double tol,
 int launch_update_p(hipStream_t s, LoopArgs la, ScalarSrc full, int64_t n, const double *r,
                     double *p, const double *v);
 // alpha = rho / (rw.v); r -= alpha v; x += alpha pw; parts[2b] = sum r^2
+// x == NULL: the update of x is left to launch_full(..., pw) of the same iteration
 int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, const double *v,
                 double *x, const double *pw, double *parts, int *nparts);
 // omega = (t.r)/(t.t); x += omega s; r -= omega t; parts = (rw.r, r.r); it++
 // half.ptr != NULL: evaluate the half-step stopping test from `half` first (fused small-system loop)
+// pw != NULL: x += alpha pw (the half step's update, with the alpha k_half stored) before x += omega s
 int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, const double *sv,
                 double *r, const double *t, const double *rw, double *parts, int *nparts,
-                ScalarSrc half = ScalarSrc{nullptr, 0, 1});
+                ScalarSrc half = ScalarSrc{nullptr, 0, 1}, const double *pw = nullptr);
 // pipelined BiCGStab (kernels.hip, "pipelined BiCGStab"): partials of k_pipe_a have stride 3, of k_pipe_b stride 5
 int launch_pipe_seed(hipStream_t s, ScalarSrc init, ScalarSrc rww, double *out5);
 // the hatted (M^-1-applied) vectors of the preconditioned form; all NULL without a preconditioner

@@ -1330,23 +1330,41 @@ __global__ __launch_bounds__(kBlock) void k_half(LoopArgs la, ScalarSrc rv, int6
     const double nalpha = -alpha;
     if (leader()) st->alpha = alpha;
     double acc[1] = {0.0};
-    CM_VEC_LOOP(n,
-        {
-            const double2 vv = ((const double2 *)v)[i];
-            const double2 pp = ((const double2 *)pw)[i];
-            double2 rr = ((double2 *)r)[i];
-            double2 xx = ((double2 *)x)[i];
-            rr.x = fma(nalpha, vv.x, rr.x); rr.y = fma(nalpha, vv.y, rr.y);   // :109
-            xx.x = fma(alpha, pp.x, xx.x);  xx.y = fma(alpha, pp.y, xx.y);    // :110
-            ((double2 *)r)[i] = rr; ((double2 *)x)[i] = xx;
-            acc[0] += rr.x * rr.x; acc[0] += rr.y * rr.y;                     // :111
-        },
-        {
-            const double rr = fma(nalpha, v[i], r[i]);
-            r[i] = rr;
-            x[i] = fma(alpha, pw[i], x[i]);
-            acc[0] += rr * rr;
-        })
+    if (x) {
+        CM_VEC_LOOP(n,
+            {
+                const double2 vv = ((const double2 *)v)[i];
+                const double2 pp = ((const double2 *)pw)[i];
+                double2 rr = ((double2 *)r)[i];
+                double2 xx = ((double2 *)x)[i];
+                rr.x = fma(nalpha, vv.x, rr.x); rr.y = fma(nalpha, vv.y, rr.y);   // :109
+                xx.x = fma(alpha, pp.x, xx.x);  xx.y = fma(alpha, pp.y, xx.y);    // :110
+                ((double2 *)r)[i] = rr; ((double2 *)x)[i] = xx;
+                acc[0] += rr.x * rr.x; acc[0] += rr.y * rr.y;                     // :111
+            },
+            {
+                const double rr = fma(nalpha, v[i], r[i]);
+                r[i] = rr;
+                x[i] = fma(alpha, pw[i], x[i]);
+                acc[0] += rr * rr;
+            })
+    } else {
+        // x == NULL: line :110 is carried out by k_full of this iteration (same operation on the same operands; an exit at
+        // the half step applies it on the way out, solver.hip) -- x is then read and written once per iteration, not twice
+        CM_VEC_LOOP(n,
+            {
+                const double2 vv = ((const double2 *)v)[i];
+                double2 rr = ((double2 *)r)[i];
+                rr.x = fma(nalpha, vv.x, rr.x); rr.y = fma(nalpha, vv.y, rr.y);   // :109
+                ((double2 *)r)[i] = rr;
+                acc[0] += rr.x * rr.x; acc[0] += rr.y * rr.y;                     // :111
+            },
+            {
+                const double rr = fma(nalpha, v[i], r[i]);
+                r[i] = rr;
+                acc[0] += rr * rr;
+            })
+    }
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) parts[blockIdx.x] = acc[0];
 }
@@ -1356,7 +1374,7 @@ int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, 
 {
     const int g = vec_grid(n);
     *nparts = g;
-    if (aligned16(r) && aligned16(v) && aligned16(x) && aligned16(pw))
+    if (aligned16(r) && aligned16(v) && (!x || (aligned16(x) && aligned16(pw))))
         hipLaunchKernelGGL(k_half<1>, dim3(g), dim3(kBlock), 0, s, la, rv, n, r, v, x, pw, parts);
     else
         hipLaunchKernelGGL(k_half<0>, dim3(g), dim3(kBlock), 0, s, la, rv, n, r, v, x, pw, parts);
@@ -1369,7 +1387,7 @@ int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, 
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_full(LoopArgs la, ScalarSrc tt, int64_t n, double *x,
                                                  const double *sv, double *r, const double *t,
-                                                 const double *rw, double *parts, ScalarSrc half)
+                                                 const double *rw, double *parts, ScalarSrc half, const double *pw)
 {
     __shared__ double lds[8];
     LoopState *st = la.st;
@@ -1389,27 +1407,55 @@ __global__ __launch_bounds__(kBlock) void k_full(LoopArgs la, ScalarSrc tt, int6
     const double omega = sc[0] / sc[1];                    // :137
     const double nomega = -omega;
     double acc[2] = {0.0, 0.0};
-    CM_VEC_LOOP(n,
-        {
-            const double2 ss = ((const double2 *)sv)[i];
-            const double2 ttv = ((const double2 *)t)[i];
-            const double2 ww = ((const double2 *)rw)[i];
-            double2 rr = ((double2 *)r)[i];
-            double2 xx = ((double2 *)x)[i];
-            xx.x = fma(omega, ss.x, xx.x);   xx.y = fma(omega, ss.y, xx.y);   // :139
-            rr.x = fma(nomega, ttv.x, rr.x); rr.y = fma(nomega, ttv.y, rr.y); // :140
-            ((double2 *)x)[i] = xx; ((double2 *)r)[i] = rr;
-            acc[0] += ww.x * rr.x; acc[0] += ww.y * rr.y;                     // :81 of i+1
-            acc[1] += rr.x * rr.x; acc[1] += rr.y * rr.y;                     // :142
-        },
-        {
-            const double ss = sv[i];
-            x[i] = fma(omega, ss, x[i]);
-            const double rr = fma(nomega, t[i], r[i]);
-            r[i] = rr;
-            acc[0] += rw[i] * rr;
-            acc[1] += rr * rr;
-        })
+    if (!pw) {
+        CM_VEC_LOOP(n,
+            {
+                const double2 ss = ((const double2 *)sv)[i];
+                const double2 ttv = ((const double2 *)t)[i];
+                const double2 ww = ((const double2 *)rw)[i];
+                double2 rr = ((double2 *)r)[i];
+                double2 xx = ((double2 *)x)[i];
+                xx.x = fma(omega, ss.x, xx.x);   xx.y = fma(omega, ss.y, xx.y);   // :139
+                rr.x = fma(nomega, ttv.x, rr.x); rr.y = fma(nomega, ttv.y, rr.y); // :140
+                ((double2 *)x)[i] = xx; ((double2 *)r)[i] = rr;
+                acc[0] += ww.x * rr.x; acc[0] += ww.y * rr.y;                     // :81 of i+1
+                acc[1] += rr.x * rr.x; acc[1] += rr.y * rr.y;                     // :142
+            },
+            {
+                const double ss = sv[i];
+                x[i] = fma(omega, ss, x[i]);
+                const double rr = fma(nomega, t[i], r[i]);
+                r[i] = rr;
+                acc[0] += rw[i] * rr;
+                acc[1] += rr * rr;
+            })
+    } else {
+        // the half step's x += alpha pw (:110), left out by k_half, first -- then :139: two roundings in the reference's order
+        const double alpha = st->alpha;
+        CM_VEC_LOOP(n,
+            {
+                const double2 ss = ((const double2 *)sv)[i];
+                const double2 ttv = ((const double2 *)t)[i];
+                const double2 ww = ((const double2 *)rw)[i];
+                const double2 pp = ((const double2 *)pw)[i];
+                double2 rr = ((double2 *)r)[i];
+                double2 xx = ((double2 *)x)[i];
+                xx.x = fma(alpha, pp.x, xx.x);   xx.y = fma(alpha, pp.y, xx.y);   // :110
+                xx.x = fma(omega, ss.x, xx.x);   xx.y = fma(omega, ss.y, xx.y);   // :139
+                rr.x = fma(nomega, ttv.x, rr.x); rr.y = fma(nomega, ttv.y, rr.y); // :140
+                ((double2 *)x)[i] = xx; ((double2 *)r)[i] = rr;
+                acc[0] += ww.x * rr.x; acc[0] += ww.y * rr.y;                     // :81 of i+1
+                acc[1] += rr.x * rr.x; acc[1] += rr.y * rr.y;                     // :142
+            },
+            {
+                const double ss = sv[i];
+                x[i] = fma(omega, ss, fma(alpha, pw[i], x[i]));
+                const double rr = fma(nomega, t[i], r[i]);
+                r[i] = rr;
+                acc[0] += rw[i] * rr;
+                acc[1] += rr * rr;
+            })
+    }
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
         parts[2 * blockIdx.x] = acc[0];
@@ -1423,14 +1469,14 @@ __global__ __launch_bounds__(kBlock) void k_full(LoopArgs la, ScalarSrc tt, int6
 }
 
 int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, const double *sv,
-                double *r, const double *t, const double *rw, double *parts, int *nparts, ScalarSrc half)
+                double *r, const double *t, const double *rw, double *parts, int *nparts, ScalarSrc half, const double *pw)
 {
     const int g = vec_grid(n);
     *nparts = g;
-    if (aligned16(x) && aligned16(sv) && aligned16(r) && aligned16(t) && aligned16(rw))
-        hipLaunchKernelGGL(k_full<1>, dim3(g), dim3(kBlock), 0, s, la, tt, n, x, sv, r, t, rw, parts, half);
+    if (aligned16(x) && aligned16(sv) && aligned16(r) && aligned16(t) && aligned16(rw) && (!pw || aligned16(pw)))
+        hipLaunchKernelGGL(k_full<1>, dim3(g), dim3(kBlock), 0, s, la, tt, n, x, sv, r, t, rw, parts, half, pw);
     else
-        hipLaunchKernelGGL(k_full<0>, dim3(g), dim3(kBlock), 0, s, la, tt, n, x, sv, r, t, rw, parts, half);
+        hipLaunchKernelGGL(k_full<0>, dim3(g), dim3(kBlock), 0, s, la, tt, n, x, sv, r, t, rw, parts, half, pw);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }

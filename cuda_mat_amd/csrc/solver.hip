@@ -958,6 +958,10 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     CM_HIP(hipMemcpyAsync(s->pw, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
     CM_TRY(spmv_local(s, s->pw, s->r, 0, nullptr, nullptr, la_none, CHECK_NONE, nosrc));
     int np_full = 0, np_half = 0;
+    // reference loop in its five-launch form: the half step's x += alpha pw (pbicgstab.cu:110) is carried out by k_full of the
+    // same iteration (CUDAMAT_DEFER_X=0: by k_half, as the reference orders it) -- same operations on the same operands
+    const bool defer_x = [] { const char *e = getenv("CUDAMAT_DEFER_X"); return !(e && e[0] == '0'); }();
+    const double *pw_last = nullptr;
     CM_TRY(launch_init(st, n, b, s->r, s->rw, s->p, s->parts_full, &np_full));   // :69-74
     ScalarSrc full_src{s->parts_full, np_full, 2};
     if (sharded) {
@@ -1248,7 +1252,10 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             rv_src = ScalarSrc{s->red + 0, 0, 1};
         }
         // alpha, r -= alpha v, x += alpha pw, ||r||                 :107-111
-        CM_TRY(launch_half(st, la, rv_src, n, s->r, s->v, x, pw, s->parts_half, &np_half));
+        // (x += alpha pw rides in k_full -- x is then streamed once per iteration, not twice; an exit at the half step
+        // applies it after the loop)
+        CM_TRY(launch_half(st, la, rv_src, n, s->r, s->v, defer_x ? nullptr : x, pw, s->parts_half, &np_half));
+        pw_last = pw;
         const ScalarSrc half_src{s->parts_half, np_half, 1};
         const double *sv = s->r;
         ScalarSrc tt_src{s->parts_tt, spmv_parts(s), 2};
@@ -1288,7 +1295,8 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             tt_src = ScalarSrc{s->red + 2, 0, 1};
         }
         // omega, x += omega s, r -= omega t, (rw.r, ||r||), i++     :137-151
-        CM_TRY(launch_full(st, la, tt_src, n, x, sv, s->r, s->t, s->rw, s->parts_full, &np_full));
+        CM_TRY(launch_full(st, la, tt_src, n, x, sv, s->r, s->t, s->rw, s->parts_full, &np_full, ScalarSrc{nullptr, 0, 1},
+                           defer_x ? pw : nullptr));
         full_src = ScalarSrc{s->parts_full, np_full, 2};
         if (sharded) {
             CM_TRY(launch_reduce_parts(st, full_src, 2, s->red + 4, 0));
@@ -1322,6 +1330,10 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             *precond_gave_up = true;
             return CUDAMAT_OK;
         }
+    }
+    if (defer_x && pw_last && s->st_ring[0].state == 1) {      // left through the half step: pbicgstab.cu:110 is still due
+        CM_TRY(launch_axpy(st, n, s->st_ring[0].alpha, pw_last, x));
+        CM_HIP(hipStreamSynchronize(st));
     }
     if (perm) {                              // the iterate leaves U's space
         CM_TRY(perm_from_space(s, true, x, x_user));

@@ -1180,6 +1180,35 @@ def test_pipelined_bicgstab_vs_oracle(cm, ctx, oracle, golden_dir, name, tol):
     assert np.linalg.norm(x - x2) / np.linalg.norm(x2) <= 1e-5
 
 
+def test_half_step_update_of_x_rides_in_the_full_step_kernel(cm, ctx, oracle, golden_dir, monkeypatch):
+    """the five-launch reference loop leaves pbicgstab.cu:110 (x += alpha p) to k_full of the same iteration, and to one
+    axpy after the loop when the solve leaves through the half-step test; CUDAMAT_DEFER_X=0 does it in k_half as the
+    reference orders it.  Same operations on the same operands: solutions and histories must be bit-identical, through
+    both exits, with and without ILU(0), and equal to the oracle's within its tolerance."""
+    monkeypatch.setenv("CUDAMAT_FUSED", "0")                # the five-launch form also on small systems
+    monkeypatch.setenv("CUDAMAT_RESIDENT", "0")
+    A = oracle.rand_rows(5000, 12, 7)
+    xs = oracle.xstar(A.n, 3)
+    b = oracle.spmv(A, xs)
+    seen_half = seen_full = False
+    for precond in (cm.PRECOND_NONE, cm.PRECOND_ILU0):
+        for tol in (1e-3, 1e-5, 1e-7, 1e-8, 1e-11):
+            got = {}
+            for defer in ("1", "0"):
+                monkeypatch.setenv("CUDAMAT_DEFER_X", defer)
+                got[defer] = _solve_dev(cm, ctx, A, b, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=100, tol=tol)
+            (x1, st1, h1), (x0, st0, h0) = got["1"], got["0"]
+            assert st1.converged and (st1.iters, st1.half_exit) == (st0.iters, st0.half_exit)
+            np.testing.assert_array_equal(x1, x0)
+            np.testing.assert_array_equal(h1, h0)
+            xo, so = oracle.pbicgstab(A, b, vm=oracle.ilu0(A) if precond else None, maxit=100, tol=tol)
+            assert (st1.iters, st1.half_exit) == (so.iters, so.half_exit), (tol, st1.iters, so.iters)
+            np.testing.assert_allclose(x1, xo, rtol=1e-9, atol=1e-12)
+            seen_half |= bool(st1.half_exit)
+            seen_full |= not st1.half_exit
+    assert seen_half and seen_full, "the tolerances above were chosen to leave through both tests"
+
+
 def test_pipelined_bicgstab_exits_and_limits(cm, ctx, oracle):
     """half-step exit returns x + alpha p (kept in a side buffer), maxit stops without convergence, an exact initial
     guess converges in 0 iterations, NO_EXIT runs the full window"""
