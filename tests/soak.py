@@ -14,7 +14,7 @@ forms = {}
 dicts = 0
 
 
-def oracle_spread(A, b, loop, precond, first):
+def oracle_spread(A, b, loop, precond, first, nperm=8):
     """iteration counts of the oracle's loop on P A P^T, P b for 8 random permutations P: the same system in exact
     arithmetic, other summation orders in the dots and row sums.  (With ILU(0), whose factors depend on the ordering, b
     is scaled by 1 + k ulp instead: the same solution path up to rounding-sized input changes.)"""
@@ -22,9 +22,9 @@ def oracle_spread(A, b, loop, precond, first):
     S = sp.csr_matrix((A.val, A.colidx - base, A.rowptr - base), shape=(A.n, A.n))
     prng = np.random.default_rng(12345)
     counts = [first]
-    for k in range(8):
+    for k in range(nperm):
         if precond:
-            bk = b * (1.0 + (k - 4 + (k >= 4)) * 1.1e-16)
+            bk = b * (1.0 + (k - nperm // 2 + (k >= nperm // 2)) * 1.1e-16)
             if loop == 2: _, sp_ = O.pipelined_bicgstab(A, bk, vm=O.ilu0(A), maxit=500, tol=1e-9)
             else: _, sp_ = O.pbicgstab(A, bk, vm=O.ilu0(A), maxit=500, tol=1e-9)
             if sp_.converged: counts.append(sp_.iters)
@@ -114,7 +114,12 @@ for case in range(ncase):
                 lim = so.iters if long_run else max(2, 0.1 * so.iters)
                 if abs(st.iters - so.iters) > lim:
                     lo, hi = oracle_spread(A, b, loop, precond, so.iters)
-                    if not (lo - max(2, 0.1 * lo) <= st.iters <= hi + max(2, 0.1 * hi)):
+                    inside = lambda lo, hi: lo - max(2, 0.1 * lo) <= st.iters <= hi + max(2, 0.1 * hi)
+                    if not inside(lo, hi):
+                        # 8 orders are a small sample (seed 51 case 29, pipelined loop: 79..89 over 8 permutations, 76..91 over
+                        # 24; the GPU needs 69, the reference loop's restatement 75): look at 24 before calling it a finding
+                        lo, hi = oracle_spread(A, b, loop, precond, so.iters, nperm=24)
+                    if not inside(lo, hi):
                         msgs.append("loop%d pc%d iters %d vs %d (oracle over other summation orders: %d..%d)" % (loop, precond, st.iters, so.iters, lo, hi))
             if st.converged:
                 if so.converged and np.linalg.norm(xg - xo) > 1e-5 * np.linalg.norm(xo): msgs.append("loop%d pc%d x differs" % (loop, precond))
