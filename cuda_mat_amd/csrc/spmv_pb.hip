@@ -31,7 +31,13 @@ typedef unsigned short u16;
 constexpr int kPbBuildWaves = 4;
 constexpr int kP1Threads = 1024;
 constexpr int kP1Unroll = 8;          // steps of phase 1 whose loads are in flight together (k_pb_phase1_dict)
-constexpr int kTileMax = 13312;        // doubles per LDS tile (104 KB)
+constexpr int kTileMax = 13312;        // doubles per y tile of a row block (104 KB)
+// doubles per x tile of a column block (phase 1): CUDAMAT_PB_XTILE overrides (experiment)
+static int x_tile_max()
+{
+    static const int v = [] { const char *e = getenv("CUDAMAT_PB_XTILE"); const int t = e ? atoi(e) : 0; return t >= 1024 && t <= 19968 ? t : kTileMax; }();
+    return v;
+}
 
 static double now_s()
 {
@@ -243,7 +249,7 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
         p.per = cols->per;
         p.chunks = cols->chunks < 1 ? 1 : cols->chunks > kPbMaxChunks ? kPbMaxChunks : cols->chunks;
         p.chunk_len = (p.per + p.chunks - 1) / p.chunks;
-        p.bpc = (int)((p.chunk_len + kTileMax - 1) / kTileMax);
+        p.bpc = (int)((p.chunk_len + x_tile_max() - 1) / x_tile_max());
         p.CB = (int)((p.chunk_len + p.bpc - 1) / p.bpc);
         const int64_t slices = (n_cols + p.per - 1) / p.per;
         p.NCB = (int)(slices * p.chunks * p.bpc);
@@ -252,7 +258,7 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
         p.per = n_cols;
         p.chunks = 1;
         p.chunk_len = n_cols;
-        p.NCB = round_blocks(n_cols, kTileMax);
+        p.NCB = round_blocks(n_cols, x_tile_max());
         p.CB = (int)((n_cols + p.NCB - 1) / p.NCB);
         p.NCB = (int)((n_cols + p.CB - 1) / p.CB);
         p.bpc = p.NCB;
