@@ -118,7 +118,7 @@ for case in range(ncase):
                     if not inside(lo, hi):
                         # 8 orders are a small sample: look at 24 before calling it a finding.  (Seed 51 case 29, pipelined
                         # loop, stays one: 79..89 over these 24 permutations -- 76..91 over another 24 -- and 69 on the GPU;
-                        # histories equal to 1e-12 up to iteration 3, unrelated from 11 on: scripts/soak_case.py 51 29 2)
+                        # histories equal to 1e-12 up to iteration 3, unrelated from 11 on: tests/soak_case.py 51 29 2)
                         lo, hi = oracle_spread(A, b, loop, precond, so.iters, nperm=24)
                     if not inside(lo, hi):
                         msgs.append("loop%d pc%d iters %d vs %d (oracle over other summation orders: %d..%d)" % (loop, precond, st.iters, so.iters, lo, hi))

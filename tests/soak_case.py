@@ -1,10 +1,10 @@
 """GPU box: replay ONE system of tests/soak.py (same draws) and put the residual histories of the GPU loop and of the
-oracle's restatement side by side: where do they part, how do they end?   python scripts/soak_case.py SEED CASE LOOP [PRECOND]"""
+oracle's restatement side by side: where do they part, how do they end?   python tests/soak_case.py SEED CASE LOOP [PRECOND]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp
 import cuda_mat_amd as cm
-from oracle import oracle as O      # (a script of the test infrastructure: it lives beside tests/soak.py's generator)
+from oracle import oracle as O
 seed, target, loop = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 precond = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 rng = np.random.default_rng(seed)
