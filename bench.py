@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_START = time.time()
 # thread placement of the CPU baseline, fixed before any OpenMP runtime is loaded; the CPUs this process
 # may use are counted first (libgomp binds the initial thread to ONE place once OMP_PROC_BIND is set, after which
 # sched_getaffinity reports a single CPU)
@@ -71,7 +72,7 @@ def parse():
     ap.add_argument("--drop-in", default="auto", choices=["auto", "off"],
                     help="auto: also time the host-pointer entry point (cudamat_solve = bicgstab(), pbicgstab.h:113) end to end, "
                          "twice (one GPU only; the second call reuses the first one's plan)")
-    ap.add_argument("--cpu-iters-full", type=int, default=3, help="iterations of the CPU baseline on the full matrix")
+    ap.add_argument("--cpu-iters-full", type=int, default=2, help="iterations of the CPU baseline on the full matrix, per OpenMP team size")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     return ap.parse_args()
 
@@ -104,10 +105,27 @@ def _free_port():
     return port
 
 
-def _form_limit(first):
-    """seconds a set of workers may take for one exchange form (import, generation, tuning, gate, timed region)"""
+FORM_LIMITS = (180.0, 120.0, 120.0)   # s per exchange form, first to last (a healthy two-rank set takes 4-9 s after the first import)
+BUDGET_S = 500.0                      # all forms together, from the start of bench.py: the driver ends a bench run after 600 s (which
+                                      # include torch.distributed.run's own start-up), and a line must be out before that
+FORM_RESERVE_S = 45.0                 # what every LATER form is left with at least when an earlier one runs into its limit
+
+
+def _form_limit(i, n_forms=None, left=None):
+    """seconds a set of workers may take for exchange form i (import, generation, tuning, gate, timed region): the form's
+    own limit (CUDAMAT_BENCH_FORM_TIMEOUT pins one for all), shrunk so that the forms after it keep FORM_RESERVE_S each
+    inside what is left of the overall budget (`left` seconds; None = no budget)"""
     v = os.environ.get("CUDAMAT_BENCH_FORM_TIMEOUT")
-    return float(v) if v else (240.0 if first else 150.0)
+    limit = float(v) if v else FORM_LIMITS[min(i, len(FORM_LIMITS) - 1)]
+    if left is not None:
+        reserve = float(os.environ.get("CUDAMAT_BENCH_RESERVE") or FORM_RESERVE_S)
+        limit = min(limit, left - reserve * max((n_forms or 1) - 1 - i, 0))
+    return limit
+
+
+def _budget():
+    v = os.environ.get("CUDAMAT_BENCH_BUDGET")
+    return float(v) if v else BUDGET_S
 
 
 def _kill_group(proc):
@@ -155,15 +173,25 @@ def supervisor(argv):
     if os.environ.get("CUDAMAT_BENCH_FORMS"):
         forms = os.environ["CUDAMAT_BENCH_FORMS"].split(",")
     log, line, rc_final = [], None, 1
+    # the overall budget runs from the launcher's start (CUDAMAT_BENCH_DEADLINE, epoch seconds) or, under a bare
+    # torch.distributed.run, from rank 0's start of this function; every rank uses rank 0's deadline
+    box = [float(os.environ.get("CUDAMAT_BENCH_DEADLINE") or (T_START + _budget())) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    deadline = box[0]
     for i, form in enumerate(forms):
-        box = [_free_port() if rank == 0 else None]
+        box = [(_free_port(), _form_limit(i, len(forms), deadline - time.time())) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
+        port, limit = box[0]
+        if limit < 5.0:
+            log.append({"form": form, "ok": False, "seconds": 0.0, "limit_s": round(limit, 1), "ranks": ["not started: budget spent"] * world})
+            if rank == 0:
+                print("bench.py supervisor: form %s not started, %.0f s of the budget left" % (form, deadline - time.time()), file=sys.stderr, flush=True)
+            continue
         env = dict(os.environ, CUDAMAT_BENCH_WORKER="1", CUDAMAT_BENCH_FORMS=form, MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(box[0]), TORCHELASTIC_USE_AGENT_STORE="False")
+                   MASTER_PORT=str(port), TORCHELASTIC_USE_AGENT_STORE="False")
         out = tempfile.TemporaryFile(mode="w+")
         t0 = time.time()
         proc = subprocess.Popen(_worker_cmd() + argv, env=env, stdout=out, start_new_session=True, preexec_fn=_die_with_parent)
-        limit = _form_limit(i == 0)
         while True:
             rc = proc.poll()
             status = 0 if rc is None else (1 if rc == 0 else 2)
@@ -180,7 +208,7 @@ def supervisor(argv):
             _kill_group(proc)
         outcomes = [None] * world
         dist.all_gather_object(outcomes, {0: "running", 1: "ok", 2: "exit %s" % proc.returncode, 3: "time limit"}[status])
-        log.append({"form": form, "ok": ok, "seconds": round(time.time() - t0, 1), "limit_s": limit, "ranks": outcomes})
+        log.append({"form": form, "ok": ok, "seconds": round(time.time() - t0, 1), "limit_s": round(limit, 1), "ranks": outcomes})
         if rank == 0:
             print("bench.py supervisor: form %s -> %s (%s)" % (form, "ok" if ok else "FAILED", outcomes), file=sys.stderr, flush=True)
         if ok:
@@ -195,6 +223,9 @@ def supervisor(argv):
         if rc_final == 0 and line is not None:
             res = json.loads(line)
             res.setdefault("comm", {})["launcher"] = log
+            # a line timed on a later form of the ladder is NOT the headline configuration: say so at the top level
+            res["degraded_form"] = (None if len(log) == 1 else
+                                    "timed on exchange form %s after %s failed" % (log[-1]["form"], ", ".join(e["form"] for e in log[:-1])))
             print(json.dumps(res), flush=True)
         else:
             print("bench.py: every exchange form failed: %s" % json.dumps(log), file=sys.stderr, flush=True)
@@ -205,13 +236,15 @@ def supervisor(argv):
 def launcher(args, argv):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start the ranks as a child job.  Makes no GPU call."""
     import subprocess
-    forms = os.environ.get("CUDAMAT_BENCH_FORMS")
-    n_forms = len(forms.split(",")) if forms else len(DEFAULT_FORMS)
-    total = _form_limit(True) + (n_forms - 1) * _form_limit(False) + 120.0
+    total = _budget() + 40.0           # the supervisors keep to the budget themselves; this is the backstop
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
+    # this pool's host driver only supports dmabuf IPC: without this switch RCCL (and any sharing of device memory
+    # between processes) fails with `hipIpcGetMemHandle: invalid argument`.  The image exports it already; it is set
+    # here so that a job started from a scrubbed environment still has it (DESIGN.md section 7, "launch environment")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("CUDAMAT_BENCH_DEADLINE", "%.1f" % (T_START + _budget()))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
     try:
         out, _ = proc.communicate(timeout=total)
@@ -228,18 +261,29 @@ def launcher(args, argv):
     return 0
 
 
+def cpu_teams():
+    """OpenMP team sizes the CPU baseline tries: around the CPUs' worth of time this process is GRANTED (cgroup quota; a
+    one-GPU box of the pool shows 256 CPUs and is throttled to 16) -- half, once, twice and four times that -- plus 8 /
+    16 / 32 / 64, never more than the CPUs the process may run on"""
+    q = cpu_quota()
+    q = int(round(q)) if q else HOST_CPUS
+    cand = {q // 2, q, 2 * q, 4 * q, 8, 16, 32, 64}
+    teams = sorted(c for c in cand if 1 <= c <= HOST_CPUS) or [HOST_CPUS]
+    return teams[-6:]
+
+
 def cpu_baseline(args):
     """The reference's CPU path (bicstab_omp BiCG, bicstab.cpp:93-196) as restated by the oracle, faithful threading
     (SpMV + dot OpenMP, the five vector loops serial as upstream), timed on this host ON THE WHOLE WORKLOAD MATRIX
     (built in memory, 6 GB at 1e7 x 50; first touch by the generator's static row partition, which is the
     SpMV's): `value` = iterations / seconds of the reference's iteration loop (bicstab.cpp:146-182; BiCG, like BiCGSTAB,
-    costs 2 SpMV per iteration) with the thread count that runs the SpMV fastest on this host -- every CPU the process
-    may use (SURVEY 8d) unless a smaller team measures faster (SMT siblings, a CPU quota below the visible CPU count);
-    the sweep is reported.  Its one-off transposition (Transpose2, a serial loop upstream: ~70 s at this size) is done
-    with every thread and reported beside the rate, not in it.  `one_gpu_share_16_threads` keeps round 2's figure
-    (16 threads = the share of the host a one-GPU box is meant to use)."""
+    costs 2 SpMV per iteration).  The OpenMP team is chosen ON THAT LOOP: the program runs `--cpu-iters-full` iterations
+    once per team size of cpu_teams() after one transposition, and `value` is the best of them (ties: fewer threads);
+    the whole table is reported (`loop_iters_per_s_by_threads`), so `value` >= every other team's figure by
+    construction.  The one-off transposition (Transpose2, a serial loop upstream: ~70 s at this size) is done with
+    every thread and reported beside the rate, not in it."""
     from oracle import oracle as O
-    O.set_num_threads(HOST_CPUS)
+    O.set_num_threads(min(HOST_CPUS, 64))
     full_rows = args.rows
 
     def build(n):
@@ -254,58 +298,39 @@ def cpu_baseline(args):
     n = A.n
     xs = O.xstar(n, args.seed + 1)
     b = O.spmv(A, xs)
-    # thread sweep on the operation that carries the loop (MatrixVectorMult, bicstab.cpp:69-80): best of 3 launches each
-    sweep = {}
-    for t in sorted({c for c in (8, 16, 32, 64, 128, HOST_CPUS // 2, HOST_CPUS) if 1 <= c <= HOST_CPUS}):
-        O.set_num_threads(t)
-        best = None
-        for _ in range(3):
-            t1 = time.perf_counter()
-            O.spmv(A, xs)
-            d = time.perf_counter() - t1
-            best = d if best is None or d < best else best
-        sweep[t] = best
-    t_best = min(sweep, key=lambda k: (sweep[k], k))
     iters_full = max(1, args.cpu_iters_full)
-
-    def faithful(threads, **kw):
-        O.set_num_threads(threads)
-        _, it, t_tr, t_loop = O.bicg_timed(A, b, maxit=iters_full, eps=0.0, fast_transpose=True, **kw)
-        return max(it, 1), t_tr, t_loop
-
-    it, t_tr, t_loop = faithful(t_best)
+    teams = cpu_teams()
+    _, its, t_tr, t_loops = O.bicg_teams(A, b, teams, maxit=iters_full, eps=0.0)
+    rate = {t: max(i, 1) / tl for t, i, tl in zip(teams, its, t_loops)}
+    t_best = max(teams, key=lambda t: (rate[t], -t))
     # (ii) of SURVEY 8d: the same loop with its five vector loops parallel too (what a tuned host port would do)
-    it_p, _, t_loop_p = faithful(t_best, parallel_vec=True)
+    _, its_p, _, t_loops_p = O.bicg_teams(A, b, [t_best], maxit=iters_full, eps=0.0, parallel_vec=True)
     # like for like: the oracle's restatement of the GPU loop (BiCGSTAB, pbicgstab.cu:581-754) on the
     # same matrix; tol = 0 never triggers, so exactly iters_full iterations run
+    O.set_num_threads(t_best)
     t1 = time.perf_counter()
     _, _, st2 = O.pbicgstab2(A, b, maxit=iters_full, tol=0.0)
     dt2 = time.perf_counter() - t1
-    share = None
-    if t_best != 16 and HOST_CPUS >= 16:
-        it16, _, t_loop16 = faithful(16)
-        share = {"value": it16 / t_loop16, "unit": "iter/s", "cores": 16}
     del A, b, xs
-    out = {
-        "value": it / t_loop, "unit": "iter/s", "cores": t_best, "kind": "port",
+    i_best = teams.index(t_best)
+    return {
+        "value": rate[t_best], "unit": "iter/s", "cores": t_best, "kind": "port",
         "sample": "oracle BiCG restatement of bicstab_omp (2 SpMV/iter; SpMV+dot OpenMP, vector loops serial as in the "
                   "reference): %d iterations of its loop (bicstab.cpp:146-182) on the FULL %d-row x %d nnz/row matrix, "
-                  "built in host memory by the same generator; %d threads = the fastest team of the sweep"
-                  % (it, n, args.per_row if args.workload == "rand50" else 5, t_best),
-        "loop_seconds": t_loop, "transpose_seconds": t_tr, "build_seconds": t_build,
+                  "built in host memory by the same generator; %d threads = the team that runs THIS LOOP fastest (sweep below)"
+                  % (its[i_best], n, args.per_row if args.workload == "rand50" else 5, t_best),
+        "loop_seconds": t_loops[i_best], "transpose_seconds": t_tr, "build_seconds": t_build,
         "threads": {"nproc": os.cpu_count(), "sched_affinity_at_start": HOST_CPUS, "cgroup_cpu_quota_cores": cpu_quota(),
                     "omp_threads_used": t_best, "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
                     "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
-                    "spmv_seconds_by_threads": {str(k): v for k, v in sweep.items()}},
-        "parallel_vector_loops": {"value": it_p / t_loop_p, "unit": "iter/s",
-                                  "sample": "the same BiCG loop with its five vector loops under OpenMP as well, %d iterations" % it_p},
+                    "loop_iters_per_s_by_threads": {str(t): rate[t] for t in teams}},
+        "parallel_vector_loops": {"value": max(its_p[0], 1) / t_loops_p[0], "unit": "iter/s",
+                                  "sample": "the same BiCG loop with its five vector loops under OpenMP as well, %d iterations, %d threads"
+                                            % (its_p[0], t_best)},
         "bicgstab_port": {"value": max(st2.iters, 1) / dt2, "unit": "iter/s",
-                          "sample": "oracle BiCGSTAB restatement (pbicgstab.cu:581-754), %d iterations on the same full matrix"
-                                    % max(st2.iters, 1)},
+                          "sample": "oracle BiCGSTAB restatement (pbicgstab.cu:581-754), %d iterations on the same full matrix, %d threads"
+                                    % (max(st2.iters, 1), t_best)},
     }
-    if share is not None:
-        out["one_gpu_share_16_threads"] = share
-    return out
 
 
 def hbm_ceiling(ctx):
@@ -777,8 +802,8 @@ def run_bench(args):
                                  and "hbm_bytes_per_launch_corrected" in v), None)
                     far = [v for name, v in pm.items() if name.startswith("cm::k_pb_phase") and "far part" in name and isinstance(v, dict)
                            and "hbm_bytes_per_launch_corrected" in v]
-                    if near is not None and far:
-                        groups = [max(2, min(16, nl // 17)) for nl in (st.n_levels_l, st.n_levels_u)]      # ilu.hip plan_groups
+                    groups = [st.trsv_groups_l, st.trsv_groups_u]       # what the library's plan holds (cudamat_stats)
+                    if near is not None and far and min(groups) >= 2 and st.trsv_form == 1:
                         n_near = sum(groups)
                         n_far = sum(g - 1 for g in groups)            # blocked SpMVs (phase 1 + phase 2 each) per application
                         p1 = [v for name, v in pm.items() if name.startswith("cm::k_pb_phase1") and "far part" in name and isinstance(v, dict)]

@@ -35,7 +35,8 @@ class Stats(C.Structure):
                 ("ms_gather_exposed", C.c_double), ("ms_allreduce", C.c_double), ("overlapped", C.c_int),
                 ("loop_form", C.c_int), ("gather_fraction", C.c_double), ("ms_spmv_alone", C.c_double),
                 ("loop_fallbacks", C.c_int), ("restarts", C.c_int), ("t_upload", C.c_double), ("t_setup", C.c_double),
-                ("t_tune", C.c_double), ("spmv_mode", C.c_int), ("plan_reused", C.c_int)]
+                ("t_tune", C.c_double), ("spmv_mode", C.c_int), ("plan_reused", C.c_int),
+                ("trsv_groups_l", C.c_int), ("trsv_groups_u", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

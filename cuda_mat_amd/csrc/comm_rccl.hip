@@ -23,6 +23,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 
@@ -98,8 +99,37 @@ struct RcclComm {
     hipStream_t main = nullptr;      // the context's stream (not owned)
     hipStream_t side = nullptr;      // owned
     hipStream_t rstream = nullptr;   // owned
-    std::mutex mu;                   // abort may come from another thread than the rank's (sharded.cpp)
-    std::atomic<bool> aborted{false};
+    // Abort may come from another thread than the rank's (sharded.cpp: the thread of the rank that failed aborts
+    // EVERY rank's communicators).  ncclCommAbort frees the communicator, so an enqueue path must never hold a handle
+    // that abort is tearing down: every enqueue registers itself under `mu` (RcclUse: refused once `aborted`, handles
+    // snapshotted, `inflight` counted), and abort first closes the door, then waits until the calls in flight have
+    // returned before it touches the handles.
+    std::mutex mu;
+    std::condition_variable cv;
+    int inflight = 0;
+    bool aborted = false;            // guarded by mu
+};
+
+// one enqueue's registration with its communicator (see RcclComm::mu)
+struct RcclUse {
+    RcclComm *c;
+    bool ok;
+    ncclComm_t coll = nullptr, p2p = nullptr, red = nullptr;
+    explicit RcclUse(RcclComm *c_) : c(c_)
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        ok = !c->aborted;
+        if (ok) { c->inflight++; coll = c->coll; p2p = c->p2p; red = c->red; }
+        else set_error("the communicator was aborted");
+    }
+    ~RcclUse()
+    {
+        if (!ok) return;
+        std::lock_guard<std::mutex> lock(c->mu);
+        if (--c->inflight == 0) c->cv.notify_all();
+    }
+    RcclUse(const RcclUse &) = delete;
+    RcclUse &operator=(const RcclUse &) = delete;
 };
 
 // a group that met an error must still be closed: an open group would swallow every later call of this thread
@@ -116,24 +146,27 @@ struct RcclComm {
 static int rccl_allgather(void *user, const double *send, double *recv, int64_t count)
 {
     RcclComm *c = (RcclComm *)user;
-    if (c->aborted) { set_error("the communicator was aborted"); return CUDAMAT_ERR_COMM; }
-    CM_NCCL(g_api.AllGather(send, recv, (size_t)count, ncclDouble, c->coll, c->main));
+    RcclUse use(c);
+    if (!use.ok) return CUDAMAT_ERR_COMM;
+    CM_NCCL(g_api.AllGather(send, recv, (size_t)count, ncclDouble, use.coll, c->main));
     return 0;
 }
 
 static int rccl_allreduce(void *user, double *buf, int count)
 {
     RcclComm *c = (RcclComm *)user;
-    if (c->aborted) { set_error("the communicator was aborted"); return CUDAMAT_ERR_COMM; }
-    CM_NCCL(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->coll, c->main));
+    RcclUse use(c);
+    if (!use.ok) return CUDAMAT_ERR_COMM;
+    CM_NCCL(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, use.coll, c->main));
     return 0;
 }
 
 static int rccl_allreduce_side(void *user, double *buf, int count)
 {
     RcclComm *c = (RcclComm *)user;
-    if (c->aborted) { set_error("the communicator was aborted"); return CUDAMAT_ERR_COMM; }
-    CM_NCCL(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->red, c->rstream));
+    RcclUse use(c);
+    if (!use.ok) return CUDAMAT_ERR_COMM;
+    CM_NCCL(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, use.red, c->rstream));
     return 0;
 }
 
@@ -141,14 +174,15 @@ static int rccl_allreduce_side(void *user, double *buf, int count)
 static int rccl_gather_part(void *user, const double *send, double *recv, int64_t stride, int64_t offset, int64_t count)
 {
     RcclComm *c = (RcclComm *)user;
-    if (c->aborted) { set_error("the communicator was aborted"); return CUDAMAT_ERR_COMM; }
     if (c->world <= 1 || count <= 0) return 0;
+    RcclUse use(c);
+    if (!use.ok) return CUDAMAT_ERR_COMM;
     CM_NCCL(g_api.GroupStart());
     for (int d = 1; d < c->world; d++) {
         // peer order rotated by rank: at every position of the group the world's sends hit distinct receivers
         const int to = (c->rank + d) % c->world, from = (c->rank - d + c->world) % c->world;
-        CM_NCCL_IN_GROUP(g_api.Send(send + offset, (size_t)count, ncclDouble, to, c->p2p, c->side));
-        CM_NCCL_IN_GROUP(g_api.Recv(recv + (size_t)from * (size_t)stride + (size_t)offset, (size_t)count, ncclDouble, from, c->p2p, c->side));
+        CM_NCCL_IN_GROUP(g_api.Send(send + offset, (size_t)count, ncclDouble, to, use.p2p, c->side));
+        CM_NCCL_IN_GROUP(g_api.Recv(recv + (size_t)from * (size_t)stride + (size_t)offset, (size_t)count, ncclDouble, from, use.p2p, c->side));
     }
     CM_NCCL(g_api.GroupEnd());
     return 0;
@@ -159,16 +193,17 @@ static int rccl_gather_window(void *user, const double *send, double *recv, int6
                               const int64_t *send_cnt, const int64_t *recv_off, const int64_t *recv_cnt)
 {
     RcclComm *c = (RcclComm *)user;
-    if (c->aborted) { set_error("the communicator was aborted"); return CUDAMAT_ERR_COMM; }
     if (c->world <= 1) return 0;
+    RcclUse use(c);
+    if (!use.ok) return CUDAMAT_ERR_COMM;
     CM_NCCL(g_api.GroupStart());
     for (int d = 1; d < c->world; d++) {
         const int to = (c->rank + d) % c->world, from = (c->rank - d + c->world) % c->world;
         if (send_cnt[to] > 0)
-            CM_NCCL_IN_GROUP(g_api.Send(send + send_off[to], (size_t)send_cnt[to], ncclDouble, to, c->coll, c->main));
+            CM_NCCL_IN_GROUP(g_api.Send(send + send_off[to], (size_t)send_cnt[to], ncclDouble, to, use.coll, c->main));
         if (recv_cnt[from] > 0)
             CM_NCCL_IN_GROUP(g_api.Recv(recv + (size_t)from * (size_t)stride + (size_t)recv_off[from], (size_t)recv_cnt[from], ncclDouble,
-                                        from, c->coll, c->main));
+                                        from, use.coll, c->main));
     }
     CM_NCCL(g_api.GroupEnd());
     return 0;
@@ -267,13 +302,23 @@ extern "C" int cudamat_rccl_comm_abort(cudamat_comm *comm)
     if (!comm || !comm->user) return CUDAMAT_OK;
     CM_ARG(comm->allgather == rccl_allgather, "not a communicator made by cudamat_rccl_comm_create");
     RcclComm *c = (RcclComm *)comm->user;
-    std::lock_guard<std::mutex> lock(c->mu);
-    if (c->aborted) return CUDAMAT_OK;
-    c->aborted = true;
-    hipSetDevice(c->device);
-    ncclComm_t *all[] = {&c->coll, &c->p2p, &c->red};
-    for (ncclComm_t *q : all)
-        if (*q) { g_api.CommAbort(*q); *q = nullptr; }
+    ncclComm_t h[3];
+    int device;
+    {
+        std::unique_lock<std::mutex> lock(c->mu);
+        device = c->device;
+        if (c->aborted) return CUDAMAT_OK;
+        c->aborted = true;               // no new enqueue gets a handle from here on
+        // Enqueues return within microseconds; one that does not is blocked INSIDE RCCL waiting for a rank that will never
+        // come (connection set-up of a first send/recv), and ncclCommAbort from another thread is what RCCL offers to
+        // release it -- so the wait is bounded, and only in that case is a handle aborted while a call still holds it.
+        c->cv.wait_for(lock, std::chrono::seconds(2), [c] { return c->inflight == 0; });
+        h[0] = c->coll; h[1] = c->p2p; h[2] = c->red;
+        c->coll = c->p2p = c->red = nullptr;
+    }
+    hipSetDevice(device);
+    for (ncclComm_t q : h)
+        if (q) g_api.CommAbort(q);
     return CUDAMAT_OK;
 }
 
@@ -283,7 +328,9 @@ extern "C" int cudamat_rccl_comm_destroy(cudamat_comm *comm)
     CM_ARG(comm->allgather == rccl_allgather, "not a communicator made by cudamat_rccl_comm_create");
     RcclComm *c = (RcclComm *)comm->user;
     hipSetDevice(c->device);
-    if (c->aborted) {               // (the communicators are gone; their kernels were told to leave)
+    bool was_aborted;
+    { std::lock_guard<std::mutex> lock(c->mu); was_aborted = c->aborted; }
+    if (was_aborted) {              // (the communicators are gone; their kernels were told to leave)
         bounded_sync(c->main, 5.0);
         bounded_sync(c->side, 5.0);
         bounded_sync(c->rstream, 5.0);

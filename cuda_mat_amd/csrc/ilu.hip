@@ -673,6 +673,7 @@ int ilu0_release(cudamat_solver *s)
     if (s->x_perm) { hipFree(s->x_perm); s->x_perm = nullptr; }
     if (s->b_perm) { hipFree(s->b_perm); s->b_perm = nullptr; }
     s->perm_ready = false;
+    s->perm_failed = false;
     if (s->lu) hipFree(s->lu);
     if (s->diag_pos) hipFree(s->diag_pos);
     if (s->pm_owned) {
@@ -1686,6 +1687,15 @@ int trsv_form_code(cudamat_solver *s)
     return 0;
 }
 
+void trsv_group_counts(cudamat_solver *s, int *groups_l, int *groups_u)
+{
+    *groups_l = *groups_u = 0;
+    IluPlans *pl = plans_of(s, false);
+    if (!pl || !s->has_ilu) return;
+    if (pl->L.hybrid) *groups_l = (int)pl->L.grp_level.size() - 1;
+    if (pl->U.hybrid) *groups_u = (int)pl->U.grp_level.size() - 1;
+}
+
 void trsv_disable_syncfree(cudamat_solver *s)
 {
     if (IluPlans *pl = plans_of(s, false)) pl->L.syncfree = pl->U.syncfree = false;
@@ -1847,6 +1857,7 @@ int ilu_perm_matrix(cudamat_solver *s)
         if (q) hipFree(q);
     if (rc) {
         pb_free(&s->pb_perm);
+        valdict_free(&s->vd_perm);
         return rc;
     }
     s->perm_ready = true;

@@ -149,8 +149,8 @@ int launch_pipe_b(hipStream_t s, LoopArgs la, ScalarSrc A, int64_t n, const doub
                   const double *v, const double *rw, const double *sv, const double *z, const double *xh, double *x, double *r,
                   double *w, double *parts, int *nparts, PipeHatB hat);
 // residual replacement: r = f - ax; the five dots of k_pipe_b recomputed (stride 5 partials)
-int launch_residual(hipStream_t s, int64_t n, const double *f, const double *ax, double *r);
-int launch_pipe_dots(hipStream_t s, int64_t n, const double *rw, const double *r, const double *w, const double *sv,
+int launch_residual(hipStream_t s, const LoopArgs &la, int64_t n, const double *f, const double *ax, double *r);
+int launch_pipe_dots(hipStream_t s, const LoopArgs &la, int64_t n, const double *rw, const double *r, const double *w, const double *sv,
                      const double *z, double *parts, int *nparts);
 // standalone stopping tests (one workgroup)
 int launch_check(hipStream_t s, LoopArgs la, ScalarSrc src, int which);

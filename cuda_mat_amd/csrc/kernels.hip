@@ -1751,8 +1751,9 @@ int launch_pipe_b(hipStream_t s, LoopArgs la, ScalarSrc A, int64_t n, const doub
 // ---- residual replacement of the pipelined loop (solver.hip): r = f - ax, and the five dots k_pipe_b would have left
 // (rw.r, rw.w, rw.s, rw.z, r.r) recomputed from the replaced vectors (same layout: stride kPipeB per workgroup)
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_residual(int64_t n, const double *f, const double *ax, double *r)
+__global__ __launch_bounds__(kBlock) void k_residual(const LoopState *st, int64_t n, const double *f, const double *ax, double *r)
 {
+    if (st && st->state != 0) return;                  // frozen loop: ax is stale, r must stay the iterate's residual
     CM_VEC_LOOP(n,
         {
             const double2 ff = ((const double2 *)f)[i];
@@ -1763,21 +1764,22 @@ __global__ __launch_bounds__(kBlock) void k_residual(int64_t n, const double *f,
         { r[i] = f[i] - ax[i]; })
 }
 
-int launch_residual(hipStream_t s, int64_t n, const double *f, const double *ax, double *r)
+int launch_residual(hipStream_t s, const LoopArgs &la, int64_t n, const double *f, const double *ax, double *r)
 {
     const int g = vec_grid(n);
-    if (aligned16(f) && aligned16(ax) && aligned16(r)) hipLaunchKernelGGL(k_residual<1>, dim3(g), dim3(kBlock), 0, s, n, f, ax, r);
-    else hipLaunchKernelGGL(k_residual<0>, dim3(g), dim3(kBlock), 0, s, n, f, ax, r);
+    if (aligned16(f) && aligned16(ax) && aligned16(r)) hipLaunchKernelGGL(k_residual<1>, dim3(g), dim3(kBlock), 0, s, la.st, n, f, ax, r);
+    else hipLaunchKernelGGL(k_residual<0>, dim3(g), dim3(kBlock), 0, s, la.st, n, f, ax, r);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }
 
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_pipe_dots(int64_t n, const double *rw, const double *r, const double *w,
+__global__ __launch_bounds__(kBlock) void k_pipe_dots(const LoopState *st, int64_t n, const double *rw, const double *r, const double *w,
                                                       const double *s, const double *z, double *parts)
 {
 #pragma clang fp contract(off)
     __shared__ double lds[4 * kPipeB];
+    if (st && st->state != 0) return;                  // frozen loop: the partials k_pipe_b left stay what they are
     double acc[kPipeB] = {0.0, 0.0, 0.0, 0.0, 0.0};
     auto elem = [&](double ww_, double rr, double wn, double ss, double zz) {
         acc[0] += ww_ * rr;
@@ -1802,15 +1804,15 @@ __global__ __launch_bounds__(kBlock) void k_pipe_dots(int64_t n, const double *r
         for (int j = 0; j < kPipeB; j++) parts[kPipeB * blockIdx.x + j] = acc[j];
 }
 
-int launch_pipe_dots(hipStream_t s, int64_t n, const double *rw, const double *r, const double *w, const double *sv,
+int launch_pipe_dots(hipStream_t s, const LoopArgs &la, int64_t n, const double *rw, const double *r, const double *w, const double *sv,
                      const double *z, double *parts, int *nparts)
 {
     const int g = vec_grid(n);
     *nparts = g;
     if (aligned16(rw) && aligned16(r) && aligned16(w) && aligned16(sv) && aligned16(z))
-        hipLaunchKernelGGL(k_pipe_dots<1>, dim3(g), dim3(kBlock), 0, s, n, rw, r, w, sv, z, parts);
+        hipLaunchKernelGGL(k_pipe_dots<1>, dim3(g), dim3(kBlock), 0, s, la.st, n, rw, r, w, sv, z, parts);
     else
-        hipLaunchKernelGGL(k_pipe_dots<0>, dim3(g), dim3(kBlock), 0, s, n, rw, r, w, sv, z, parts);
+        hipLaunchKernelGGL(k_pipe_dots<0>, dim3(g), dim3(kBlock), 0, s, la.st, n, rw, r, w, sv, z, parts);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }

@@ -128,6 +128,7 @@ struct cudamat_solver {
     cm::ValDict vd_perm;
     double *x_perm = nullptr, *b_perm = nullptr;
     bool perm_ready = false;    // pb_perm is built
+    bool perm_failed = false;   // ... could not be (out of memory): the loop permutes around every M^-1 instead
     bool perm_active = false;   // the solve in progress runs in the level-major spaces (spmv_local uses pb_perm)
     double t_perm_matrix = 0.0;
     double t_analysis = 0.0, t_factor = 0.0, t_analysis_l = 0.0, t_analysis_u = 0.0;
@@ -158,5 +159,6 @@ int ilu_perm_matrix(cudamat_solver *s);
 int trsv_status(cudamat_solver *s);   // after a stream sync: did a dependency-driven solve give up waiting?
 bool trsv_syncfree_active(cudamat_solver *s);
 int trsv_form_code(cudamat_solver *s);           // 0 level launches, 1 dependency-driven, 2 single workgroup in LDS
+void trsv_group_counts(cudamat_solver *s, int *groups_l, int *groups_u);   // hybrid factors: groups of levels (0: not split)
 void trsv_disable_syncfree(cudamat_solver *s);   // sticky: level-by-level kernels from now on
 }  // namespace cm

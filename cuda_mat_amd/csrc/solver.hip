@@ -908,10 +908,11 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
         const char *pe = getenv("CUDAMAT_TRSV_PERM");
         perm = precond == CUDAMAT_PRECOND_ILU0 && !s->sharded && loop == CUDAMAT_LOOP_PBICGSTAB && s->L.lm && s->U.lm && !s->d &&
                !(pe && pe[0] == '0');
+        if (perm && s->perm_failed) perm = false;
         if (perm && !s->perm_ready) {
             const int rcp = ilu_perm_matrix(s);
-            if (rcp == CUDAMAT_ERR_NOMEM) perm = false;          // no room for the second blocked copy: permute per application
-            else CM_TRY(rcp);
+            if (rcp == CUDAMAT_ERR_NOMEM) { perm = false; s->perm_failed = true; }    // no room for the second blocked copy: permute per
+            else CM_TRY(rcp);                                                        // application, and do not try again on every solve
         }
     }
     s->perm_active = perm;
@@ -1177,9 +1178,11 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
             if (pipe_rr > 0 && (k + 1) % pipe_rr == 0) {
                 // Residual replacement.  q and y are free until the next k_pipe_a; pw is not used by this loop.  The
                 // kernels below return at once when the loop is frozen (`la`), the triangular solves do not look.
+                // (every kernel of this block returns at once when the loop is frozen, so r and the phase-B partials stay
+                // those of the returned iterate; the copy of x only fills the scratch vector pw)
                 CM_HIP(hipMemcpyAsync(s->pw, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
                 CM_TRY(spmv_local(s, s->pw, s->pq, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));      // q = A x
-                CM_TRY(launch_residual(st, n, b, s->pq, s->r));                                       // r = b - A x
+                CM_TRY(launch_residual(st, la, n, b, s->pq, s->r));                                   // r = b - A x
                 if (pipe_pc) CM_TRY(precond_apply(s, s->r, s->ptmp, s->prh));                         // rh = M^-1 r
                 CM_TRY(spmv_local(s, rh, s->pww, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));        // w = A rh
                 CM_TRY(spmv_local(s, s->p, s->s, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));        // s = A ph
@@ -1187,7 +1190,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
                 CM_TRY(spmv_local(s, sh, s->pz, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));         // z = A sh
                 if (pipe_pc) CM_TRY(precond_apply(s, s->pz, s->ptmp, s->pzh));                        // zh = M^-1 z
                 CM_TRY(spmv_local(s, zh, s->v, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));          // v = A zh
-                CM_TRY(launch_pipe_dots(st, n, s->rw, s->r, s->pww, s->s, s->pz, s->pipeB, &np_b));
+                CM_TRY(launch_pipe_dots(st, la, n, s->rw, s->r, s->pww, s->s, s->pz, s->pipeB, &np_b));
             }
             pipeB_src = ScalarSrc{s->pipeB, np_b, 5};
             CM_TRY(pipe_reduce(pipeB_src, 5, s->red_pipe + 8, 1));
@@ -1362,6 +1365,7 @@ static int solve_once(cudamat_solver *s, const double *b, double *x, int precond
     stt.n_levels_u = s->U.nlevels;
     stt.trsv_form = precond ? trsv_form_code(s) : 0;
     stt.trsv_fallbacks = s->trsv_fallbacks;
+    if (precond) trsv_group_counts(s, &stt.trsv_groups_l, &stt.trsv_groups_u);
     stt.loop_form = loop_form;
     stt.loop_fallbacks = s->loop_fallbacks;
     stt.overlapped = sharded && s->windowed ? 2 : (sharded && s->overlap && s->spmv_mode == 1) ? 1 : 0;

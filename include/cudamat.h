@@ -131,6 +131,10 @@ typedef struct cudamat_stats {
     int spmv_mode;         /* the SpMV form the solve used: 0 CSR forms, 1 blocked two-phase, 2 SELL-C-sigma             */
     int plan_reused;       /* cudamat_solve: 1 = the previous call brought the same matrix (pattern AND values): its solver
                             * -- device copies, SpMV plan, value dictionary, ILU(0) factors -- was reused; 0 = built anew */
+    /* hybrid triangular solves (big factors with wide, scattered levels): groups of consecutive levels per factor; one
+     * application of L^-1 (U^-1) = `groups` dependency-driven launches over the entries inside a group + `groups - 1`
+     * blocked two-phase SpMVs over the entries whose column lies in an earlier group.  0: the factor is not split.    */
+    int trsv_groups_l;     int trsv_groups_u;
 } cudamat_stats;
 
 /* Collectives for a row-sharded solve.  Either supplied by the host program (e.g.

@@ -54,6 +54,8 @@ def lib():
         L.orc_bicg_timed.argtypes = [C.c_int, i32p, i32p, f64p, f64p, f64p, C.c_int, C.c_double,
                                      C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
+        L.orc_bicg_teams.argtypes = [C.c_int, i32p, i32p, f64p, f64p, f64p, C.c_int, C.c_double,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, C.POINTER(C.c_double), f64p]
         L.orc_pbicgstab.argtypes = [C.c_int, i32p, i32p, f64p, C.c_void_p, f64p, f64p, C.c_int,
                                     C.c_double, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_pipelined_bicgstab.argtypes = [C.c_int, i32p, i32p, f64p, f64p, f64p, C.c_int, C.c_double,
@@ -161,6 +163,19 @@ def bicg_timed(A, b, maxit=2000, eps=1e-6, int_transpose=False, parallel_vec=Fal
     lib().orc_bicg_timed(A.n, A.rowptr, A.colidx, A.val, _f(b), x, maxit, eps, int(int_transpose),
                          int(parallel_vec), C.byref(it), int(fast_transpose), C.byref(tt), C.byref(tl))
     return x, it.value, tt.value, tl.value
+
+
+def bicg_teams(A, b, teams, maxit=2, eps=0.0, parallel_vec=False):
+    """the BiCG program once per OpenMP team size in `teams` after one (threaded) transposition: returns
+    (x of the last run, [iterations], t_transpose, [loop seconds]) -- bench.py's CPU baseline"""
+    x = np.empty(A.n)
+    teams = np.ascontiguousarray(teams, dtype=np.int32)
+    its = np.zeros(len(teams), np.int32)
+    tl = np.zeros(len(teams))
+    tt = C.c_double(0.0)
+    lib().orc_bicg_teams(A.n, A.rowptr, A.colidx, A.val, _f(b), x, maxit, eps, 0, int(parallel_vec), 1,
+                         len(teams), teams, its, C.byref(tt), tl)
+    return x, [int(i) for i in its], tt.value, [float(t) for t in tl]
 
 
 def ilu0(A):

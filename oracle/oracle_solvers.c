@@ -109,6 +109,19 @@ int orc_bicg_timed(int n, const int *rp_in, const int *ci_in, const double *v,
                    int int_transpose, int parallel_vec, int *iters, int fast_transpose,
                    double *t_transpose, double *t_loop)
 {
+    return orc_bicg_teams(n, rp_in, ci_in, v, b, x, maxit, eps, int_transpose, parallel_vec, fast_transpose,
+                          0, NULL, iters, t_transpose, t_loop);
+}
+
+/* The BiCG program once per OpenMP team size: ONE transposition (with the team in force at the call), then for every
+ * entry of teams[] the program's set-up (:135-144) and iteration loop (:146-182) from x = 1 with that many threads;
+ * iters[k] / t_loop[k] report each run, x holds the last one.  n_teams == 0: one run with the current team (this is
+ * orc_bicg_timed).  bench.py's CPU baseline picks its team on the loop it reports with this. */
+int orc_bicg_teams(int n, const int *rp_in, const int *ci_in, const double *v,
+                   const double *b, double *x, int maxit, double eps,
+                   int int_transpose, int parallel_vec, int fast_transpose,
+                   int n_teams, const int *teams, int *iters, double *t_transpose, double *t_loop)
+{
     /* the reference program is 0-based (bicstab.cpp:198-214); rebase if needed */
     const int base = rp_in[0];
     const int nz = rp_in[n] - base;
@@ -130,7 +143,10 @@ int orc_bicg_timed(int n, const int *rp_in, const int *ci_in, const double *v,
     double *multAP = dalloc(n), *multAtbiP = dalloc(n), *tmp;
     double alfa, beta, numerator, denominator, check, norm;
     int i, iter;
+    const int team_before = omp_get_max_threads();
 
+    for (int run = 0; run < (n_teams > 0 ? n_teams : 1); run++) {
+    if (n_teams > 0) omp_set_num_threads(teams[run] > 0 ? teams[run] : 1);
     norm = sqrt(orc_dot(n, b, b));                                      /* :135 */
     for (i = 0; i < n; i++) x[i] = 1.0;                                 /* :139 */
     orc_spmv(n, rp, ci, v, x, multAP);                                  /* :142 */
@@ -165,8 +181,10 @@ int orc_bicg_timed(int n, const int *rp_in, const int *ci_in, const double *v,
         tmp = biR; biR = nbiR; nbiR = tmp;
         tmp = biP; biP = nbiP; nbiP = tmp;                              /* :181 */
     }
-    if (iters) *iters = iter;
-    if (t_loop) *t_loop = wall_s() - tl0;
+    if (iters) iters[run] = iter;
+    if (t_loop) t_loop[run] = wall_s() - tl0;
+    }
+    if (n_teams > 0) omp_set_num_threads(team_before);
 
     free(R); free(biR); free(nR); free(nbiR);
     free(P); free(biP); free(nP); free(nbiP);

@@ -30,6 +30,7 @@ def test_plain_command_starts_its_own_ranks_and_relays_one_line():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["argv"] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
     assert out["comm"]["launcher"] == [dict(out["comm"]["launcher"][0], form="good:1", ok=True, ranks=["ok", "ok"])]
+    assert out["degraded_form"] is None
 
 
 def test_a_form_that_hangs_is_replaced_by_fresh_processes():
@@ -41,6 +42,36 @@ def test_a_form_that_hangs_is_replaced_by_fresh_processes():
     assert "time limit" in log[0]["ranks"] and log[0]["seconds"] >= 6
     assert out["comm"]["gate"][0]["form"] == "good:0"          # the line is the second form's
     assert dt < 120
+
+
+def test_two_hanging_forms_leave_the_third_its_share_of_the_budget():
+    """the driver ends a bench run after 600 s: the ladder keeps to ONE overall budget (CUDAMAT_BENCH_BUDGET, default 500 s
+    from the start of bench.py), a form that hangs is cut where the later forms keep their reserve, and the line says at
+    its top level that it was not timed on the first form"""
+    r, dt = _run("hang:1,hang:0,good:0", extra_env={"CUDAMAT_BENCH_FORM_TIMEOUT": "", "CUDAMAT_BENCH_BUDGET": "90", "CUDAMAT_BENCH_RESERVE": "15"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    log = out["comm"]["launcher"]
+    assert [e["ok"] for e in log] == [False, False, True], log
+    assert log[0]["limit_s"] <= 60 and log[1]["limit_s"] <= log[0]["limit_s"] and log[2]["limit_s"] >= 5
+    assert sum(e["seconds"] for e in log) < 90 and dt < 150
+    assert "good:0" in out["degraded_form"] and "hang:1" in out["degraded_form"]
+    for form in ("hang:1", "hang:0"):          # the launcher's log reaches stderr as it happens
+        assert "form %s -> FAILED" % form in r.stderr
+
+
+def test_default_limits_fit_the_drivers_time_limit():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert sum(b.FORM_LIMITS) <= 480 and b.BUDGET_S <= 540
+    # every form hanging: the limits handed out never exceed the budget
+    left, used = b.BUDGET_S, 0.0
+    for i in range(3):
+        lim = b._form_limit(i, 3, left)
+        used, left = used + lim, left - lim
+    assert used <= b.BUDGET_S
 
 
 def test_a_rank_that_dies_ends_its_peers_within_seconds():
