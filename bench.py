@@ -541,7 +541,7 @@ def run_bench(args):
             try:
                 if form is not None:
                     kind, overlap = form
-                    os.environ["CUDAMAT_OVERLAP"] = "1" if overlap else "0"
+                    ctx.set_option("OVERLAP", "1" if overlap else "0")
                     if comm is None or comm_desc[0] != kind:
                         solver.set_comm(None)
                         if comm is not None and hasattr(comm, "close"):
@@ -631,7 +631,7 @@ def run_bench(args):
         side = None
         if (world == 1 and not latency_bound and precond == cm.PRECOND_NONE and forced_fp64
                 and os.environ.get("CUDAMAT_BENCH_COMPARE", "1") != "0"):
-            del os.environ["CUDAMAT_VALUE_DICT"]
+            ctx.set_option("VALUE_DICT", "1")         # (a context reads the environment once; later changes go through set_option)
             s2 = None
             try:
                 s2, _ = make_solver()
@@ -648,7 +648,7 @@ def run_bench(args):
             except Exception as e:  # noqa: BLE001 - the comparison must never take the bench line down
                 side = {"error": "%s: %s" % (type(e).__name__, e)}
             finally:
-                os.environ["CUDAMAT_VALUE_DICT"] = "0"
+                ctx.set_option("VALUE_DICT", "0")
                 if s2 is not None:
                     s2.close()
 

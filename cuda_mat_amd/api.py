@@ -175,6 +175,18 @@ class Context:
     def sync(self):
         check(_lib.lib().cudamat_ctx_sync(self.h))
 
+    def set_option(self, name, value):
+        """one switch of this context (csrc/config.h; `name` as in options_help(), with or without the CUDAMAT_ prefix).
+        A context reads the CUDAMAT_* environment once, when it is created; afterwards only this call changes a switch.
+        Whatever runs on the context after the call sees the new value."""
+        check(_lib.lib().cudamat_ctx_set_option(self.h, str(name).encode(), str(value).encode()))
+        return self
+
+    def reset_options(self):
+        """back to what a context created now would hold: the defaults overridden by the CUDAMAT_* environment"""
+        check(_lib.lib().cudamat_ctx_reset_options(self.h))
+        return self
+
     def empty(self, n, dtype=np.float64):
         return DeviceArray(self, n, dtype)
 

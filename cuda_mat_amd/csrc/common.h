@@ -8,6 +8,7 @@
 #include <string>
 
 #include "cudamat.h"
+#include "config.h"
 
 namespace cm {
 
@@ -37,9 +38,10 @@ int set_max_lds(const void *fn);
         }                                     \
     } while (0)
 
-// Optional roctx ranges: with CUDAMAT_ROCTX=1 in the environment the phases of a solve (setup,
-// analysis + factorisation, iteration loop, exchanges) are bracketed by roctxRangePush/Pop, bound at run time from
-// librocprofiler-sdk-roctx / libroctx64 -- `rocprofv3 --marker-trace` then shows them.  No-ops otherwise.
+// Optional roctx ranges: once a context was created with the option ROCTX = 1 the phases of a solve
+// (setup, analysis + factorisation, iteration loop, exchanges) are bracketed by roctxRangePush/Pop, bound at run time
+// from librocprofiler-sdk-roctx / libroctx64 -- `rocprofv3 --marker-trace` then shows them.  No-ops otherwise.
+void range_enable();
 void range_push(const char *name);
 void range_pop();
 struct Range {
@@ -85,8 +87,9 @@ enum Check { CHECK_NONE = 0, CHECK_HALF = 1, CHECK_FULL = 2 };
 }  // namespace cm
 
 struct cudamat_ctx {
-    int device;
-    hipStream_t stream;
-    bool own_stream;
-    double *parts;   // kMaxParts * 2 doubles scratch for the standalone dot/nrm2
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    double *parts = nullptr;   // kMaxParts * 2 doubles scratch for the standalone dot/nrm2
+    cm::Config cfg;            // the switches everything running on this context reads (config.h)
 };

@@ -5,7 +5,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
+#include <new>
 #include <set>
 #include <utility>
 
@@ -46,13 +48,12 @@ int set_max_lds(const void *fn)
 
 // ---- optional roctx ranges
 namespace {
+std::atomic<bool> g_roctx_on{false};
 struct Roctx {
     int (*push)(const char *) = nullptr;
     int (*pop)() = nullptr;
     Roctx()
     {
-        const char *e = getenv("CUDAMAT_ROCTX");
-        if (!e || e[0] != '1') return;
         const char *names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
         for (const char *n : names) {
             void *h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -72,13 +73,16 @@ Roctx &roctx()
 }
 }  // namespace
 
+void range_enable() { g_roctx_on = true; }
 void range_push(const char *name)
 {
+    if (!g_roctx_on) return;
     Roctx &r = roctx();
     if (r.push) r.push(name);
 }
 void range_pop()
 {
+    if (!g_roctx_on) return;
     Roctx &r = roctx();
     if (r.pop) r.pop();
 }
@@ -110,21 +114,23 @@ extern "C" int cudamat_ctx_create(int device, void *stream, cudamat_ctx **out)
     }
     CM_ARG(device >= 0 && device < count, "device index out of range");
     CM_HIP(hipSetDevice(device));
-    cudamat_ctx *c = (cudamat_ctx *)calloc(1, sizeof(cudamat_ctx));
+    cudamat_ctx *c = new (std::nothrow) cudamat_ctx();
     if (!c) return CUDAMAT_ERR_NOMEM;
     c->device = device;
+    c->cfg = config_from_env();
+    if (c->cfg.roctx) range_enable();
     if (stream) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
     } else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { free(c); return fail_hip(e, "hipStreamCreate", __FILE__, __LINE__); }
+        if (e != hipSuccess) { delete c; return fail_hip(e, "hipStreamCreate", __FILE__, __LINE__); }
         c->own_stream = true;
     }
     hipError_t e = hipMalloc((void **)&c->parts, sizeof(double) * 2 * kMaxParts);
     if (e != hipSuccess) {
         if (c->own_stream) hipStreamDestroy(c->stream);
-        free(c);
+        delete c;
         return fail_hip(e, "hipMalloc(parts)", __FILE__, __LINE__);
     }
     *out = c;
@@ -138,9 +144,31 @@ extern "C" int cudamat_ctx_destroy(cudamat_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     hipFree(ctx->parts);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
-    free(ctx);
+    delete ctx;
     return CUDAMAT_OK;
 }
+
+// One switch of this context (config.h; names as in cudamat_options_help, with or without the CUDAMAT_ prefix).  Read by
+// whatever runs on the context AFTER the call: set SpMV-form switches before the first use of a solver, ILU(0) ones
+// before cudamat_solver_ilu0, loop ones before cudamat_solver_solve.
+extern "C" int cudamat_ctx_set_option(cudamat_ctx *ctx, const char *name, const char *value)
+{
+    CM_ARG(ctx && name && value, "null pointer");
+    if (!config_set(ctx->cfg, name, value)) return CUDAMAT_ERR_ARG;
+    if (ctx->cfg.roctx) range_enable();
+    return CUDAMAT_OK;
+}
+
+// back to what a context created NOW would hold: the defaults overridden by the CUDAMAT_* environment
+extern "C" int cudamat_ctx_reset_options(cudamat_ctx *ctx)
+{
+    CM_ARG(ctx, "ctx is NULL");
+    ctx->cfg = config_from_env();
+    if (ctx->cfg.roctx) range_enable();
+    return CUDAMAT_OK;
+}
+
+extern "C" const char *cudamat_options_help(void) { return config_help(); }
 
 extern "C" int cudamat_ctx_sync(cudamat_ctx *ctx)
 {
@@ -270,8 +298,8 @@ extern "C" int cudamat_spmv(cudamat_ctx *ctx, int n, const int *rowptr, const in
     int last = 0;
     CM_HIP(hipMemcpyAsync(&last, rowptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CM_HIP(hipStreamSynchronize(ctx->stream));
-    SpmvPlan plan = plan_spmv(n, (int64_t)last - base);
-    CM_TRY(plan_spmv_refine(ctx->stream, n, (int64_t)last - base, rowptr, base, &plan));
+    SpmvPlan plan = plan_spmv(ctx->cfg, n, (int64_t)last - base);
+    CM_TRY(plan_spmv_refine(ctx->stream, ctx->cfg, n, (int64_t)last - base, rowptr, base, &plan));
     SpmvArgs a{};
     a.n = n;
     a.rp = rowptr;

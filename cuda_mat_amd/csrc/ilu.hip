@@ -40,10 +40,9 @@ static double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static bool verbose() { static const bool v = getenv("CUDAMAT_VERBOSE") != nullptr; return v; }
 #define CM_STAMP(label)                                                                       \
     do {                                                                                      \
-        if (verbose()) {                                                                      \
+        if (s->ctx->cfg.verbose) {                                                            \
             hipStreamSynchronize(st);                                                         \
             const double t_now = now_s();                                                     \
             fprintf(stderr, "[cudamat] ilu0 %-28s %8.3f ms\n", label, (t_now - t_stamp) * 1e3); \
@@ -623,16 +622,11 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
     bool want_hybrid = false;              // this factor alone would take the hybrid solve (the two factors decide together)
     bool syncfree = false;                 // one dependency-driven launch per group instead of one launch per level
     int spin_limit = kSpinLimit;
-    int nap = 2;                           // s_sleep between polls (CUDAMAT_TRSV_NAP = 0, 1, 2, 4)
+    int nap = 2;                           // s_sleep between polls (0 / 1 / 2 / 4 measured equal within noise)
     int occ = 8;                           // workgroups per CU the dependency-driven launch may keep resident
     bool lds = false;                      // n <= 16384, narrow levels: the whole solve in one workgroup, x in LDS
     unsigned *tickets = nullptr;           // device: one chunk-ticket counter per dependency-driven launch (group)
-    // far phase 1 beside the previous group's near launch (round 3): the column blocks of far[g] whose positions lie in
-    // groups <= g-2 are final one group earlier; they run on `side` while group g-1 is solved
-    hipStream_t side = nullptr;
-    std::vector<hipEvent_t> ev_near, ev_p1a;
-    std::vector<int> ready_blocks;         // per group: leading column blocks of its far plan that may run early
-    size_t p1_lds = 0;                     // largest dynamic LDS request of the far plans' phase 1
+    int pb_strict = 0;                     // Config::pb_strict at set-up: passed to the far parts' phase 2
 };
 
 }  // namespace cm
@@ -696,9 +690,6 @@ int ilu0_release(cudamat_solver *s)
             for (PbPlan &fp : h->far) pb_free(&fp);
             if (h->far_buf) hipFree(h->far_buf);
             if (h->tickets) hipFree(h->tickets);
-            for (hipEvent_t e : h->ev_near) if (e) hipEventDestroy(e);
-            for (hipEvent_t e : h->ev_p1a) if (e) hipEventDestroy(e);
-            if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
         }
         if (pl->err_host) hipHostFree(pl->err_host);
         if (pl->posU) hipFree(pl->posU);
@@ -711,11 +702,11 @@ int ilu0_release(cudamat_solver *s)
 }
 
 // host-side loops over 1e7 rows (level sort, row pointers): a few threads over contiguous ranges
-static int host_threads(long long n)
+static int host_threads(const Config &cfg, long long n)
 {
     if (n < (1 << 20)) return 1;
     unsigned hw = std::thread::hardware_concurrency();
-    if (const char *e = getenv("CUDAMAT_HOST_THREADS")) hw = (unsigned)atoi(e);
+    if (cfg.host_threads) hw = (unsigned)cfg.host_threads;
     return hw < 1 ? 1 : hw > 16 ? 16 : (int)hw;
 }
 
@@ -751,15 +742,15 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
                         std::vector<int> &h_rp, std::vector<int> &h_diag, int *err_host, int *err_dev)
 {
     hipStream_t st = s->ctx->stream;
+    const Config &cfg = s->ctx->cfg;
     const int n = s->n;
     double t_stamp = now_s();
     const long long threads = (long long)n * 8;
     const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
-    // one dependency-driven pass; the relaxation sweeps below remain as the fallback (CUDAMAT_LEVELS_SWEEP=1
+    // one dependency-driven pass; the relaxation sweeps below remain as the fallback (option LEVELS_SWEEP = 1
     // or a timed-out wait)
     bool have_levels = false;
-    const char *force_sweep = getenv("CUDAMAT_LEVELS_SWEEP");
-    if (n > 0 && err_host && !(force_sweep && force_sweep[0] == '1')) {
+    if (n > 0 && err_host && !s->ctx->cfg.levels_sweep) {
         CM_HIP(hipMemsetAsync(d_lev, 0xFF, sizeof(int) * (size_t)n, st));
         // lanes per row from the mean number of dependencies: with 2 per row (stencils) one lane per row keeps 8x
         // more rows in flight, and rows in flight are what a chain-like dependency graph needs (unlike the
@@ -804,7 +795,7 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
     // stable counting sort of the rows by level + the factor's row pointers.  Big systems: T host threads over
     // contiguous row ranges (per-thread level counts give every thread its own stable write cursors; same result as
     // the serial loops) -- at 1e7 rows 44 ms per factor serial
-    const int T = host_threads(n);
+    const int T = host_threads(s->ctx->cfg, n);
     std::vector<int> tmax((size_t)T, 0);
     parallel_ranges(n, T, [&](int t, int lo, int hi) {
         int m = 0;
@@ -874,22 +865,18 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
     CM_HIP(hipMemcpy(H.level_ptr_dev, F.level_ptr.data(), sizeof(int) * ((size_t)nlev + 1), hipMemcpyHostToDevice));
     CM_STAMP("factor arrays alloc + upload");
     H.lanes = pick_lanes(n ? (double)F.nnz / n : 1.0);
-    if (const char *e = getenv("CUDAMAT_TRSV_LANES")) {
-        const int v = atoi(e);
-        if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) H.lanes = v;
-    }
+    if (cfg.trsv_lanes) H.lanes = cfg.trsv_lanes;
     // the hybrid solve is for big factors with many wide levels whose columns are scattered (the gather-bound case);
     // the two factors decide together (ilu0_setup): they share the level-major index spaces
     H.lev_host.swap(lev);
-    const char *hy = getenv("CUDAMAT_TRSV_HYBRID");
-    H.want_hybrid = nlev >= 4 && (hy ? hy[0] == '1' : (n >= 500000 && F.nnz >= (8 << 20) && nlev >= 16 && n / nlev >= 16384));
+    H.want_hybrid = nlev >= 4 && (cfg.trsv_hybrid >= 0 ? cfg.trsv_hybrid == 1 : (n >= 500000 && F.nnz >= (8 << 20) && nlev >= 16 && n / nlev >= 16384));
     return CUDAMAT_OK;
 }
 
 // groups of consecutive levels (hybrid: ~17 levels per group leaves ~15 % of the entries near; measured at C5, round 3:
 // 5 / 8 / 12 / 16 / 24 groups -> 4.85 / 4.79 / 5.03 / 5.54 / 6.57 ms per L^-1 U^-1 -- the near launches shrink with more
 // groups, the far SpMVs lose more on their shorter segments) and the launch plan
-static void plan_groups(const TriFactor &F, TriHost &H, bool hybrid)
+static void plan_groups(const Config &cfg, const TriFactor &F, TriHost &H, bool hybrid)
 {
     const int nlev = F.nlevels;
     int K = 1;
@@ -897,15 +884,12 @@ static void plan_groups(const TriFactor &F, TriHost &H, bool hybrid)
         K = nlev / 17;
         if (K < 2) K = 2;
         if (K > 16) K = 16;
-        if (const char *e = getenv("CUDAMAT_TRSV_GROUPS")) {
-            const int v = atoi(e);
-            if (v >= 2 && v <= 128 && v <= nlev) K = v;
-        }
+        if (cfg.trsv_groups >= 2 && cfg.trsv_groups <= nlev) K = cfg.trsv_groups;
     }
     H.hybrid = K > 1;
     H.grp_level.assign((size_t)K + 1, 0);
     for (int g = 0; g <= K; g++) H.grp_level[(size_t)g] = (int)((long long)nlev * g / K);
-    if (getenv("CUDAMAT_VERBOSE") && K > 1) {
+    if (cfg.verbose && K > 1) {
         fprintf(stderr, "cudamat: trsv groups (levels:rows)");
         for (int g = 0; g < K; g++)
             fprintf(stderr, " %d:%d", H.grp_level[(size_t)g + 1] - H.grp_level[(size_t)g],
@@ -1115,7 +1099,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
         std::vector<unsigned char> g_of_level((size_t)F.nlevels);
         for (int g = 0; g < K; g++)
             for (int l = H.grp_level[(size_t)g]; l < H.grp_level[(size_t)g + 1]; l++) g_of_level[(size_t)l] = (unsigned char)g;
-        parallel_ranges(n, host_threads(n), [&](int, int lo, int hi) {
+        parallel_ranges(n, host_threads(s->ctx->cfg, n), [&](int, int lo, int hi) {
             for (int i = lo; i < hi; i++) hg[(size_t)i] = g_of_level[(size_t)H.lev_host[(size_t)i]];
         });
     }
@@ -1166,7 +1150,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
             const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)g]], r1 = F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]];
             const int64_t cnt = (int64_t)hf_grp[(size_t)g + 1] - hf_grp[(size_t)g];
             if (r1 <= r0 || cnt <= 0) continue;
-            rc = pb_build(st, r1 - r0, r0, cnt, qrp + r0, qci2, qval2, &H.far[(size_t)g]);
+            rc = pb_build(st, s->ctx->cfg, r1 - r0, r0, cnt, qrp + r0, qci2, qval2, &H.far[(size_t)g]);
         }
         CM_STAMP("far plans (pb_build)");
         if (rc) break;
@@ -1343,7 +1327,7 @@ int ilu0_setup(cudamat_solver *s, bool block)
         if ((rc = build_levels(s, true, d_lev, d_flags, s->U, pl->U, h_rp, h_diag, pl->err_host, pl->err_dev))) break;
         int maxrow_all = 0;
         {
-            const int T = host_threads(n);
+            const int T = host_threads(s->ctx->cfg, n);
             std::vector<int> tm((size_t)T, 0);
             parallel_ranges(n, T, [&](int t, int lo, int hi) {
                 int m = 0;
@@ -1356,8 +1340,8 @@ int ilu0_setup(cudamat_solver *s, bool block)
             // the two factors take the hybrid solve TOGETHER: they then share the level-major index spaces (L's output
             // feeds U's right-hand side, U's output the permuted matrix of the preconditioned loop)
             const bool hybrid = pl->L.want_hybrid && pl->U.want_hybrid && maxrow_all <= kSortRowMax;
-            plan_groups(s->L, pl->L, hybrid);
-            plan_groups(s->U, pl->U, hybrid);
+            plan_groups(s->ctx->cfg, s->L, pl->L, hybrid);
+            plan_groups(s->ctx->cfg, s->U, pl->U, hybrid);
         }
         s->t_analysis_u = now_s() - tu;
         s->t_analysis = now_s() - t0;
@@ -1370,8 +1354,7 @@ int ilu0_setup(cudamat_solver *s, bool block)
         const int maxrow = maxrow_all;
         const int cap = ((maxrow + 63) / 64) * 64 + 64;
         const bool one_wave = cap > 2048;
-        const char *slow = getenv("CUDAMAT_ILU0_SIMPLE");
-        const bool fast = cap <= 1024 && !(slow && slow[0] == '1');
+        const bool fast = cap <= 1024 && !s->ctx->cfg.ilu0_simple;
         if ((size_t)cap * sizeof(double) > 150 * 1024) {
             set_error("ILU(0): a row with %d entries exceeds the %d-entry LDS staging limit", maxrow, 150 * 1024 / 8);
             rc = CUDAMAT_ERR_ARG;
@@ -1445,10 +1428,10 @@ int ilu0_setup(cudamat_solver *s, bool block)
         pl->U.lev_host.clear(); pl->U.lev_host.shrink_to_fit();
         s->t_factor = now_s() - t1;
         // solve form: one dependency-driven launch per group (default whenever there is more than one level
-        // to chain), or one launch per level / run of small levels (CUDAMAT_TRSV_SYNCFREE=0)
+        // to chain), or one launch per level / run of small levels (option TRSV_SYNCFREE = 0)
         {
-            const char *sf = getenv("CUDAMAT_TRSV_SYNCFREE");
-            const bool on = sf ? sf[0] == '1' : true;
+            const Config &cfg = s->ctx->cfg;
+            const bool on = cfg.trsv_syncfree != 0;
             // narrow levels (mat10000: <= 100 rows each): the whole factor runs as ONE single-workgroup launch with a
             // barrier per level (0.75 us per level, measured), which beats hand-offs through memory (1.0 us); from a few
             // hundred rows per level on, the dependency-driven form wins (Poisson 4000x2500: 6x)
@@ -1457,15 +1440,14 @@ int ilu0_setup(cudamat_solver *s, bool block)
                 for (int l = 0; l < F.nlevels; l++) w = std::max(w, F.level_ptr[(size_t)l + 1] - F.level_ptr[(size_t)l]);
                 return w;
             };
-            const bool forced = sf && sf[0] == '1';
+            const bool forced = cfg.trsv_syncfree == 1;
             pl->L.syncfree = on && s->L.nlevels > 1 && (forced || widest(s->L) > 512);
             pl->U.syncfree = on && s->U.nlevels > 1 && (forced || widest(s->U) > 512);
-            const char *le = getenv("CUDAMAT_TRSV_LDS");
-            const bool lds_on = !(le && le[0] == '0') && n > 0 && n <= kLdsTrsvRows;
+            const bool lds_on = cfg.trsv_lds && n > 0 && n <= kLdsTrsvRows;
             pl->L.lds = lds_on && !pl->L.hybrid && widest(s->L) <= 512;
             pl->U.lds = lds_on && !pl->U.hybrid && widest(s->U) <= 512;
-            if (const char *lim = getenv("CUDAMAT_TRSV_SPIN_LIMIT")) pl->L.spin_limit = pl->U.spin_limit = atoi(lim);
-            if (const char *np = getenv("CUDAMAT_TRSV_NAP")) pl->L.nap = pl->U.nap = atoi(np);
+            if (cfg.trsv_spin_limit) pl->L.spin_limit = pl->U.spin_limit = cfg.trsv_spin_limit;
+            pl->L.pb_strict = pl->U.pb_strict = cfg.pb_strict;
             // Resident workgroups per CU of the dependency-driven launch.  Every waiting row polls memory, and pollers
             // slow the very hand-offs they wait for: with little work per level the chain of hand-offs is the whole
             // cost and FEWER resident workgroups are faster (Poisson 4000x2500, 5 K entries per level: 27.6 ms per
@@ -1477,48 +1459,15 @@ int ilu0_setup(cudamat_solver *s, bool block)
             };
             pl->L.occ = pick_occ(s->L);
             pl->U.occ = pick_occ(s->U);
-            if (const char *oc = getenv("CUDAMAT_TRSV_OCC")) pl->L.occ = pl->U.occ = atoi(oc);
             for (TriHost *h : {&pl->L, &pl->U}) {
                 const size_t k = h->grp_level.size() > 1 ? h->grp_level.size() - 1 : 1;
                 if (!h->tickets && (rc = dalloc(&h->tickets, k))) break;
             }
             if (rc) break;
-            // far phase 1 beside the near launches (level-major factors, dependency-driven solves): which blocks of every
-            // far plan are final one group early, a side stream, one event pair per group.  Built and measured in round 3
-            // (alternating A/B at C5): 4.95 ms per L^-1 U^-1 with the overlap against 4.78 without -- the streaming
-            // phase 1 and the gathering near launch compete for the same fabric requests, and the near launch loses its
-            // one-workgroup-per-CU residency.  So it is OFF unless CUDAMAT_TRSV_OVERLAP=1.
-            {
-                const char *ov = getenv("CUDAMAT_TRSV_OVERLAP");
-                const bool want_ov = ov && ov[0] == '1';
-                for (int f = 0; f < 2 && want_ov; f++) {
-                    TriHost *h = f ? &pl->U : &pl->L;
-                    const TriFactor &F = f ? s->U : s->L;
-                    if (!h->hybrid || !h->syncfree || !F.lm) continue;
-                    const int K = (int)h->grp_level.size() - 1;
-                    h->ready_blocks.assign((size_t)K, 0);
-                    bool any = false;
-                    for (int g = 2; g < K; g++) {
-                        const PbPlan &fp = h->far[(size_t)g];
-                        if (fp.nnz <= 0 || fp.CB <= 0) continue;
-                        const long long start_prev = F.level_ptr[(size_t)h->grp_level[(size_t)g - 1]];     // first position of group g-1
-                        int rb = (int)(start_prev / fp.CB);
-                        if (rb > fp.NCB) rb = fp.NCB;
-                        h->ready_blocks[(size_t)g] = rb;
-                        any = any || rb > 0;
-                        const size_t need = pb_phase1_lds_bytes(fp);
-                        h->p1_lds = need > h->p1_lds ? need : h->p1_lds;
-                    }
-                    if (!any) { h->ready_blocks.clear(); continue; }
-                    bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
-                    h->ev_near.assign((size_t)K, nullptr);
-                    h->ev_p1a.assign((size_t)K, nullptr);
-                    for (int g = 0; g < K && ok; g++)
-                        ok = hipEventCreateWithFlags(&h->ev_near[(size_t)g], hipEventDisableTiming) == hipSuccess &&
-                             hipEventCreateWithFlags(&h->ev_p1a[(size_t)g], hipEventDisableTiming) == hipSuccess;
-                    if (!ok) h->ready_blocks.clear();            // (no overlap: everything on the solver's stream)
-                }
-            }
+            // (The early column blocks of a group's far phase 1 on a side stream beside the previous group's near launch were
+            // built and measured in round 3, alternating A/B at C5: 4.95 ms per L^-1 U^-1 with the overlap against 4.78
+            // without -- the streaming phase 1 and the gathering near launch compete for the same fabric requests, and the
+            // near launch loses its one-workgroup-per-CU residency.  Removed in round 4; HISTORY.md.)
         }
         s->has_ilu = true;
     } while (0);
@@ -1531,22 +1480,6 @@ int ilu0_setup(cudamat_solver *s, bool block)
         set_error("%s", saved);
     }
     return rc;
-}
-
-static SpmvArgs far_args(const TriFactor &F, const TriHost &H, int grp, const double *out)
-{
-    const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)grp]];
-    SpmvArgs a{};
-    a.n = H.far[(size_t)grp].n;
-    a.x = out;
-    a.alpha = 1.0;
-    a.beta = 0.0;
-    a.y = H.far_buf + r0;
-    a.dot = 0;
-    a.loop = LoopArgs{nullptr, nullptr, 0, 0, 0};
-    a.check = CHECK_NONE;
-    a.half = ScalarSrc{nullptr, 0, 1};
-    return a;
 }
 
 // the far SpMV of one group: far_buf[rows of the group] = far_g . out
@@ -1563,6 +1496,7 @@ static int launch_far(hipStream_t st, const TriFactor &F, const TriHost &H, int 
     a.loop = LoopArgs{nullptr, nullptr, 0, 0, 0};
     a.check = CHECK_NONE;
     a.half = ScalarSrc{nullptr, 0, 1};
+    a.pb_strict = H.pb_strict;
     return launch_spmv_pb(st, H.far[(size_t)grp], a);
 }
 
@@ -1606,32 +1540,13 @@ static int launch_trsv_syncfree_b(hipStream_t st, const TriFactor &F, const TriH
                        (unsigned long long *)out);
     const int K = (int)H.grp_level.size() - 1;
     CM_HIP(hipMemsetAsync(H.tickets, 0, sizeof(unsigned) * (size_t)(K > 0 ? K : 1), st));     // one ticket counter per launch
-    // Far phase 1 beside the near launches: the blocks of far[g + 1] whose positions lie in groups <= g - 1 are final as
-    // soon as group g - 1 is solved, so they are issued on the side stream (behind group g - 1's event) right before
-    // group g's own launches go to the solver's stream -- the streaming phase 1 then runs while group g's far rest, its
-    // phase 2 and its dependency-driven launch (whose waves spend much of their time waiting) occupy the solver's stream.
-    const bool ov = !H.ready_blocks.empty() && H.side != nullptr;
     for (int g = 0; g < K; g++) {
         const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)g]], r1 = F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]];
         if (r1 <= r0) continue;
         const double *far = nullptr;
         if (H.hybrid && g > 0 && H.far[(size_t)g].nnz > 0) {
-            const int early = ov ? H.ready_blocks[(size_t)g] : 0;
-            if (early > 0) {
-                const SpmvArgs a = far_args(F, H, g, out);
-                CM_HIP(hipStreamWaitEvent(st, H.ev_p1a[(size_t)g], 0));                    // the early blocks (side stream)
-                CM_TRY(launch_pb_phase1_range(st, H.far[(size_t)g], a, early, H.far[(size_t)g].NCB));
-                CM_TRY(launch_pb_phase2(st, H.far[(size_t)g], a));
-            } else {
-                CM_TRY(launch_far(st, F, H, g, out));
-            }
+            CM_TRY(launch_far(st, F, H, g, out));
             far = H.far_buf;
-        }
-        if (ov && g + 1 < K && g >= 1 && H.ready_blocks[(size_t)g + 1] > 0 && H.far[(size_t)g + 1].nnz > 0) {
-            const SpmvArgs a1 = far_args(F, H, g + 1, out);
-            CM_HIP(hipStreamWaitEvent(H.side, H.ev_near[(size_t)g - 1], 0));               // groups <= g - 1 are final
-            CM_TRY(launch_pb_phase1_range(H.side, H.far[(size_t)g + 1], a1, 0, H.ready_blocks[(size_t)g + 1]));
-            CM_HIP(hipEventRecord(H.ev_p1a[(size_t)g + 1], H.side));
         }
         // A ticket = `steps` consecutive sub-chunks of RPB rows: at least 256 rows, so that the one counter sees an
         // atomic per 256 rows at most (far below what one address sustains).  The rows in flight are
@@ -1645,18 +1560,11 @@ static int launch_trsv_syncfree_b(hipStream_t st, const TriFactor &F, const TriH
         // no more workgroups than can be resident; more would only queue behind the persistent ones
         const long long cap = (long long)per_cu * 256;
         const unsigned grid = (unsigned)(ntick < cap ? ntick : cap);
-        // residency is pinned with an (unused) dynamic LDS request: fewer waiting workgroups, fewer pollers; with the far
-        // phase 1 running beside it, room is left for one of its workgroups (x tile) per compute unit
-        size_t lds_pad = (size_t)(152 * 1024) / (size_t)per_cu;
-        if (ov && per_cu == 1) {
-            const size_t room = (size_t)160 * 1024 - 2048;
-            lds_pad = room > H.p1_lds ? room - H.p1_lds : 0;
-            if (lds_pad > (size_t)(152 * 1024)) lds_pad = (size_t)(152 * 1024);
-        }
+        // residency is pinned with an (unused) dynamic LDS request: fewer waiting workgroups, fewer pollers
+        const size_t lds_pad = (size_t)(152 * 1024) / (size_t)per_cu;
         CM_TRY(set_max_lds((const void *)k_trsv_syncfree<LANES, BLOCK>));
         hipLaunchKernelGGL((k_trsv_syncfree<LANES, BLOCK>), dim3(grid), dim3(BLOCK), lds_pad, st, r0, r1, F.rp, F.ci, F.val,
                            F.rhs_of, F.out_of, F.dinv, far, rhs, out, err, H.spin_limit, H.nap, H.tickets + g, steps);
-        if (ov) CM_HIP(hipEventRecord(H.ev_near[(size_t)g], st));
     }
     return CUDAMAT_OK;
 }
@@ -1845,9 +1753,9 @@ int ilu_perm_matrix(cudamat_solver *s)
         if ((rc = device_exclusive_scan(st, n, d_len, d_rp))) break;
         if ((rc = launch_sort_rows(st, n, s->pm_rp, s->L.row_of, d_rp, s->pm_ci, s->pm_val, pl->posU, d_ci, d_val))) break;
         if (nnz >= (1 << 20)) {
-            if ((rc = valdict_build(st, nnz, d_val, &s->vd_perm))) break;       // (n == 0 afterwards: no dictionary, fp64 values)
+            if ((rc = valdict_build(st, s->ctx->cfg, nnz, d_val, &s->vd_perm))) break;       // (n == 0 afterwards: no dictionary, fp64 values)
         }
-        if ((rc = pb_build(st, n, n, nnz, d_rp, d_ci, d_val, &s->pb_perm, nullptr, &s->vd_perm))) break;
+        if ((rc = pb_build(st, s->ctx->cfg, n, n, nnz, d_rp, d_ci, d_val, &s->pb_perm, nullptr, &s->vd_perm))) break;
         if (!s->x_perm && (rc = dalloc(&s->x_perm, (size_t)(s->n_pad > n ? s->n_pad : n)))) break;
         if (!s->b_perm && (rc = dalloc(&s->b_perm, (size_t)(s->n_pad > n ? s->n_pad : n)))) break;
         if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("permuted matrix build failed"); break; }
@@ -1864,7 +1772,7 @@ int ilu_perm_matrix(cudamat_solver *s)
     hipFree(pl->posU);
     pl->posU = nullptr;
     s->t_perm_matrix = now_s() - t0;
-    if (verbose()) fprintf(stderr, "[cudamat] ilu0 permuted matrix (rows in L order, columns in U positions) %8.3f ms\n", s->t_perm_matrix * 1e3);
+    if (s->ctx->cfg.verbose) fprintf(stderr, "[cudamat] ilu0 permuted matrix (rows in L order, columns in U positions) %8.3f ms\n", s->t_perm_matrix * 1e3);
     return CUDAMAT_OK;
 }
 

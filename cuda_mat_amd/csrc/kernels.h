@@ -48,7 +48,7 @@ struct SpmvPlan {
     short *d_off16 = nullptr;
     unsigned char *d_val8 = nullptr;
 };
-SpmvPlan plan_spmv(int n_rows, int64_t nnz);
+SpmvPlan plan_spmv(const Config &cfg, int n_rows, int64_t nnz);
 void plan_spmv_free(SpmvPlan *plan);
 // per-workgroup dot partials one launch leaves behind
 inline int plan_spmv_parts(const SpmvPlan &p) { return p.grid + (p.tiles ? p.tile_fix_grid : 0); }
@@ -56,7 +56,7 @@ inline int plan_spmv_parts(const SpmvPlan &p) { return p.grid + (p.tiles ? p.til
 // `stream_rows` consecutive rows holds at most kStreamNnz entries (checked on the device); otherwise, when
 // the lanes-per-row kernel would spend > 2.5 lane-iterations per entry (skewed row lengths), switch it to the
 // nnz-balanced tile kernel.  CUDAMAT_SPMV_FORM=lanes|tiles forces one of the two.
-int plan_spmv_refine(hipStream_t s, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan);
+int plan_spmv_refine(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan);
 
 // y = alpha*(A x + d .* xd) + beta*y  on 0- or 1-based CSR (base folded into the
 // pointers by the caller).  dot: 0 none, 1: parts[2b] = sum y*w, 2: also
@@ -78,6 +78,7 @@ struct SpmvArgs {
     LoopArgs loop;
     int check;
     ScalarSrc half;
+    int pb_strict;        // blocked form, phase 2: add a row's products of one wave instruction rank by rank (Config::pb_strict)
 };
 int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a);
 
@@ -108,10 +109,10 @@ int launch_resident_loop(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a,
 bool fused_spmv_supported(const SpmvPlan &plan);
 int launch_fused_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a, const FuseArgs &f);
 // stream plans only: build the compressed index copy when every offset fits (no-op otherwise); rp/ci 0-based
-int plan_spmv_compress(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const int *ci, SpmvPlan *plan);
+int plan_spmv_compress(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, const int *ci, SpmvPlan *plan);
 // compressed stream plans of a matrix with a value dictionary (valdict.h): vidx = 8-bit value index per entry in CSR
 // order, dict = 256 doubles on the device (not owned); no-op when the plan has no compressed copy
-int plan_spmv_align(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const double *val, SpmvPlan *plan);
+int plan_spmv_align(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, const double *val, SpmvPlan *plan);
 int plan_spmv_dict(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const unsigned char *vidx, const double *dict,
                    SpmvPlan *plan);
 
@@ -127,10 +128,8 @@ int launch_init_finish(hipStream_t s, LoopState *st, ScalarSrc init, double tol,
 // p = r + beta (p - omega v), preceded by the full-step test of the previous iteration
 int launch_update_p(hipStream_t s, LoopArgs la, ScalarSrc full, int64_t n, const double *r,
                     double *p, const double *v);
-// alpha = rho / (rw.v); r -= alpha v; x += alpha pw; parts[2b] = sum r^2
-// x == NULL: the update of x is left to launch_full(..., pw) of the same iteration
-int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, const double *v,
-                double *x, const double *pw, double *parts, int *nparts);
+// alpha = rho / (rw.v); r -= alpha v; parts[b] = sum r^2   (the half step's x += alpha pw rides in launch_full(..., pw))
+int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, const double *v, double *parts, int *nparts);
 // omega = (t.r)/(t.t); x += omega s; r -= omega t; parts = (rw.r, r.r); it++
 // half.ptr != NULL: evaluate the half-step stopping test from `half` first (fused small-system loop)
 // pw != NULL: x += alpha pw (the half step's update, with the alpha k_half stored) before x += omega s

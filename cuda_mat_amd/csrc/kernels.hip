@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a, int rows_per_block)
     }
 }
 
-SpmvPlan plan_spmv(int n_rows, int64_t nnz)
+SpmvPlan plan_spmv(const Config &cfg, int n_rows, int64_t nnz)
 {
     SpmvPlan p;
     p.stream_rows = 0;
@@ -308,10 +308,7 @@ SpmvPlan plan_spmv(int n_rows, int64_t nnz)
     else if (mean <= 12.0) L = 8;
     else if (mean <= 40.0) L = 16;
     else if (mean <= 96.0) L = 32;
-    if (const char *e = getenv("CUDAMAT_SPMV_LANES")) {
-        int v = atoi(e);
-        if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L = v;
-    }
+    if (cfg.spmv_lanes) L = cfg.spmv_lanes;
     p.lanes = L;
     const int rpb = kBlock / L;
     long long groups = ((long long)n_rows + rpb - 1) / rpb;
@@ -596,10 +593,9 @@ __global__ __launch_bounds__(kBlock) void k_stream_compress(int n, int R, const 
     }
 }
 
-int plan_spmv_compress(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const int *ci, SpmvPlan *plan)
+int plan_spmv_compress(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, const int *ci, SpmvPlan *plan)
 {
-    const char *env = getenv("CUDAMAT_SPMV_COMPRESS");
-    if (!plan->stream_rows || nnz <= 0 || (env && env[0] == '0')) return CUDAMAT_OK;
+    if (!plan->stream_rows || nnz <= 0 || !cfg.spmv_compress) return CUDAMAT_OK;
     const int R = plan->stream_rows;
     const size_t ntiles = ((size_t)n_rows + R - 1) / R;
     int *flags = nullptr, h = 0;
@@ -689,11 +685,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_align_fill(int n, int R, const 
 // L1 -> L2 requests, and a request moves at most one 128-byte line: with a tile's entries starting
 // anywhere, a wave's 512-byte value load touches five lines and its 128-byte offset load two; with every tile starting on
 // a 64-entry boundary they touch four and one.  Costs <= 63 idle slots per tile (2.5 % at 5 entries per row) and a second
-// copy of the values in HBM.  CUDAMAT_SPMV_ALIGN=0 keeps the packed arrays.
-int plan_spmv_align(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const double *val, SpmvPlan *plan)
+// copy of the values in HBM.  The option SPMV_ALIGN = 0 keeps the packed arrays.
+int plan_spmv_align(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, const double *val, SpmvPlan *plan)
 {
-    const char *env = getenv("CUDAMAT_SPMV_ALIGN");
-    if (!plan->stream_rows || !plan->c_off16 || nnz <= 0 || (env && env[0] == '0')) return CUDAMAT_OK;
+    if (!plan->stream_rows || !plan->c_off16 || nnz <= 0 || !cfg.spmv_align) return CUDAMAT_OK;
     const int R = plan->stream_rows;
     const int ntiles = (int)(((long long)n_rows + R - 1) / R);
     if (nnz + 63LL * ntiles > 0x7fffffffLL) return CUDAMAT_OK;
@@ -1064,11 +1059,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_nnz_max(int n, const int *rp, i
 }
 
 // skewed row lengths: measure what the lanes-per-row plan would cost and switch to tiles when it is unbalanced
-static int plan_spmv_balance(hipStream_t s, int n_rows, int64_t nnz, const int *rp, SpmvPlan *plan)
+static int plan_spmv_balance(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, SpmvPlan *plan)
 {
-    const char *form = getenv("CUDAMAT_SPMV_FORM");
-    if (form && !strcmp(form, "lanes")) return CUDAMAT_OK;
-    const bool force = form && !strcmp(form, "tiles");
+    if (cfg.spmv_form == 1) return CUDAMAT_OK;          // lanes
+    const bool force = cfg.spmv_form == 2;              // tiles
     if (nnz <= 0 || n_rows <= 0) return CUDAMAT_OK;
     if (!force) {
         if (nnz < 65536) return CUDAMAT_OK;
@@ -1090,14 +1084,14 @@ static int plan_spmv_balance(hipStream_t s, int n_rows, int64_t nnz, const int *
     return plan_spmv_tiles(s, n_rows, nnz, rp, plan);
 }
 
-int plan_spmv_refine(hipStream_t s, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan)
+int plan_spmv_refine(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan)
 {
     (void)base;
     plan->stream_rows = 0;
-    if (getenv("CUDAMAT_SPMV_LANES")) return CUDAMAT_OK;          // explicit lanes-per-row request
+    if (cfg.spmv_lanes) return CUDAMAT_OK;          // explicit lanes-per-row request
     const double mean = n_rows > 0 ? (double)nnz / n_rows : 0.0;
     if (n_rows < 64) return CUDAMAT_OK;
-    if (mean > 12.0) return plan_spmv_balance(s, n_rows, nnz, rp, plan);
+    if (mean > 12.0) return plan_spmv_balance(s, cfg, n_rows, nnz, rp, plan);
     int *d = nullptr, h[3] = {0, 0, 0};
     CM_HIP(hipMalloc((void **)&d, 3 * sizeof(int)));
     hipMemsetAsync(d, 0, 3 * sizeof(int), s);
@@ -1111,7 +1105,7 @@ int plan_spmv_refine(hipStream_t s, int n_rows, int64_t nnz, const int *rp, int 
     if (h[2] <= kStreamNnz) R = 256;
     else if (h[1] <= kStreamNnz) R = 128;
     else if (h[0] <= kStreamNnz) R = 64;
-    if (!R) return plan_spmv_balance(s, n_rows, nnz, rp, plan);
+    if (!R) return plan_spmv_balance(s, cfg, n_rows, nnz, rp, plan);
     const long long tiles_r = ((long long)n_rows + R - 1) / R;
     int grid = (int)(tiles_r < kSpmvGridMax ? tiles_r : kSpmvGridMax);
     const long long per = (tiles_r + grid - 1) / grid;
@@ -1314,11 +1308,13 @@ int launch_update_p(hipStream_t s, LoopArgs la, ScalarSrc full, int64_t n, const
     return CUDAMAT_OK;
 }
 
-// alpha = rho/(rw.v); r -= alpha v; x += alpha pw; ||r||^2     pbicgstab.cu:106-111
+// alpha = rho/(rw.v); r -= alpha v; ||r||^2     pbicgstab.cu:106-111
+// The reference's x += alpha pw (:110) is carried out by k_full of the same iteration (same operation on the same
+// operands, in the reference's order; an exit at the half step applies it on the way out, loops.hip): x is read and
+// written once per iteration, not twice, and this kernel moves 24 B per row.
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_half(LoopArgs la, ScalarSrc rv, int64_t n, double *r,
-                                                 const double *v, double *x, const double *pw,
-                                                 double *parts)
+                                                 const double *v, double *parts)
 {
     __shared__ double lds[8];
     LoopState *st = la.st;
@@ -1330,54 +1326,31 @@ __global__ __launch_bounds__(kBlock) void k_half(LoopArgs la, ScalarSrc rv, int6
     const double nalpha = -alpha;
     if (leader()) st->alpha = alpha;
     double acc[1] = {0.0};
-    if (x) {
-        CM_VEC_LOOP(n,
-            {
-                const double2 vv = ((const double2 *)v)[i];
-                const double2 pp = ((const double2 *)pw)[i];
-                double2 rr = ((double2 *)r)[i];
-                double2 xx = ((double2 *)x)[i];
-                rr.x = fma(nalpha, vv.x, rr.x); rr.y = fma(nalpha, vv.y, rr.y);   // :109
-                xx.x = fma(alpha, pp.x, xx.x);  xx.y = fma(alpha, pp.y, xx.y);    // :110
-                ((double2 *)r)[i] = rr; ((double2 *)x)[i] = xx;
-                acc[0] += rr.x * rr.x; acc[0] += rr.y * rr.y;                     // :111
-            },
-            {
-                const double rr = fma(nalpha, v[i], r[i]);
-                r[i] = rr;
-                x[i] = fma(alpha, pw[i], x[i]);
-                acc[0] += rr * rr;
-            })
-    } else {
-        // x == NULL: line :110 is carried out by k_full of this iteration (same operation on the same operands; an exit at
-        // the half step applies it on the way out, solver.hip) -- x is then read and written once per iteration, not twice
-        CM_VEC_LOOP(n,
-            {
-                const double2 vv = ((const double2 *)v)[i];
-                double2 rr = ((double2 *)r)[i];
-                rr.x = fma(nalpha, vv.x, rr.x); rr.y = fma(nalpha, vv.y, rr.y);   // :109
-                ((double2 *)r)[i] = rr;
-                acc[0] += rr.x * rr.x; acc[0] += rr.y * rr.y;                     // :111
-            },
-            {
-                const double rr = fma(nalpha, v[i], r[i]);
-                r[i] = rr;
-                acc[0] += rr * rr;
-            })
-    }
+    CM_VEC_LOOP(n,
+        {
+            const double2 vv = ((const double2 *)v)[i];
+            double2 rr = ((double2 *)r)[i];
+            rr.x = fma(nalpha, vv.x, rr.x); rr.y = fma(nalpha, vv.y, rr.y);   // :109
+            ((double2 *)r)[i] = rr;
+            acc[0] += rr.x * rr.x; acc[0] += rr.y * rr.y;                     // :111
+        },
+        {
+            const double rr = fma(nalpha, v[i], r[i]);
+            r[i] = rr;
+            acc[0] += rr * rr;
+        })
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) parts[blockIdx.x] = acc[0];
 }
 
-int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, const double *v,
-                double *x, const double *pw, double *parts, int *nparts)
+int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, const double *v, double *parts, int *nparts)
 {
     const int g = vec_grid(n);
     *nparts = g;
-    if (aligned16(r) && aligned16(v) && (!x || (aligned16(x) && aligned16(pw))))
-        hipLaunchKernelGGL(k_half<1>, dim3(g), dim3(kBlock), 0, s, la, rv, n, r, v, x, pw, parts);
+    if (aligned16(r) && aligned16(v))
+        hipLaunchKernelGGL(k_half<1>, dim3(g), dim3(kBlock), 0, s, la, rv, n, r, v, parts);
     else
-        hipLaunchKernelGGL(k_half<0>, dim3(g), dim3(kBlock), 0, s, la, rv, n, r, v, x, pw, parts);
+        hipLaunchKernelGGL(k_half<0>, dim3(g), dim3(kBlock), 0, s, la, rv, n, r, v, parts);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }

@@ -270,10 +270,10 @@ extern "C" int cudamat_solve_sharded(int ngpu, int n, int nnz, const double *A, 
     CM_ARG(precond != CUDAMAT_PRECOND_ILU0, "ILU(0) of the whole matrix does not shard: use CUDAMAT_PRECOND_BLOCK_ILU0");
     CM_ARG(ngpu <= n, "more ranks than rows");
     const double t0 = now_s();
-    const char *emu = getenv("CUDAMAT_SHARDED_ONE_DEVICE");
+    cudamat_plan_cache_clear();          // what cudamat_solve keeps on device 0 (several GB) is needed by the ranks
     Shared sh;
     sh.world = ngpu;
-    sh.emulate = emu && emu[0] == '1';
+    sh.emulate = cm::config_from_env().sharded_one_device != 0;
     if (!sh.emulate) {
         int have = 0;
         CM_TRY(cudamat_device_count(&have));

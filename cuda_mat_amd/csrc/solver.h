@@ -143,6 +143,23 @@ struct cudamat_solver {
 };
 
 namespace cm {
+// ---- solver.hip: what the loops (loops.hip) and the drop-in entry point (dropin.hip) use of the resident system
+int dev_alloc(void **p, size_t bytes);
+int ensure_work(cudamat_solver *s);                  // the seven work vectors (+ the gather buffer when sharded)
+int ensure_spmv_mode(cudamat_solver *s);             // choose the SpMV form (once per system / partition)
+int setup_agree(cudamat_solver *s, int rc_local);    // sharded: the ranks compare their set-up outcomes (collective)
+// y = (A + diag d) x with x a LOCAL n_pad-long work vector (pad zero); exchanges first when sharded; dot / check as SpmvArgs
+int spmv_local(cudamat_solver *s, const double *x_local, double *y, int dot, const double *w, double *parts, LoopArgs la, int check,
+               ScalarSrc half);
+int spmv_parts(const cudamat_solver *s);             // per-workgroup partial sums an SpMV launch leaves in `parts`
+int allreduce(cudamat_solver *s, double *buf, int count);
+void comm_mark_begin(cudamat_solver *s, int kind, hipStream_t st);
+void comm_mark_end(cudamat_solver *s, hipStream_t st);
+hipEvent_t prof_event(cudamat_solver *s, size_t i);
+// native: `in` is in L's level-major space and `out` leaves in U's (the loop that runs in those spaces); otherwise both are in
+// the caller's row numbering
+int precond_apply(cudamat_solver *s, const double *in, double *tmp, double *out, bool native = false);
+
 constexpr int kSortRowMax = 1024;     // longest row k_sort_rows stages (level-major index spaces need every row below it)
 int launch_sort_rows(hipStream_t st, int nrows, const int *src_rp, const int *src_of, const int *dst_rp, const int *ci,
                      const double *val, const int *colmap, int *out_ci, double *out_val);

@@ -1,4 +1,8 @@
-// solver.hip -- the BiCGSTAB driver: one host loop that only ENQUEUES work.
+// solver.hip -- the HBM-resident system behind cudamat_solver_*: creation, the choice of the SpMV form, the sharded
+// SpMV (exchange + multiply), the set-up agreement of the ranks.  The iteration loops live in loops.hip, the host-pointer
+// drop-in entry point in dropin.hip.
+//
+// The BiCGSTAB driver as a whole: one host loop that only ENQUEUES work.
 //
 // Reference behaviour restated (citations into /root/reference):
 //   CUDAMAT_LOOP_PBICGSTAB  = gpu_pbicgstab  pbicgstab.cu:45-154  (ILU(0) or M = I)
@@ -32,7 +36,9 @@ static double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static int dev_alloc(void **p, size_t bytes)
+namespace cm {
+
+int dev_alloc(void **p, size_t bytes)
 {
     *p = nullptr;
     hipError_t e = hipMalloc(p, bytes ? bytes : 16);
@@ -54,7 +60,7 @@ static void free_work(cudamat_solver *s)
     }
 }
 
-static int ensure_work(cudamat_solver *s)
+int ensure_work(cudamat_solver *s)
 {
     if (s->r) return CUDAMAT_OK;
     hipStream_t st = s->ctx->stream;
@@ -71,7 +77,7 @@ static int ensure_work(cudamat_solver *s)
     return CUDAMAT_OK;
 }
 
-static int ensure_spmv_mode(cudamat_solver *s);
+}  // namespace cm
 
 // ---- input validation (once, at creation): a malformed CSR must become an error code, never a stray access
 // flags[0]: row pointers not 0 = rp[0] <= rp[1] <= ... <= rp[n] = nnz;  flags[1]: a column id outside [0, n_cols);
@@ -129,7 +135,7 @@ static int validate_csr(cudamat_solver *s)
     return CUDAMAT_OK;
 }
 
-static int ensure_valdict(cudamat_solver *s);
+namespace cm { static int ensure_valdict(cudamat_solver *s); }
 
 extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz,
                                      const int *rowptr, const int *colidx, const double *val,
@@ -183,7 +189,7 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
         cudamat_solver_destroy(s);
         return rc;
     }
-    const bool verbose = getenv("CUDAMAT_VERBOSE") != nullptr;
+    const bool verbose = ctx->cfg.verbose != 0;
     double t_mark = now_s();
     auto stamp = [&](const char *what) {
         if (!verbose) return;
@@ -197,13 +203,13 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
         return rcv;
     }
     stamp("validation");
-    s->plan = plan_spmv(n_local, nnz);
-    if (int rc2 = plan_spmv_refine(st, n_local, nnz, s->rp, 0, &s->plan)) {
+    s->plan = plan_spmv(ctx->cfg, n_local, nnz);
+    if (int rc2 = plan_spmv_refine(st, ctx->cfg, n_local, nnz, s->rp, 0, &s->plan)) {
         cudamat_solver_destroy(s);
         return rc2;
     }
     stamp("CSR launch plan (refine)");
-    if (int rc3 = plan_spmv_compress(st, n_local, nnz, s->rp, s->ci, &s->plan)) {
+    if (int rc3 = plan_spmv_compress(st, ctx->cfg, n_local, nnz, s->rp, s->ci, &s->plan)) {
         cudamat_solver_destroy(s);
         return rc3;
     }
@@ -220,7 +226,7 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
             }
         }
         if (!s->plan.d_pbase) {     // fp64 values: line-aligned copies of the two entry streams
-            if (int rc6 = plan_spmv_align(st, n_local, nnz, s->rp, s->val, &s->plan)) {
+            if (int rc6 = plan_spmv_align(st, ctx->cfg, n_local, nnz, s->rp, s->val, &s->plan)) {
                 cudamat_solver_destroy(s);
                 return rc6;
             }
@@ -290,8 +296,7 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     s->windowed = false;
     s->windows_known = false;
     if (s->need_dev) { hipFree(s->need_dev); s->need_dev = nullptr; }
-    const char *force = getenv("CUDAMAT_FORCE_SHARDED");
-    const bool forced = comm && comm->world == 1 && force && force[0] == '1';
+    const bool forced = comm && comm->world == 1 && s->ctx->cfg.force_sharded;
     if (!comm || (comm->world <= 1 && !forced)) {
         s->sharded = false;
         s->n_pad = s->n;
@@ -321,12 +326,11 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
             CM_HIP(hipStreamCreateWithFlags(&s->part_stream[c], hipStreamNonBlocking));
         }
     }
-    if (const char *ch = getenv("CUDAMAT_OVERLAP_CHUNKS")) {
-        const int v = atoi(ch);
-        if (v >= 1 && v <= kPbMaxChunks) s->overlap_chunks = v;
-    }
+    if (s->ctx->cfg.overlap_chunks >= 1 && s->ctx->cfg.overlap_chunks <= kPbMaxChunks) s->overlap_chunks = s->ctx->cfg.overlap_chunks;
     return CUDAMAT_OK;
 }
+
+namespace cm {
 
 // profiling of the exchanges: one (start, stop) pair per call, pooled per solver
 static hipEvent_t comm_event(cudamat_solver *s)
@@ -338,21 +342,21 @@ static hipEvent_t comm_event(cudamat_solver *s)
     }
     return s->comm_ev[s->comm_used++];
 }
-static void comm_mark_begin(cudamat_solver *s, int kind, hipStream_t st)
+void comm_mark_begin(cudamat_solver *s, int kind, hipStream_t st)
 {
     if (!s->profiling) return;
     s->comm_kind.push_back(kind);
     hipEventRecord(comm_event(s), st);
 }
-static void comm_mark_end(cudamat_solver *s, hipStream_t st)
+void comm_mark_end(cudamat_solver *s, hipStream_t st)
 {
     if (s->profiling) hipEventRecord(comm_event(s), st);
 }
 
 // y = (A + diag d) x with x a LOCAL n_pad-long work vector (pad zero); gathers first
 // when sharded.  dot/check as in SpmvArgs.
-static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int dot, const double *w,
-                      double *parts, LoopArgs la, int check, ScalarSrc half)
+int spmv_local(cudamat_solver *s, const double *x_local, double *y, int dot, const double *w,
+               double *parts, LoopArgs la, int check, ScalarSrc half)
 {
     Range range_spmv(s->sharded ? "cudamat: SpMV + exchange of its input" : "cudamat: SpMV");
     const double *xfull = x_local;
@@ -396,6 +400,7 @@ static int spmv_local(cudamat_solver *s, const double *x_local, double *y, int d
     a.loop = la;
     a.check = check;
     a.half = half;
+    a.pb_strict = s->ctx->cfg.pb_strict;
     if (overlapped) {
         // The gather in pieces on the communicator's stream, phase 1 piece by piece behind it:
         //   comm stream  :  [wait x ready] piece 0 | piece 1 | ...
@@ -451,11 +456,11 @@ static int ensure_valdict(cudamat_solver *s)
     if (s->vd_tried) return CUDAMAT_OK;
     s->vd_tried = true;
     if (s->nnz < (1 << 20)) return CUDAMAT_OK;
-    return valdict_build(s->ctx->stream, s->nnz, s->val, &s->vd);
+    return valdict_build(s->ctx->stream, s->ctx->cfg, s->nnz, s->val, &s->vd);
 }
 
 // number of per-workgroup partial sums an SpMV launch leaves in `parts`
-static int spmv_parts(const cudamat_solver *s)
+int spmv_parts(const cudamat_solver *s)
 {
     if (s->perm_active) return s->pb_perm.NRB;
     return s->spmv_mode == 1 ? s->pb.NRB : s->spmv_mode == 2 ? s->sell.grid : plan_spmv_parts(s->plan);
@@ -505,7 +510,7 @@ static int col_span_bytes(cudamat_solver *s, double *out)
 // or timing anything (a sharded solver still times the blocked form alone: ms_spmv_alone feeds the exposed-gather
 // figure).  CUDAMAT_SPMV_TUNE=full restores the timing of every candidate.
 static int ensure_spmv_mode_inner(cudamat_solver *s);
-static int ensure_spmv_mode(cudamat_solver *s)
+int ensure_spmv_mode(cudamat_solver *s)
 {
     if (s->spmv_mode >= 0) return CUDAMAT_OK;
     Range range_mode("cudamat: SpMV form (matrix copies, tuning)");
@@ -513,7 +518,7 @@ static int ensure_spmv_mode(cudamat_solver *s)
     const int rc = ensure_spmv_mode_inner(s);
     hipStreamSynchronize(s->ctx->stream);
     s->t_spmv_setup = now_s() - t0;
-    if (getenv("CUDAMAT_VERBOSE"))
+    if (s->ctx->cfg.verbose)
         fprintf(stderr, "[cudamat] SpMV form %d chosen in %.3f ms (blocked copy %.3f ms, timing %.3f ms)\n", s->spmv_mode,
                 s->t_spmv_setup * 1e3, s->pb.build_seconds * 1e3, s->t_spmv_timing * 1e3);
     return rc;
@@ -522,10 +527,10 @@ static int ensure_spmv_mode(cudamat_solver *s)
 static int ensure_spmv_mode_inner(cudamat_solver *s)
 {
     hipStream_t st = s->ctx->stream;
-    const char *env = getenv("CUDAMAT_SPMV_MODE");
-    const bool force_csr = env && !strcmp(env, "csr");
-    const bool force_pb = env && !strcmp(env, "pb");
-    const bool force_sell = env && !strcmp(env, "sell");
+    const Config &cfg = s->ctx->cfg;
+    const bool force_csr = cfg.spmv_mode == 0;
+    const bool force_pb = cfg.spmv_mode == 1;
+    const bool force_sell = cfg.spmv_mode == 2;
     s->spmv_mode = 0;
     if (force_csr || s->n == 0 || s->nnz == 0) return CUDAMAT_OK;
     bool have[3] = {true, false, false};
@@ -544,7 +549,7 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
                 cols.chunks = can_overlap ? s->overlap_chunks : 1;
             }
             CM_TRY(ensure_valdict(s));
-            const int rc = pb_build(st, s->n, s->n_cols, s->nnz, s->rp, s->ci, s->val, &s->pb, &cols, &s->vd);
+            const int rc = pb_build(st, cfg, s->n, s->n_cols, s->nnz, s->rp, s->ci, s->val, &s->pb, &cols, &s->vd);
             if (rc != CUDAMAT_OK && force_pb) return rc;
             have[1] = rc == CUDAMAT_OK;          // e.g. out of memory for the blocked copy: keep the others
         }
@@ -554,8 +559,7 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
     // scattered columns: the gather-based forms cannot win (see above)
     bool scattered = false;
     {
-        const char *tune = getenv("CUDAMAT_SPMV_TUNE");
-        if (have[1] && !force_pb && !force_sell && !(tune && !strcmp(tune, "full")) && s->nnz >= 8 * (int64_t)s->n) {
+        if (have[1] && !force_pb && !force_sell && !cfg.spmv_tune_full && s->nnz >= 8 * (int64_t)s->n) {
             CM_TRY(col_span_bytes(s, &s->col_span_bytes));
             scattered = s->col_span_bytes >= 16.0 * 1024 * 1024;
         }
@@ -563,7 +567,7 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
             have[0] = false;
             if (!s->sharded) {
                 s->spmv_mode = 1;
-                if (getenv("CUDAMAT_VERBOSE"))
+                if (cfg.verbose)
                     fprintf(stderr, "cudamat: SpMV: a row's columns span %.1f MB of x on average -> blocked, nothing timed\n", s->col_span_bytes / 1048576.0);
                 return CUDAMAT_OK;
             }
@@ -573,8 +577,7 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
     // faster there: C3 0.174 vs 0.191 ms) whose padded copy stays below 1.5 x the entries.  Measured on 2e6-row banded
     // matrices (scripts/sell_probe.py): row lengths 14..70 0.46 ms vs 0.94 (CSR forms) / 0.66 (blocked); 13..20 0.18
     // vs 0.40 / 0.26; with scattered columns the blocked form wins (0.48 vs 1.07) -- hence: time them.
-    const char *se = getenv("CUDAMAT_SPMV_SELL");
-    const bool sell_off = se && se[0] == '0';
+    const bool sell_off = !cfg.spmv_sell;
     if (force_sell || (!force_pb && !scattered && !sell_off && s->n >= 4096 && s->nnz >= (1 << 16) && s->plan.stream_rows == 0 && s->nnz >= 8 * (int64_t)s->n)) {
         const int rc = sell_build(st, s->n, s->nnz, s->rp, s->ci, s->val, &s->sell, force_sell ? 0.0 : 1.5);
         if (rc != CUDAMAT_OK && force_sell) return rc;
@@ -598,6 +601,7 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
         SpmvArgs a{};
         a.n = s->n; a.rp = s->rp; a.ci = s->ci; a.val = s->val; a.x = xin; a.d = nullptr; a.xd = s->p;
         a.alpha = 1.0; a.beta = 0.0; a.y = s->v; a.dot = 0; a.loop = la_none; a.check = CHECK_NONE; a.half = nosrc;
+        a.pb_strict = cfg.pb_strict;
         for (int rep = 0; rep < 3 && rc == CUDAMAT_OK; rep++) {
             if (rep == 1) hipEventRecord(e0, st);
             rc = mode == 1 ? launch_spmv_pb(st, s->pb, a) : mode == 2 ? launch_spmv_sell(st, s->sell, a) : launch_spmv(st, s->plan, a);
@@ -622,24 +626,21 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
     const double sell_fill = s->sell.fill;
     if (best != 1) pb_free(&s->pb);
     if (best != 2) sell_free(&s->sell);
-    if (getenv("CUDAMAT_VERBOSE"))
+    if (cfg.verbose)
         fprintf(stderr, "cudamat: SpMV auto-tune csr %.3f ms, blocked %s%.3f ms, sell %s%.3f ms (fill %.2f) -> %s\n", s->ms_csr,
                 have[1] ? "" : "(n/a) ", s->ms_pb, have[2] ? "" : "(n/a) ", s->ms_sell, sell_fill,
                 best == 1 ? "blocked" : best == 2 ? "sell" : "csr");
     return CUDAMAT_OK;
 }
 
-static int allreduce(cudamat_solver *s, double *buf, int count)
+int allreduce(cudamat_solver *s, double *buf, int count)
 {
     Range range_ar("cudamat: all-reduce");
-    // fault injection for the tests of the failure paths: CUDAMAT_TEST_COMM_FAIL="rank:k" makes the k-th all-reduce
+    // fault injection for the tests of the failure paths: the option TEST_COMM_FAIL = "rank:k" makes the k-th all-reduce
     // of that rank's solver report an error (tests/test_gpu_dist.py: a failing rank must not strand its peers)
-    if (const char *inj = getenv("CUDAMAT_TEST_COMM_FAIL")) {
-        int r = -1, k = -1;
-        if (sscanf(inj, "%d:%d", &r, &k) == 2 && r == s->comm.rank && ++s->test_allreduces == k) {
-            set_error("injected all-reduce failure (CUDAMAT_TEST_COMM_FAIL=%s)", inj);
-            return CUDAMAT_ERR_COMM;
-        }
+    if (s->ctx->cfg.fail_rank >= 0 && s->ctx->cfg.fail_rank == s->comm.rank && ++s->test_allreduces == s->ctx->cfg.fail_call) {
+        set_error("injected all-reduce failure (TEST_COMM_FAIL=%d:%d)", s->ctx->cfg.fail_rank, s->ctx->cfg.fail_call);
+        return CUDAMAT_ERR_COMM;
     }
     comm_mark_begin(s, 3, s->ctx->stream);
     if (s->comm.allreduce(s->comm.user, buf, count) != 0) {
@@ -746,10 +747,9 @@ static int compute_windows(cudamat_solver *s)
         if (p == me) s->gather_fraction = frac;
         worst = frac > worst ? frac : worst;
     }
-    const char *env = getenv("CUDAMAT_WINDOWED");
-    s->windowed = worst <= 0.5 && !(env && env[0] == '0');
+    s->windowed = worst <= 0.5 && s->ctx->cfg.windowed;
     if (!s->windowed) s->gather_fraction = 1.0;
-    if (getenv("CUDAMAT_VERBOSE"))
+    if (s->ctx->cfg.verbose)
         fprintf(stderr, "cudamat: rank %d references %.4f of the other slices (worst rank %.4f) -> %s\n", me,
                 s->windowed ? s->gather_fraction : worst, worst, s->windowed ? "windowed gather" : "whole gather");
     return CUDAMAT_OK;
@@ -759,7 +759,7 @@ static int compute_windows(cudamat_solver *s)
 // data path -- a rank whose blocked copy, ILU(0) or allocation failed makes every rank return an error (instead of
 // leaving its peers inside a collective for ever), and the gather is overlapped only if every rank runs the
 // blocked SpMV (the pieces are exchanged by a different call sequence than the plain all-gather).
-static int setup_agree(cudamat_solver *s, int rc_local)
+int setup_agree(cudamat_solver *s, int rc_local)
 {
     if (!s->sharded) return rc_local;
     char saved[512];
@@ -774,9 +774,8 @@ static int setup_agree(cudamat_solver *s, int rc_local)
     CM_TRY(allreduce(s, s->red + 10, 2));
     CM_HIP(hipMemcpyAsync(h, s->red + 10, sizeof(h), hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
-    const char *ov = getenv("CUDAMAT_OVERLAP");
     s->overlap = s->comm.world > 1 && s->comm.gather_part && s->comm.comm_stream && s->ev_x && s->pb.chunks >= 1 &&
-                 h[1] == (double)s->comm.world && !(ov && ov[0] == '0');
+                 h[1] == (double)s->comm.world && s->ctx->cfg.overlap;
     s->agreed = true;
     if (h[0] == 0.0 && !s->windows_known) CM_TRY(compute_windows(s));       // collective: same call on every rank
     if (h[0] != 0.0) {
@@ -786,6 +785,8 @@ static int setup_agree(cudamat_solver *s, int rc_local)
     }
     return CUDAMAT_OK;
 }
+
+}  // namespace cm
 
 extern "C" int cudamat_solver_spmv_mode(cudamat_solver *s, int *mode)
 {
@@ -845,7 +846,9 @@ extern "C" int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, dou
                       CHECK_NONE, ScalarSrc{nullptr, 0, 1});
 }
 
-static hipEvent_t prof_event(cudamat_solver *s, size_t i)
+namespace cm {
+
+hipEvent_t prof_event(cudamat_solver *s, size_t i)
 {
     while (s->prof_ev.size() <= i) {
         hipEvent_t e;
@@ -857,13 +860,15 @@ static hipEvent_t prof_event(cudamat_solver *s, size_t i)
 
 // native: `in` is in L's level-major space and `out` leaves in U's (the loop that runs in those spaces); otherwise both
 // are in the caller's row numbering (level-major factors then permute on the way in and out)
-static int precond_apply(cudamat_solver *s, const double *in, double *tmp, double *out, bool native = false)
+int precond_apply(cudamat_solver *s, const double *in, double *tmp, double *out, bool native)
 {
     if (s->L.lm && !native) return precond_apply_original(s, in, tmp, out);
     CM_TRY(trsv_apply(s, s->L, false, in, tmp));    // pbicgstab.cu:92-94 / :121-123
     CM_TRY(trsv_apply(s, s->U, true, tmp, out));    // pbicgstab.cu:96-98 / :125-127
     return CUDAMAT_OK;
 }
+
+}  // namespace cm
 
 extern "C" int cudamat_solver_precond_apply(cudamat_solver *s, const double *in, double *out)
 {
@@ -874,830 +879,3 @@ extern "C" int cudamat_solver_precond_apply(cudamat_solver *s, const double *in,
     return precond_apply(s, in, s->t, out);
 }
 
-static int solve_once(cudamat_solver *s, const double *b, double *x, int precond, int loop, int maxit, double tol,
-                      int flags, cudamat_stats *out, bool *precond_gave_up, bool *resident_gave_up, double abs_tol)
-{
-    CM_ARG(s && b && x, "null pointer");
-    CM_ARG(precond == CUDAMAT_PRECOND_NONE || precond == CUDAMAT_PRECOND_ILU0 || precond == CUDAMAT_PRECOND_BLOCK_ILU0,
-           "precond");
-    CM_ARG(loop == CUDAMAT_LOOP_PBICGSTAB || loop == CUDAMAT_LOOP_PBICGSTAB2 || loop == CUDAMAT_LOOP_PIPELINED, "loop");
-    CM_ARG(maxit >= 0, "maxit");
-    CM_ARG(!(precond == CUDAMAT_PRECOND_ILU0 && s->sharded),
-           "ILU(0) of the whole matrix is single-GPU only (SURVEY 8e); sharded runs take CUDAMAT_PRECOND_BLOCK_ILU0");
-    CM_ARG(!(precond && s->d), "the (A0 + I d) variant has no preconditioner (pbicgstab.h:110)");
-    CM_HIP(hipSetDevice(s->ctx->device));
-    const double t_begin = now_s();
-    hipStream_t st = s->ctx->stream;
-    {
-        int rc_setup = ensure_work(s);
-        if (rc_setup == CUDAMAT_OK) rc_setup = ensure_spmv_mode(s);
-        if (rc_setup == CUDAMAT_OK && precond && (!s->has_ilu || (s->sharded && !s->ilu_block)))
-            rc_setup = ilu0_setup(s, precond == CUDAMAT_PRECOND_BLOCK_ILU0);
-        CM_TRY(setup_agree(s, rc_setup));        // sharded: every rank learns of a failure on any rank
-    }
-    // The loop in LEVEL-MAJOR SPACES (round 3).  With the hybrid triangular solves the factors live in level-major index
-    // spaces: L reads and writes streams in L's order, U writes a stream in U's order.  The reference loop
-    // (pbicgstab.cu:45-154) only ever combines vectors element by element within two families -- r, rw, p, v, t
-    // (residual side: outputs of A, inputs of L) and M^-1 p, M^-1 r, x (solution side: outputs of U, inputs of A) -- so
-    // the first family is kept in L's order, the second in U's, and A is stored with rows in L's order and columns in
-    // U's positions (ilu_perm_matrix).  Then no vector is permuted inside the loop: per M^-1 application the only indexed
-    // access left besides the near gathers is U reading its right-hand side from L's space (1 per row instead of 4).
-    // b and x0 are permuted on the way in, x on the way out.  One GPU, reference loop; CUDAMAT_TRSV_PERM=0 disables.
-    bool perm = false;
-    {
-        const char *pe = getenv("CUDAMAT_TRSV_PERM");
-        perm = precond == CUDAMAT_PRECOND_ILU0 && !s->sharded && loop == CUDAMAT_LOOP_PBICGSTAB && s->L.lm && s->U.lm && !s->d &&
-               !(pe && pe[0] == '0');
-        if (perm && s->perm_failed) perm = false;
-        if (perm && !s->perm_ready) {
-            const int rcp = ilu_perm_matrix(s);
-            if (rcp == CUDAMAT_ERR_NOMEM) { perm = false; s->perm_failed = true; }    // no room for the second blocked copy: permute per
-            else CM_TRY(rcp);                                                        // application, and do not try again on every solve
-        }
-    }
-    s->perm_active = perm;
-    struct PermOff { cudamat_solver *s; ~PermOff() { s->perm_active = false; } } perm_off{s};
-    double *const x_user = x;
-    if (perm) {
-        CM_TRY(perm_to_space(s, false, b, s->b_perm));
-        if (!(flags & CUDAMAT_FLAG_X0_ONES)) CM_TRY(perm_to_space(s, true, x, s->x_perm));
-        b = s->b_perm;
-        x = s->x_perm;
-    }
-
-    // residual history: two entries per iteration (half / full step) or one; capped at 2^20 entries (8 MB) -- a solve
-    // with a larger maxit keeps the first 2^20 (the kernels check the capacity)
-    const long long want_hist = (long long)(loop != CUDAMAT_LOOP_PBICGSTAB2 ? 2 : 1) * (maxit > 0 ? maxit : 1);
-    const int need_hist = (int)(want_hist < (1LL << 20) ? want_hist : (1LL << 20));
-    // a restart segment (abs_tol > 0) appends to the history of the segments before it (the kernels check the capacity)
-    const int hist_base = abs_tol > 0.0 ? (s->hist_count < s->hist_cap ? s->hist_count : s->hist_cap) : 0;
-    if (hist_base == 0 && need_hist > s->hist_cap) {
-        if (s->hist) { CM_HIP(hipStreamSynchronize(st)); hipFree(s->hist); s->hist = nullptr; }
-        CM_TRY(dev_alloc((void **)&s->hist, sizeof(double) * (size_t)need_hist));
-        s->hist_cap = need_hist;
-    }
-    if (s->hist_cap > hist_base)
-        CM_HIP(hipMemsetAsync(s->hist + hist_base, 0xFF, sizeof(double) * (size_t)(s->hist_cap - hist_base), st));  // NaN fill
-    s->last_loop = loop;
-    const bool profile = (flags & CUDAMAT_FLAG_PROFILE) != 0;
-    const bool sharded = s->sharded;
-    const int n = s->n;
-    LoopArgs la{s->st, s->hist + hist_base, s->hist_cap - hist_base, loop, (flags & CUDAMAT_FLAG_NO_EXIT) ? 1 : 0, s->snap_dev, kRing, 0};
-    for (int i = 0; i < kRing; i++) s->snap_host[i] = 0ULL;
-    const LoopArgs la_none{nullptr, nullptr, 0, 0, 0};
-    const ScalarSrc nosrc{nullptr, 0, 1};
-    size_t pe = 0;   // profiling events used
-
-    s->comm_used = 0;
-    s->comm_kind.clear();
-    s->profiling = profile && sharded;
-    struct ProfilingOff { cudamat_solver *s; ~ProfilingOff() { s->profiling = false; } } profiling_off{s};
-    Range range_loop("cudamat: iteration loop (enqueue + lagged checks)");
-    const double t_loop0 = now_s();
-    if (flags & CUDAMAT_FLAG_X0_ONES) CM_TRY(launch_fill(st, n, 1.0, x));
-    // r = A x0 (pbicgstab.cu:67 / :645-646); x may be a caller buffer without pad
-    CM_HIP(hipMemcpyAsync(s->pw, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
-    CM_TRY(spmv_local(s, s->pw, s->r, 0, nullptr, nullptr, la_none, CHECK_NONE, nosrc));
-    int np_full = 0, np_half = 0;
-    // reference loop in its five-launch form: the half step's x += alpha pw (pbicgstab.cu:110) is carried out by k_full of the
-    // same iteration (CUDAMAT_DEFER_X=0: by k_half, as the reference orders it) -- same operations on the same operands
-    const bool defer_x = [] { const char *e = getenv("CUDAMAT_DEFER_X"); return !(e && e[0] == '0'); }();
-    const double *pw_last = nullptr;
-    CM_TRY(launch_init(st, n, b, s->r, s->rw, s->p, s->parts_full, &np_full));   // :69-74
-    ScalarSrc full_src{s->parts_full, np_full, 2};
-    if (sharded) {
-        CM_TRY(launch_reduce_parts(st, full_src, 2, s->red + 4, 0));
-        CM_TRY(allreduce(s, s->red + 4, 2));
-        full_src = ScalarSrc{s->red + 4, 0, 1};
-    }
-    CM_TRY(launch_init_finish(st, s->st, full_src, tol, abs_tol));
-
-    // Pipelined BiCGStab (kernels.hip): extra vectors, w0 = A rh0 (with rw.w0), t0 = A wh0, and the seed
-    // [rw.r0, rw.w0, 0, 0, r0.r0] of the first k_pipe_a.  A reduction phase = the per-workgroup partials of a
-    // kernel summed (and, sharded, all-reduced) into red_pipe: on the communicator's reduce stream when it has one,
-    // so that it runs beside the SpMV that follows the kernel.
-    // With a preconditioner (ILU(0), or block-Jacobi ILU(0) when sharded: SURVEY 8 f4) the hatted vectors M^-1 r,
-    // M^-1 w, M^-1 s, M^-1 z, M^-1 q are carried too and M^-1 is applied in front of each SpMV, where
-    // pbicgstab.cu:92-98,121-127 apply it.
-    const bool pipelined = loop == CUDAMAT_LOOP_PIPELINED;
-    const bool pipe_pc = pipelined && precond != CUDAMAT_PRECOND_NONE;
-    // residual replacement period (Cools & Vanroose): every rr-th iteration r, w, s, z (and their hatted forms, and v)
-    // are recomputed from x and p, which discards the rounding errors the recurrences have accumulated
-    int pipe_rr = kPipeRR;
-    if (const char *e = getenv("CUDAMAT_PIPE_RR")) pipe_rr = atoi(e);
-    ScalarSrc pipeB_src{nullptr, 0, 1};
-    hipStream_t rst = nullptr;
-    if (pipelined) {
-        const size_t nb = sizeof(double) * (size_t)(s->n_pad > 0 ? s->n_pad : 1);
-        if (!s->pz) {
-            double **vs[] = {&s->pz, &s->pww, &s->pq, &s->py, &s->pxh};
-            for (double **q : vs) {
-                CM_TRY(dev_alloc((void **)q, nb));
-                CM_HIP(hipMemsetAsync(*q, 0, nb, st));
-            }
-            CM_TRY(dev_alloc((void **)&s->pipeA, sizeof(double) * 3 * kVecGridMax));
-            CM_TRY(dev_alloc((void **)&s->pipeB, sizeof(double) * 5 * kVecGridMax));
-            CM_TRY(dev_alloc((void **)&s->red_pipe, sizeof(double) * 16));
-        }
-        if (pipe_pc && !s->prh) {
-            double **vs[] = {&s->prh, &s->pwh, &s->psh, &s->pzh, &s->pqh, &s->ptmp};
-            for (double **q : vs) {
-                CM_TRY(dev_alloc((void **)q, nb));
-                CM_HIP(hipMemsetAsync(*q, 0, nb, st));
-            }
-        }
-        if (sharded && s->comm.allreduce_side && s->comm.reduce_stream) {
-            rst = (hipStream_t)s->comm.reduce_stream;
-            for (int e = 0; e < 2; e++) {
-                if (!s->ev_red[e]) CM_HIP(hipEventCreateWithFlags(&s->ev_red[e], hipEventDisableTiming));
-                if (!s->ev_red_done[e]) CM_HIP(hipEventCreateWithFlags(&s->ev_red_done[e], hipEventDisableTiming));
-            }
-        }
-        const LoopArgs la_freeze{s->st, nullptr, 0, loop, 0};      // (returns at once when the initial guess already passes: restarts)
-        const double *rh0 = s->r;
-        if (pipe_pc) { CM_TRY(precond_apply(s, s->r, s->ptmp, s->prh)); rh0 = s->prh; }              // rh0 = M^-1 r0
-        CM_TRY(spmv_local(s, rh0, s->pww, 1, s->rw, s->parts_rv, la_freeze, CHECK_NONE, nosrc));      // w0 = A rh0, rw.w0
-        ScalarSrc rww{s->parts_rv, spmv_parts(s), 2};
-        if (sharded) {
-            CM_TRY(launch_reduce_parts(st, rww, 1, s->red + 0, 0));
-            CM_TRY(allreduce(s, s->red + 0, 1));
-            rww = ScalarSrc{s->red + 0, 0, 1};
-        }
-        const double *wh0 = s->pww;
-        if (pipe_pc) { CM_TRY(precond_apply(s, s->pww, s->ptmp, s->pwh)); wh0 = s->pwh; }            // wh0 = M^-1 w0
-        CM_TRY(spmv_local(s, wh0, s->t, 0, nullptr, nullptr, la_freeze, CHECK_NONE, nosrc));          // t0 = A wh0
-        CM_TRY(launch_pipe_seed(st, full_src, rww, s->red_pipe + 8));
-        pipeB_src = ScalarSrc{s->red_pipe + 8, 0, 1};
-    }
-    // one reduction phase of the pipelined loop: partials -> K sums in `out` (all-reduced when sharded); returns
-    // the source the consumer kernel reads.  With a reduce stream the work is queued there, behind `slot`'s event.
-    auto pipe_reduce = [&](ScalarSrc parts, int K, double *out, int slot) -> int {
-        if (!sharded) return CUDAMAT_OK;                     // the consumer sums the partials itself
-        if (rst) {
-            CM_HIP(hipEventRecord(s->ev_red[slot], st));
-            CM_HIP(hipStreamWaitEvent(rst, s->ev_red[slot], 0));
-            CM_TRY(launch_reduce_parts(rst, parts, K, out, 0));
-            comm_mark_begin(s, 3, rst);
-            if (s->comm.allreduce_side(s->comm.user, out, K) != 0) { set_error("allreduce_side callback failed"); return CUDAMAT_ERR_COMM; }
-            comm_mark_end(s, rst);
-            CM_HIP(hipEventRecord(s->ev_red_done[slot], rst));
-        } else {
-            CM_TRY(launch_reduce_parts(st, parts, K, out, 0));
-            CM_TRY(allreduce(s, out, K));
-        }
-        return CUDAMAT_OK;
-    };
-    auto pipe_wait = [&](int slot) -> int {
-        if (sharded && rst) CM_HIP(hipStreamWaitEvent(st, s->ev_red_done[slot], 0));
-        return CUDAMAT_OK;
-    };
-    int np_a = 0, np_b = 0;
-
-    // Small systems (vectors resident in L2): three launches per iteration instead of five -- the vector updates
-    // in front of the two SpMVs are folded into them (kernels.hip, "fused loop"); p, v and r are double-buffered.
-    bool fused = false;
-    {
-        // Measured (bench.py, one MI355X): 5-point stencil rows 38.5 -> 46.3 k it/s at 1e4 rows, 37.7 -> 43.8 k at 4e4,
-        // 30.4 -> 32.1 k at 1.6e5, even at 4.9e5, slower beyond; with 50 entries per row the three gathers per entry
-        // cost more than the two launches save (29.9 -> 24.1 k it/s at 2e4 rows).  So: short rows (the stream-tile
-        // plan) up to 3e5 rows.  CUDAMAT_FUSED=0 disables, CUDAMAT_FUSED=N forces it for every supported plan up to N rows.
-        const char *fe = getenv("CUDAMAT_FUSED");
-        const bool forced = fe && fe[0] != '\0';
-        const long long max_rows = forced ? atoll(fe) : 300000;
-        fused = loop != CUDAMAT_LOOP_PIPELINED && !sharded && !precond && s->spmv_mode == 0 && fused_spmv_supported(s->plan) && n > 0 && n <= max_rows &&
-                (forced || s->plan.stream_rows > 0);
-        if (fused && !s->v2) {
-            const size_t nb = sizeof(double) * (size_t)(s->n_pad > 0 ? s->n_pad : 1);
-            CM_TRY(dev_alloc((void **)&s->v2, nb));
-            CM_HIP(hipMemsetAsync(s->v2, 0, nb, st));
-        }
-    }
-    double *p_a = s->p, *p_b = s->pw, *v_a = s->v, *v_b = s->v2;
-
-    // Very small systems (one stream tile per workgroup, at most one workgroup per compute unit): the whole loop in ONE
-    // launch, grid barriers instead of launch boundaries (kernels.hip, "resident loop").  CUDAMAT_RESIDENT=0 disables.
-    *resident_gave_up = false;
-    int loop_form = fused ? 1 : 0;
-    bool resident = false;
-    {
-        const char *re = getenv("CUDAMAT_RESIDENT");
-        resident = fused && !profile && !s->resident_off && !(re && re[0] == '0') && resident_loop_supported(s->plan, n);
-        if (resident) {      // all workgroups must be resident at once: at most one per two compute units of THIS device
-            if (s->device_cus == 0 &&
-                hipDeviceGetAttribute(&s->device_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device) != hipSuccess)
-                s->device_cus = -1;
-            resident = s->device_cus > 0 && 2 * s->plan.grid <= s->device_cus;
-        }
-    }
-    if (resident) {
-        loop_form = 2;
-        if (!s->bar) CM_TRY(dev_alloc((void **)&s->bar, 2 * sizeof(unsigned)));
-        SpmvArgs a{};
-        a.n = n; a.rp = s->rp; a.ci = s->ci; a.val = s->val; a.x = nullptr; a.d = s->d; a.xd = nullptr;
-        a.alpha = 1.0; a.beta = 0.0; a.check = CHECK_NONE; a.half = nosrc;
-        a.loop = la;
-        a.loop.snap = nullptr;               // no per-iteration progress words: the host waits for the launch
-        int done = 0;
-        while (done < maxit) {
-            const int c = maxit - done < 8192 ? maxit - done : 8192;      // ~0.1 s of iterations per launch
-            CM_HIP(hipMemsetAsync(s->bar, 0, 2 * sizeof(unsigned), st));
-            ResidentArgs q{};
-            q.iters = c; q.first_count = done == 0 ? np_full : s->plan.grid; q.bar = s->bar;
-            q.spin_limit = 1u << 22;
-            if (const char *lim = getenv("CUDAMAT_RESIDENT_SPIN_LIMIT")) q.spin_limit = (unsigned)atoi(lim);
-            q.p_a = p_a; q.p_b = p_b; q.v_a = v_a; q.v_b = v_b; q.r = s->r; q.s = s->s; q.t = s->t; q.x = x; q.rw = s->rw;
-            q.parts_rv = s->parts_rv; q.parts_tt = s->parts_tt; q.parts_half = s->parts_half; q.parts_full = s->parts_full;
-            CM_TRY(launch_resident_loop(st, s->plan, a, q));
-            unsigned bar_host[2] = {0u, 0u};
-            CM_HIP(hipMemcpyAsync(&s->st_ring[0], s->st, sizeof(LoopState), hipMemcpyDeviceToHost, st));
-            CM_HIP(hipMemcpyAsync(bar_host, s->bar, sizeof(bar_host), hipMemcpyDeviceToHost, st));
-            CM_HIP(hipStreamSynchronize(st));
-            if (bar_host[1] != 0u) {         // a barrier wait ran into its bound: this attempt is void
-                *resident_gave_up = true;
-                *precond_gave_up = false;
-                return CUDAMAT_OK;
-            }
-            full_src = ScalarSrc{s->parts_full, s->plan.grid, 2};
-            if (s->st_ring[0].state != 0) break;
-            if (c & 1) {
-                std::swap(p_a, p_b);
-                std::swap(v_a, v_b);
-                std::swap(s->r, s->s);
-            }
-            done += c;
-        }
-    }
-
-    int k = 0;
-    for (; !resident && k < maxit; k++) {
-        if (k >= kLag) {   // lagged, deterministic look at the device state: the progress word of
-            const int j = k - kLag;   // iteration j, published by its k_full through pinned memory
-            volatile unsigned long long *slot = &s->snap_host[j % kRing];
-            unsigned long long w = *slot;
-            if ((unsigned)(w >> 32) != (unsigned)(j + 1)) {
-                const double t_wait = now_s();
-                while ((unsigned)((w = *slot) >> 32) != (unsigned)(j + 1)) {
-                    __builtin_ia32_pause();
-                    if (now_s() - t_wait > 30.0) {
-                        // give queued work a bounded chance to drain (a query, not a wait: the device may be wedged),
-                        // then fail the solve; in a sharded run the caller must exit so that its peers are torn down
-                        const double t_drain = now_s();
-                        while (hipStreamQuery(st) == hipErrorNotReady && now_s() - t_drain < 5.0) __builtin_ia32_pause();
-                        set_error("iteration %d did not report progress within 30 s%s", j,
-                                  sharded ? " (sharded run: this rank must exit, its peers are waiting in a collective)" : "");
-                        return CUDAMAT_ERR_HIP;
-                    }
-                }
-            }
-            if ((unsigned)(w & 0xffffffffULL) != 0u) break;
-        }
-        la.k = k;
-        if (pipelined) {
-            const PipeHatA hat_a = pipe_pc ? PipeHatA{s->prh, s->pwh, s->pzh, s->psh, s->pqh} : PipeHatA{nullptr, nullptr, nullptr, nullptr, nullptr};
-            const PipeHatB hat_b = pipe_pc ? PipeHatB{s->pqh, s->pwh, s->pzh, s->prh} : PipeHatB{nullptr, nullptr, nullptr, nullptr};
-            double *const rh = pipe_pc ? s->prh : s->r, *const wh = pipe_pc ? s->pwh : s->pww;
-            double *const sh = pipe_pc ? s->psh : s->s, *const zh = pipe_pc ? s->pzh : s->pz;
-            // full-step test of iteration k-1, beta, alpha, the recurrences; dots (q.y, y.y, q.q)
-            CM_TRY(launch_pipe_a(st, la, pipeB_src, n, s->r, s->pww, s->t, s->v, s->p, s->s, s->pz, s->pq, s->py, x, s->pxh,
-                                 s->pipeA, &np_a, hat_a));
-            ScalarSrc a_src{s->pipeA, np_a, 3};
-            CM_TRY(pipe_reduce(a_src, 3, s->red_pipe + 0, 0));
-            if (sharded) a_src = ScalarSrc{s->red_pipe + 0, 0, 1};
-            if (pipe_pc) {                                                                            // zh = M^-1 z   :92-98
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                CM_TRY(precond_apply(s, s->pz, s->ptmp, s->pzh));
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-            }
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(spmv_local(s, zh, s->v, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));              // v = A zh
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(pipe_wait(0));
-            // half-step test, omega, x, r, rh, w; dots (rw.r, rw.w, rw.s, rw.z, r.r); i++
-            CM_TRY(launch_pipe_b(st, la, a_src, n, s->pq, s->py, s->t, s->v, s->rw, s->s, s->pz, s->pxh, x, s->r, s->pww,
-                                 s->pipeB, &np_b, hat_b));
-            if (pipe_rr > 0 && (k + 1) % pipe_rr == 0) {
-                // Residual replacement.  q and y are free until the next k_pipe_a; pw is not used by this loop.  The
-                // kernels below return at once when the loop is frozen (`la`), the triangular solves do not look.
-                // (every kernel of this block returns at once when the loop is frozen, so r and the phase-B partials stay
-                // those of the returned iterate; the copy of x only fills the scratch vector pw)
-                CM_HIP(hipMemcpyAsync(s->pw, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
-                CM_TRY(spmv_local(s, s->pw, s->pq, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));      // q = A x
-                CM_TRY(launch_residual(st, la, n, b, s->pq, s->r));                                   // r = b - A x
-                if (pipe_pc) CM_TRY(precond_apply(s, s->r, s->ptmp, s->prh));                         // rh = M^-1 r
-                CM_TRY(spmv_local(s, rh, s->pww, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));        // w = A rh
-                CM_TRY(spmv_local(s, s->p, s->s, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));        // s = A ph
-                if (pipe_pc) CM_TRY(precond_apply(s, s->s, s->ptmp, s->psh));                         // sh = M^-1 s
-                CM_TRY(spmv_local(s, sh, s->pz, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));         // z = A sh
-                if (pipe_pc) CM_TRY(precond_apply(s, s->pz, s->ptmp, s->pzh));                        // zh = M^-1 z
-                CM_TRY(spmv_local(s, zh, s->v, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));          // v = A zh
-                CM_TRY(launch_pipe_dots(st, la, n, s->rw, s->r, s->pww, s->s, s->pz, s->pipeB, &np_b));
-            }
-            pipeB_src = ScalarSrc{s->pipeB, np_b, 5};
-            CM_TRY(pipe_reduce(pipeB_src, 5, s->red_pipe + 8, 1));
-            if (sharded) pipeB_src = ScalarSrc{s->red_pipe + 8, 0, 1};
-            if (pipe_pc) {                                                                            // wh = M^-1 w   :121-127
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                CM_TRY(precond_apply(s, s->pww, s->ptmp, s->pwh));
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-            }
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(spmv_local(s, wh, s->t, 0, nullptr, nullptr, la, CHECK_NONE, nosrc));              // t = A wh
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(pipe_wait(1));
-            continue;
-        }
-        if (fused) {
-            SpmvArgs a{};
-            a.n = n; a.rp = s->rp; a.ci = s->ci; a.val = s->val; a.x = nullptr; a.d = s->d; a.xd = nullptr;
-            a.alpha = 1.0; a.beta = 0.0; a.loop = la; a.check = CHECK_NONE; a.half = nosrc;
-            const int np = plan_spmv_parts(s->plan);
-            // rho, beta, full-step test, p' = r + beta (p - omega v), v' = A p', rw.v'            :80-89, :104-106
-            FuseArgs f1{};
-            f1.mode = 1; f1.r = s->r; f1.p_old = p_a; f1.v_old = v_a; f1.p_out = p_b; f1.src = full_src;
-            a.y = v_b; a.dot = 1; a.w = s->rw; a.parts = s->parts_rv;
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(launch_fused_spmv(st, s->plan, a, f1));
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            // alpha, s = r - alpha v', x += alpha p', t = A s, (t.s, t.t), ||s||^2                :107-111, :132-136
-            FuseArgs f2{};
-            f2.mode = 2; f2.r = s->r; f2.v = v_b; f2.s_out = s->s; f2.xsol = x; f2.p = p_b;
-            f2.src = ScalarSrc{s->parts_rv, np, 2}; f2.parts_half = s->parts_half;
-            a.y = s->t; a.dot = 2; a.w = nullptr; a.parts = s->parts_tt;
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(launch_fused_spmv(st, s->plan, a, f2));
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            // half-step test, omega, x += omega s, r = s - omega t, (rw.r, ||r||^2), i++          :116, :137-151
-            CM_TRY(launch_full(st, la, ScalarSrc{s->parts_tt, np, 2}, n, x, s->s, s->s, s->t, s->rw, s->parts_full, &np_full,
-                               ScalarSrc{s->parts_half, np, 1}));
-            full_src = ScalarSrc{s->parts_full, np_full, 2};
-            std::swap(p_a, p_b);
-            std::swap(v_a, v_b);
-            std::swap(s->r, s->s);        // the new residual was written over s
-            continue;
-        }
-        // rho, beta, p = r + beta (p - omega v)                     :80-89
-        CM_TRY(launch_update_p(st, la, full_src, n, s->r, s->p, s->v));
-        const double *pw = s->p;
-        if (precond) {                                            // :92-98
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(precond_apply(s, s->p, s->t, s->pw, perm));
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            pw = s->pw;
-        }
-        // v = A pw, rw.v                                            :104-106
-        if (profile) hipEventRecord(prof_event(s, pe++), st);
-        CM_TRY(spmv_local(s, pw, s->v, 1, s->rw, s->parts_rv, la, CHECK_NONE, nosrc));
-        if (profile) hipEventRecord(prof_event(s, pe++), st);
-        ScalarSrc rv_src{s->parts_rv, spmv_parts(s), 2};
-        if (sharded) {
-            CM_TRY(launch_reduce_parts(st, rv_src, 1, s->red + 0, 0));
-            CM_TRY(allreduce(s, s->red + 0, 1));
-            rv_src = ScalarSrc{s->red + 0, 0, 1};
-        }
-        // alpha, r -= alpha v, x += alpha pw, ||r||                 :107-111
-        // (x += alpha pw rides in k_full -- x is then streamed once per iteration, not twice; an exit at the half step
-        // applies it after the loop)
-        CM_TRY(launch_half(st, la, rv_src, n, s->r, s->v, defer_x ? nullptr : x, pw, s->parts_half, &np_half));
-        pw_last = pw;
-        const ScalarSrc half_src{s->parts_half, np_half, 1};
-        const double *sv = s->r;
-        ScalarSrc tt_src{s->parts_tt, spmv_parts(s), 2};
-        if (!sharded) {
-            if (precond) {                                        // :116, :121-127
-                CM_TRY(launch_check(st, la, half_src, CHECK_HALF));
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                CM_TRY(precond_apply(s, s->r, s->t, s->s, perm));
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                sv = s->s;
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                CM_TRY(spmv_local(s, sv, s->t, 2, s->r, s->parts_tt, la, CHECK_NONE, nosrc));
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-            } else {
-                // half-step test fused into the SpMV prologue      :116, :132-136
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                CM_TRY(spmv_local(s, sv, s->t, 2, s->r, s->parts_tt, la, CHECK_HALF, half_src));
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-            }
-        } else {
-            // The SpMV changes only t, so the half-step test may ride with the
-            // (t.r, t.t) all-reduce: one collective instead of two.
-            CM_TRY(launch_reduce_parts(st, half_src, 1, s->red + 1, 0));
-            if (precond) {   // block-Jacobi: local triangular solves, no collective (they only write s and t, so an
-                             // exit at the half step, noticed after the all-reduce below, leaves x and r untouched)
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                CM_TRY(precond_apply(s, s->r, s->t, s->s));
-                if (profile) hipEventRecord(prof_event(s, pe++), st);
-                sv = s->s;
-            }
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(spmv_local(s, sv, s->t, 2, s->r, s->parts_tt, la, CHECK_NONE, nosrc));
-            if (profile) hipEventRecord(prof_event(s, pe++), st);
-            CM_TRY(launch_reduce_parts(st, tt_src, 2, s->red + 2, 0));
-            CM_TRY(allreduce(s, s->red + 1, 3));
-            CM_TRY(launch_check(st, la, ScalarSrc{s->red + 1, 0, 1}, CHECK_HALF));
-            tt_src = ScalarSrc{s->red + 2, 0, 1};
-        }
-        // omega, x += omega s, r -= omega t, (rw.r, ||r||), i++     :137-151
-        CM_TRY(launch_full(st, la, tt_src, n, x, sv, s->r, s->t, s->rw, s->parts_full, &np_full, ScalarSrc{nullptr, 0, 1},
-                           defer_x ? pw : nullptr));
-        full_src = ScalarSrc{s->parts_full, np_full, 2};
-        if (sharded) {
-            CM_TRY(launch_reduce_parts(st, full_src, 2, s->red + 4, 0));
-            CM_TRY(allreduce(s, s->red + 4, 2));
-            full_src = ScalarSrc{s->red + 4, 0, 1};
-        }
-    }
-    // the full-step test of the last iteration has not been looked at yet
-    if (pipelined)      // (check_full wants (., r.r): the last two of the five phase-B scalars)
-        CM_TRY(launch_check(st, la, ScalarSrc{pipeB_src.ptr + 3, pipeB_src.count, pipeB_src.stride}, CHECK_FULL));
-    else
-        CM_TRY(launch_check(st, la, full_src, CHECK_FULL));
-    CM_HIP(hipMemcpyAsync(&s->st_ring[0], s->st, sizeof(LoopState), hipMemcpyDeviceToHost, st));
-    CM_HIP(hipStreamSynchronize(st));                              // :372
-    const double t_loop1 = now_s();
-    // A dependency-driven triangular solve that gave up waiting (another spin-waiting kernel shared the GPU,
-    // see DESIGN.md section 4) invalidates this attempt; in a sharded run every rank must learn of it.
-    *precond_gave_up = false;
-    if (precond) {
-        int bad = trsv_status(s) != CUDAMAT_OK ? 1 : 0;
-        if (sharded) {
-            const double mine = (double)bad;
-            double all = 0.0;
-            CM_HIP(hipMemcpy(s->red + 7, &mine, sizeof(double), hipMemcpyHostToDevice));
-            CM_TRY(allreduce(s, s->red + 7, 1));
-            CM_HIP(hipStreamSynchronize(st));
-            CM_HIP(hipMemcpy(&all, s->red + 7, sizeof(double), hipMemcpyDeviceToHost));
-            bad = all != 0.0;
-        }
-        if (bad) {
-            *precond_gave_up = true;
-            return CUDAMAT_OK;
-        }
-    }
-    if (defer_x && pw_last && s->st_ring[0].state == 1) {      // left through the half step: pbicgstab.cu:110 is still due
-        CM_TRY(launch_axpy(st, n, s->st_ring[0].alpha, pw_last, x));
-        CM_HIP(hipStreamSynchronize(st));
-    }
-    if (perm) {                              // the iterate leaves U's space
-        CM_TRY(perm_from_space(s, true, x, x_user));
-        CM_HIP(hipStreamSynchronize(st));
-    }
-    const LoopState fin = s->st_ring[0];
-    if (pipelined && fin.state == 1) {      // left through the half step: the iterate is x + alpha p, kept in xh
-        CM_HIP(hipMemcpyAsync(x, s->pxh, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
-        CM_HIP(hipStreamSynchronize(st));
-    }
-    s->hist_count = hist_base + ((loop != CUDAMAT_LOOP_PBICGSTAB2) ? 2 * fin.it + (fin.state == 1 ? 1 : 0) : fin.it);
-    if (s->hist_count > s->hist_cap) s->hist_count = s->hist_cap;
-
-    cudamat_stats stt;
-    memset(&stt, 0, sizeof(stt));
-    stt.iters = fin.it;
-    stt.half_exit = fin.state == 1;
-    stt.converged = fin.state == 1 || fin.state == 2;
-    stt.breakdown = fin.state == 3;
-    stt.nrm0 = fin.nrm0;
-    stt.nrm = fin.nrm;
-    stt.t_analysis = s->t_analysis;
-    stt.t_factor = s->t_factor;
-    stt.t_solve = t_loop1 - t_loop0;
-    stt.n_levels_l = s->L.nlevels;
-    stt.n_levels_u = s->U.nlevels;
-    stt.trsv_form = precond ? trsv_form_code(s) : 0;
-    stt.trsv_fallbacks = s->trsv_fallbacks;
-    if (precond) trsv_group_counts(s, &stt.trsv_groups_l, &stt.trsv_groups_u);
-    stt.loop_form = loop_form;
-    stt.loop_fallbacks = s->loop_fallbacks;
-    stt.overlapped = sharded && s->windowed ? 2 : (sharded && s->overlap && s->spmv_mode == 1) ? 1 : 0;
-    stt.gather_fraction = sharded ? s->gather_fraction : 0.0;
-    stt.ms_spmv_alone = s->ms_spmv_alone;
-    stt.t_setup = s->t_create + s->t_spmv_setup;
-    stt.t_tune = s->t_spmv_timing;
-    stt.spmv_mode = s->spmv_mode;
-    if (s->profiling) {
-        // exposed part of an overlapped gather: the waits (kind 1), clipped to the gather they wait for only by
-        // construction -- the solver's stream idles there for nothing else
-        for (size_t i = 0; i < s->comm_kind.size() && 2 * i + 1 < s->comm_used; i++) {
-            float ms = 0.f;
-            hipEventElapsedTime(&ms, s->comm_ev[2 * i], s->comm_ev[2 * i + 1]);
-            switch (s->comm_kind[i]) {
-            case 0: stt.ms_gather += ms; stt.n_gather++; break;
-            case 2: stt.ms_gather += ms; stt.ms_gather_exposed += ms; stt.n_gather++; break;
-            default: stt.ms_allreduce += ms; stt.n_allreduce++; break;
-            }
-        }
-    }
-    if (profile) {
-        // events come in (start, stop) pairs; trsv pairs and spmv pairs alternate as recorded
-        size_t i = 0;
-        const int per_it_pairs = precond ? 4 : 2;
-        for (; i + 1 < pe; i += 2) {
-            float ms = 0.f;
-            hipEventElapsedTime(&ms, s->prof_ev[i], s->prof_ev[i + 1]);
-            const size_t pair = (i / 2) % per_it_pairs;
-            const bool is_trsv = precond && (pair == 0 || pair == 2);
-            if (is_trsv) { stt.ms_trsv += ms; stt.n_trsv += 2; }
-            else {
-                stt.ms_spmv += ms;
-                stt.n_spmv += 1;
-                // overlapped gather: what an SpMV took beyond the same SpMV with x already in place (the tuner's
-                // timing) is the part of the exchange that was NOT hidden behind it
-                if (stt.overlapped == 1 && s->ms_spmv_alone > 0.0 && ms > s->ms_spmv_alone) stt.ms_gather_exposed += ms - s->ms_spmv_alone;
-            }
-        }
-    }
-
-    if (flags & CUDAMAT_FLAG_DEBUG) {
-        std::vector<double> h((size_t)(s->hist_count > 0 ? s->hist_count : 1));
-        if (s->hist_count > 0)
-            hipMemcpy(h.data(), s->hist, sizeof(double) * (size_t)s->hist_count, hipMemcpyDeviceToHost);
-        if (loop != CUDAMAT_LOOP_PBICGSTAB2) {
-            printf("gpu, init residual:norm %20.16f\n", fin.nrm0);            // :77
-            for (int i = hist_base; i < s->hist_count; i++) {                  // (a restart segment prints its own part)
-                if ((i & 1) == 0) printf("i = %d, residual norm (before precond) = %g\n", i / 2, h[i]);  // :114
-                else printf("i = %d, residual norm = %g\n", i / 2, h[i]);      // :145
-            }
-        } else {
-            printf("initial norm = %g\n", fin.nrm0);                           // :659
-            for (int i = 0; i < s->hist_count; i++) printf("k = %d, norm = %g\n", i, h[i]);  // :727
-            if (fin.state == 3)
-                printf("omega is close to zero, cannot continue\nomega = %g\n", fin.omega);   // :737
-        }
-        fflush(stdout);
-    }
-    stt.t_total = now_s() - t_begin;
-    if (out) *out = stt;
-    return CUDAMAT_OK;
-}
-
-static int solve_guarded(cudamat_solver *s, const double *b, double *x, int precond, int loop, int maxit, double tol,
-                         int flags, cudamat_stats *out, double abs_tol)
-{
-    CM_ARG(s && b && x, "null pointer");
-    // keep the caller's x0 while the dependency-driven preconditioner is in use: if one of its waits times
-    // out, the solve is redone from x0 with the level-by-level kernels (same results, bit for bit)
-    // (the single-launch loop of very small systems can be voided the same way: <= 65536 rows, the copy is nothing)
-    const bool keep_x0 = (precond != CUDAMAT_PRECOND_NONE || (!s->sharded && !s->resident_off && s->n <= 65536)) &&
-                         !(flags & CUDAMAT_FLAG_X0_ONES);
-    if (keep_x0) {
-        CM_HIP(hipSetDevice(s->ctx->device));
-        if (!s->x0_save) CM_TRY(dev_alloc((void **)&s->x0_save, sizeof(double) * (size_t)(s->n > 0 ? s->n : 1)));
-        CM_HIP(hipMemcpyAsync(s->x0_save, x, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
-    }
-    bool gave_up = false, resident_gave_up = false;
-    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up, abs_tol));
-    if (resident_gave_up) {
-        // the grid barrier of the single-launch loop ran into its bound (its workgroups were not all resident: the GPU
-        // is shared): from now on this solver uses the three-launch loop; the solve is redone from x0
-        s->resident_off = true;
-        s->loop_fallbacks++;
-        if (getenv("CUDAMAT_VERBOSE"))
-            fprintf(stderr, "cudamat: the single-launch loop's grid barrier timed out (GPU shared?); redoing the solve with "
-                            "one launch per phase\n");
-        if (keep_x0)
-            CM_HIP(hipMemcpyAsync(x, s->x0_save, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
-        CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up, abs_tol));
-    }
-    if (!gave_up) return CUDAMAT_OK;
-    if (!trsv_syncfree_active(s)) {
-        set_error("triangular solve reported a timeout although the level-by-level kernels were in use");
-        return CUDAMAT_ERR_HIP;
-    }
-    trsv_disable_syncfree(s);
-    s->trsv_fallbacks++;          // reported in cudamat_stats: a redo must not pass for a slow solve
-    if (getenv("CUDAMAT_VERBOSE"))
-        fprintf(stderr, "cudamat: a dependency-driven triangular solve timed out (GPU shared with another spin-waiting "
-                        "kernel?); redoing the solve with one launch per level\n");
-    if (keep_x0)
-        CM_HIP(hipMemcpyAsync(x, s->x0_save, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->ctx->stream));
-    CM_TRY(solve_once(s, b, x, precond, loop, maxit, tol, flags, out, &gave_up, &resident_gave_up, abs_tol));
-    if (gave_up) {
-        set_error("triangular solve timed out twice");
-        return CUDAMAT_ERR_HIP;
-    }
-    return CUDAMAT_OK;
-}
-
-extern "C" int cudamat_solver_solve(cudamat_solver *s, const double *b, double *x, int precond,
-                                    int loop, int maxit, double tol, int flags, cudamat_stats *out)
-{
-    cudamat_stats st0;
-    CM_TRY(solve_guarded(s, b, x, precond, loop, maxit, tol, flags, &st0, 0.0));
-    // The pipelined loop carries r, w = A r, s = A p, z = A s by recurrences; over a few hundred iterations their rounding
-    // errors can let the recursive residual pass the test while the true one is orders of magnitude away (seen: 5e-3
-    // against a tolerance of 1e-9).  So an iterate that this loop calls converged is VERIFIED: a restart from it computes
-    // the true residual b - A x (one SpMV); within twice the target it is accepted, otherwise the loop goes on from
-    // there towards the same absolute target -- at most three times, within the caller's maxit.
-    if (loop == CUDAMAT_LOOP_PIPELINED && st0.converged && !(flags & CUDAMAT_FLAG_NO_EXIT) && st0.nrm0 > 0.0) {
-        const double target = tol * st0.nrm0;
-        for (int r = 0; r < 3 && st0.converged && st0.iters < maxit; r++) {
-            cudamat_stats st2;
-            CM_TRY(solve_guarded(s, b, x, precond, loop, maxit - st0.iters, tol, flags & ~CUDAMAT_FLAG_X0_ONES, &st2, target));
-            st0.t_solve += st2.t_solve;
-            st0.t_total += st2.t_total;
-            st0.nrm = st2.nrm;                       // the true residual of the verified iterate (st2.nrm0) or the loop's last
-            if (st2.iters == 0 && st2.converged) break;
-            st0.restarts++;
-            st0.iters += st2.iters;
-            st0.converged = st2.converged;
-            st0.half_exit = st2.half_exit;
-            st0.breakdown = st2.breakdown;
-        }
-    }
-    if (out) *out = st0;
-    return CUDAMAT_OK;
-}
-
-extern "C" int cudamat_solver_history(cudamat_solver *s, double *hist_host, int cap, int *count)
-{
-    CM_ARG(s && count, "null pointer");
-    int c = s->hist_count < cap ? s->hist_count : cap;
-    if (c < 0) c = 0;
-    if (c > 0) {
-        CM_ARG(hist_host, "hist_host is NULL");
-        CM_HIP(hipMemcpy(hist_host, s->hist, sizeof(double) * (size_t)c, hipMemcpyDeviceToHost));
-    }
-    *count = c;
-    return CUDAMAT_OK;
-}
-
-// ---------------------------------------------------------------------------------------
-// Drop-in host-pointer solve: pbicgstab.cu:157-409 / :756-922 / :926-1088 in one call.
-// ---------------------------------------------------------------------------------------
-// The reference allocates, analyses, solves and frees per call (pbicgstab.cu:157-409).  Here the solver of the last
-// call stays alive: when the next call brings the same matrix (same n, nnz, base and -- compared ON THE DEVICE after
-// the upload, 12 bytes per entry read twice: ~2.5 ms at C4 -- the same row pointers, column indices and values), its
-// device copies, SpMV plan, value dictionary and ILU(0) factors are reused and the call costs upload + loop.
-namespace {
-struct PlanCache {
-    std::mutex mu;
-    cudamat_ctx *ctx = nullptr;
-    cudamat_solver *s = nullptr;
-    int n = 0, nnz = 0, base = 0;
-    bool has_shift = false;
-    double *d_d = nullptr;          // the (A0 + I d) diagonal the cached solver points at
-};
-PlanCache g_cache;
-
-void cache_drop_locked()
-{
-    if (g_cache.s) cudamat_solver_destroy(g_cache.s);
-    if (g_cache.d_d) cudamat_free(g_cache.ctx, g_cache.d_d);
-    if (g_cache.ctx) cudamat_ctx_destroy(g_cache.ctx);
-    g_cache.s = nullptr;
-    g_cache.d_d = nullptr;
-    g_cache.ctx = nullptr;
-}
-
-bool cache_enabled()
-{
-    const char *e = getenv("CUDAMAT_PLAN_CACHE");
-    return !(e && e[0] == '0');
-}
-}  // namespace
-
-// flag[0] = 1 when a[i] != b[i] for some i (raw 32-bit words)
-__global__ __launch_bounds__(kBlock) void k_differs(long long words, const unsigned *a, const unsigned *b, int *flag)
-{
-    bool diff = false;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < words; i += (long long)gridDim.x * kBlock) diff |= a[i] != b[i];
-    if (diff) *flag = 1;
-}
-
-static int device_equal(hipStream_t st, const void *a, const void *b, size_t bytes, int *flag_dev)
-{
-    const long long words = (long long)(bytes / 4);
-    if (words == 0) return CUDAMAT_OK;
-    long long g = (words + kBlock * 8LL - 1) / (kBlock * 8LL);
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_differs, dim3((unsigned)g), dim3(kBlock), 0, st, words, (const unsigned *)a, (const unsigned *)b, flag_dev);
-    CM_HIP(hipGetLastError());
-    return CUDAMAT_OK;
-}
-
-extern "C" int cudamat_plan_cache_clear(void)
-{
-    std::lock_guard<std::mutex> lk(g_cache.mu);
-    cache_drop_locked();
-    return CUDAMAT_OK;
-}
-
-extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, const int *jA,
-                             const double *d, const double *x0, const double *b, int precond,
-                             int loop, int maxit, double tol, int debug, double *x,
-                             cudamat_stats *out)
-{
-    CM_ARG(n > 0 && nnz >= 0 && A && iA && jA && b && x, "null pointer or empty system");
-    const int base = iA[0];                                        // pbicgstab.cu:201,782,953
-    CM_ARG(base == 0 || base == 1, "iA[0] must be 0 or 1");
-    CM_ARG(iA[n] - base == nnz, "nnz != iA[n] - iA[0]");
-    const double t0 = now_s();
-    if (debug && loop == CUDAMAT_LOOP_PBICGSTAB) printf("N=%d, nnz=%d\n", n, nnz);   // :204
-    std::lock_guard<std::mutex> cache_lock(g_cache.mu);            // (the entry points are not re-entrant upstream either)
-    const bool use_cache = cache_enabled();
-    if (!use_cache) cache_drop_locked();
-    // same shape as the cached system?  then its context (device, stream) carries this call too
-    const bool candidate = use_cache && g_cache.s && g_cache.n == n && g_cache.nnz == nnz && g_cache.base == base;
-    if (!candidate) cache_drop_locked();
-    cudamat_ctx *ctx = candidate ? g_cache.ctx : nullptr;
-    if (!ctx) CM_TRY(cudamat_ctx_create(0, nullptr, &ctx));
-    int *d_rp = nullptr, *d_ci = nullptr;
-    double *d_val = nullptr, *d_b = nullptr, *d_x = nullptr, *d_d = nullptr;
-    cudamat_solver *s = nullptr;
-    bool reused = false, built_ilu = false;
-    int rc = CUDAMAT_OK;
-    cudamat_stats st;
-    memset(&st, 0, sizeof(st));
-    double t_up = 0.0;
-    do {
-        if ((rc = cudamat_malloc(ctx, sizeof(int) * ((size_t)n + 1), (void **)&d_rp))) break;
-        if ((rc = cudamat_malloc(ctx, sizeof(int) * (size_t)nnz, (void **)&d_ci))) break;
-        if ((rc = cudamat_malloc(ctx, sizeof(double) * (size_t)nnz, (void **)&d_val))) break;
-        if ((rc = cudamat_malloc(ctx, sizeof(double) * (size_t)n, (void **)&d_b))) break;
-        if ((rc = cudamat_malloc(ctx, sizeof(double) * (size_t)n, (void **)&d_x))) break;
-        if ((rc = cudamat_h2d(ctx, d_rp, iA, sizeof(int) * ((size_t)n + 1)))) break;     // :313-315
-        if ((rc = cudamat_h2d(ctx, d_ci, jA, sizeof(int) * (size_t)nnz))) break;
-        if ((rc = cudamat_h2d(ctx, d_val, A, sizeof(double) * (size_t)nnz))) break;
-        if ((rc = cudamat_h2d(ctx, d_b, b, sizeof(double) * (size_t)n))) break;
-        if (x0 && (rc = cudamat_h2d(ctx, d_x, x0, sizeof(double) * (size_t)n))) break;
-        if (d) {
-            if ((rc = cudamat_malloc(ctx, sizeof(double) * (size_t)n, (void **)&d_d))) break;
-            if ((rc = cudamat_h2d(ctx, d_d, d, sizeof(double) * (size_t)n))) break;
-        }
-        if ((rc = cudamat_ctx_sync(ctx))) break;
-        t_up = now_s() - t0;
-        if (candidate) {
-            // the cached solver holds the matrix rebased to 0: compare the uploaded arrays with it on the device
-            int *flag = nullptr, h = 1;
-            if ((rc = cudamat_malloc(ctx, sizeof(int), (void **)&flag))) break;
-            hipMemsetAsync(flag, 0, sizeof(int), ctx->stream);
-            cudamat_solver *c = g_cache.s;
-            int *tmp = nullptr;          // rebased copies of the uploaded index arrays
-            rc = cudamat_malloc(ctx, sizeof(int) * ((size_t)nnz > (size_t)n + 1 ? (size_t)nnz : (size_t)n + 1), (void **)&tmp);
-            if (!rc) rc = launch_rebase(ctx->stream, (int64_t)n + 1, d_rp, -base, tmp);
-            if (!rc) rc = device_equal(ctx->stream, tmp, c->rp, sizeof(int) * ((size_t)n + 1), flag);
-            if (!rc && nnz) rc = launch_rebase(ctx->stream, nnz, d_ci, -base, tmp);
-            if (!rc && nnz) rc = device_equal(ctx->stream, tmp, c->ci, sizeof(int) * (size_t)nnz, flag);
-            if (!rc && nnz) rc = device_equal(ctx->stream, d_val, c->val, sizeof(double) * (size_t)nnz, flag);
-            if (!rc && hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = CUDAMAT_ERR_HIP;
-            if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = CUDAMAT_ERR_HIP;
-            if (tmp) cudamat_free(ctx, tmp);
-            cudamat_free(ctx, flag);
-            if (rc) break;
-            if (h == 0) {
-                s = g_cache.s;
-                reused = true;
-            } else {                     // same shape, another matrix: the old solver goes, its context stays
-                cudamat_solver_destroy(g_cache.s);
-                g_cache.s = nullptr;
-            }
-        }
-        if (g_cache.d_d) { cudamat_free(ctx, g_cache.d_d); g_cache.d_d = nullptr; }
-        if (!s && (rc = cudamat_solver_create(ctx, n, n, nnz, d_rp, d_ci, d_val, base, &s))) break;
-        if ((rc = cudamat_solver_set_shift(s, d_d))) break;
-        if (precond != CUDAMAT_PRECOND_NONE && !(reused && s->has_ilu && !s->ilu_block)) {
-            if ((rc = cudamat_solver_ilu0(s))) break;
-            built_ilu = true;
-        }
-        if (precond != CUDAMAT_PRECOND_NONE && debug) {
-            printf("analysis lower %f (s), upper %f (s) \n", s->t_analysis_l, s->t_analysis_u);     // :349
-            printf("csrilu0 (HIP, level-scheduled) time(s) = %10.8f \n", s->t_factor);            // :355,363
-        }
-        int flags = (debug ? CUDAMAT_FLAG_DEBUG : 0) | (x0 ? 0 : CUDAMAT_FLAG_X0_ONES);
-        if ((rc = cudamat_solver_solve(s, d_b, d_x, precond, loop, maxit, tol, flags, &st))) break;
-        if ((rc = cudamat_d2h(ctx, x, d_x, sizeof(double) * (size_t)n))) break;            // :381
-    } while (0);
-    char saved[512];
-    strncpy(saved, cudamat_last_error(), sizeof(saved) - 1);
-    saved[sizeof(saved) - 1] = 0;
-    st.t_upload = t_up;
-    st.plan_reused = reused ? 1 : 0;
-    if (reused) { st.t_setup = 0.0; st.t_tune = 0.0; }                       // (they describe the call that built the plan)
-    if (reused && !built_ilu) { st.t_analysis = 0.0; st.t_factor = 0.0; }
-    // keep the solver for the next call (it owns its own copies of the matrix; the upload buffers go)
-    cudamat_solver *const old = g_cache.s;       // the previous call's solver, when it is still alive (may be s itself)
-    if (s && rc == CUDAMAT_OK && use_cache) {
-        if (old && old != s) cudamat_solver_destroy(old);
-        g_cache.ctx = ctx;
-        g_cache.s = s;
-        g_cache.n = n; g_cache.nnz = nnz; g_cache.base = base;
-        g_cache.d_d = d_d;               // the solver points at it (set_shift); replaced by the next call
-        d_d = nullptr;
-    } else {
-        if (s) cudamat_solver_destroy(s);
-        if (old && old != s) cudamat_solver_destroy(old);
-        g_cache.s = nullptr;
-    }
-    void *ptrs[] = {d_rp, d_ci, d_val, d_b, d_x, d_d};
-    for (void *p : ptrs)
-        if (p) cudamat_free(ctx, p);
-    if (!g_cache.s) {                    // nothing kept: the context goes too
-        if (g_cache.d_d) { cudamat_free(ctx, g_cache.d_d); g_cache.d_d = nullptr; }
-        cudamat_ctx_destroy(ctx);
-        g_cache.ctx = nullptr;
-    }
-    if (rc) set_error("%s", saved);
-    st.t_total = now_s() - t0;
-    if (out) *out = st;
-    return rc;
-}

@@ -55,7 +55,7 @@ struct PbPlan {
 bool pb_candidate(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci);
 // build the blocked copy from 0-based CSR on the device
 // vd (optional): the value dictionary of `val` (indices in the same CSR order) -- the copy then stores 1 byte per value
-int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
+int pb_build(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
              const double *val, PbPlan *out, const PbCols *cols = nullptr, const ValDict *vd = nullptr);
 void pb_free(PbPlan *p);
 // y = alpha*(A x + d.*xd) + beta*y with the same fused dot / prologue options as launch_spmv;
@@ -66,8 +66,5 @@ int launch_spmv_pb(hipStream_t st, const PbPlan &plan, const SpmvArgs &a);
 int launch_pb_check(hipStream_t st, const SpmvArgs &a);
 int launch_pb_phase1(hipStream_t st, const PbPlan &plan, const SpmvArgs &a, int part);
 int launch_pb_phase2(hipStream_t st, const PbPlan &plan, const SpmvArgs &a);
-// phase 1 of the column blocks [b0, b1) in index order; dynamic LDS of a phase-1 workgroup
-int launch_pb_phase1_range(hipStream_t st, const PbPlan &plan, const SpmvArgs &a, int b0, int b1);
-size_t pb_phase1_lds_bytes(const PbPlan &plan);
 
 }  // namespace cm

@@ -31,13 +31,12 @@ typedef unsigned short u16;
 constexpr int kPbBuildWaves = 4;
 constexpr int kP1Threads = 1024;
 constexpr int kP1Unroll = 8;          // steps of phase 1 whose loads are in flight together (k_pb_phase1_dict)
-constexpr int kTileMax = 13312;        // doubles per y tile of a row block (104 KB)
-// doubles per x tile of a column block (phase 1): CUDAMAT_PB_XTILE overrides (experiment)
-static int x_tile_max()
-{
-    static const int v = [] { const char *e = getenv("CUDAMAT_PB_XTILE"); const int t = e ? atoi(e) : 0; return t >= 1024 && t <= 19968 ? t : kTileMax; }();
-    return v;
-}
+constexpr int kTileMax = 13312;        // doubles per y tile of a row block / x tile of a column block (104 KB): 768 column blocks at
+                                       // 1e7 columns = three whole rounds over 256 CUs (512 / 768 / 1024 / 1280 blocks at C4: 2.66 / 2.53 /
+                                       // 2.70 / 2.89 ms per SpMV pair, HISTORY.md round 3)
+constexpr int kPbAlign = 64;           // every column block's entries start on a 64-entry boundary: the 1 KB product stores, the 1 KB value
+                                       // loads and the 256-byte column loads of a phase-1 wave then cover whole 128-byte lines (<= 63 idle
+                                       // slots per block: value 0 x column 0, never read by phase 2; -4.5 % per C4 SpMV against packed blocks)
 
 static double now_s()
 {
@@ -235,7 +234,7 @@ static int round_blocks(int64_t n, int tile_max)
     return (int)(256 * m);
 }
 
-int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
+int pb_build(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
              const double *val, PbPlan *out, const PbCols *cols, const ValDict *vd)
 {
     const double t0 = now_s();
@@ -249,7 +248,7 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
         p.per = cols->per;
         p.chunks = cols->chunks < 1 ? 1 : cols->chunks > kPbMaxChunks ? kPbMaxChunks : cols->chunks;
         p.chunk_len = (p.per + p.chunks - 1) / p.chunks;
-        p.bpc = (int)((p.chunk_len + x_tile_max() - 1) / x_tile_max());
+        p.bpc = (int)((p.chunk_len + kTileMax - 1) / kTileMax);
         p.CB = (int)((p.chunk_len + p.bpc - 1) / p.bpc);
         const int64_t slices = (n_cols + p.per - 1) / p.per;
         p.NCB = (int)(slices * p.chunks * p.bpc);
@@ -258,7 +257,7 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
         p.per = n_cols;
         p.chunks = 1;
         p.chunk_len = n_cols;
-        p.NCB = round_blocks(n_cols, x_tile_max());
+        p.NCB = round_blocks(n_cols, kTileMax);
         p.CB = (int)((n_cols + p.NCB - 1) / p.NCB);
         p.NCB = (int)((n_cols + p.CB - 1) / p.CB);
         p.bpc = p.NCB;
@@ -271,16 +270,16 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     // alternation on one box (scripts/ab_env.sh, G = 8 shard of C4, ms per iteration of one rank): 4096 waves x 4 loads
     // 0.892 / 0.906 / 0.936; 4096 x 8 the same; 2048 x 8 0.852 / 0.874 / 0.873; 2048 x 16 0.808 / 0.847 / 0.848;
     // 1024 x 16 0.827 / 0.841 / 0.855.  On the full matrix (13.5 K waves) 4 loads in flight stay the best (2.58-2.67 ms
-    // per SpMV against 2.69-2.70 with 8 and 2.68-2.75 with 16).  CUDAMAT_PB_MIN_WAVES / CUDAMAT_PB_DEPTH override.
-    double seg_target = 48.0;
-    if (const char *e = getenv("CUDAMAT_PB_SEG")) { const double v = atof(e); if (v >= 8.0 && v <= 512.0) seg_target = v; }
+    // per SpMV against 2.69-2.70 with 8 and 2.68-2.75 with 16; 32 / 48 / 72 / 96 entries per segment: 2.87-3.02 / best / equal /
+    // 3.3-3.5 ms).  The options PB_MIN_WAVES / PB_DEPTH override (tests force the shard-shaped plans on small matrices).
+    const double seg_target = 48.0;
     double nsub_t = (double)nnz / ((double)p.NCB * seg_target);
     // (the 2048-wave plan needs 8 waves per row block whose y tiles fit the LDS: up to 4.7 M rows; a 1e7-row matrix with few
     // entries per row keeps the 4096-wave rule -- with 4-wave row blocks its phase 2 took 0.50 ms instead of 0.23)
     const bool few = nsub_t < 2560.0 && (double)n / 2048.0 * 8.0 * 8.0 <= 144.0 * 1024.0;          // (a G = 4 shard, 3390 natural waves, is better off with 4096 x 4: 1.50 / 1.57 / 1.50
                                                // against 1.53 / 1.60 / 1.59 ms per iteration with 3390 x 16)
     double min_waves = few ? 2048.0 : 4096.0;
-    if (const char *e = getenv("CUDAMAT_PB_MIN_WAVES")) { const double v = atof(e); if (v >= 256.0) min_waves = v; }
+    if (cfg.pb_min_waves) min_waves = (double)cfg.pb_min_waves;
     if (nsub_t < min_waves) nsub_t = min_waves;
     if (nsub_t > (double)n / 16.0) nsub_t = (double)n / 16.0;
     if (nsub_t < 4.0) nsub_t = 4.0;
@@ -300,7 +299,7 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     const double seg = (double)nnz / ((double)p.NCB * p.NSUB);      // mean entries per segment
     p.LPS = seg <= 6.0 ? 16 : seg <= 22.0 ? 32 : 64;
     p.depth = few ? 16 : 4;
-    if (const char *e = getenv("CUDAMAT_PB_DEPTH")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) p.depth = v; }
+    if (cfg.pb_depth) p.depth = cfg.pb_depth;
     if (p.NRB > kMaxParts || p.CB > 65536 || p.SR > 65536 || (size_t)p.RB * 8 > 150 * 1024 ||
         sizeof(int) * (size_t)kPbBuildWaves * p.NCB > 150 * 1024) {     // the analysis keeps one cursor per column block in LDS
         set_error("pb_build: matrix shape outside the blocked kernel's limits");
@@ -311,11 +310,7 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
     int rc = CUDAMAT_OK;
     do {
         if ((rc = dalloc(&bins, nbins))) break;
-        // Every column block's entries start on a 64-entry boundary (round 3): the 1 KB product stores, the 1 KB value loads
-        // and the 256-byte column loads of a wave in phase 1 then cover whole 128-byte lines (the blocks hold ~650 K entries
-        // at C4: <= 63 idle slots each, zero value x column 0, never read by phase 2).  CUDAMAT_PB_ALIGN=1 packs them.
-        int align = 64;
-        if (const char *e = getenv("CUDAMAT_PB_ALIGN")) { const int v = atoi(e); if (v == 1 || v == 16 || v == 64 || v == 128) align = v; }
+        constexpr int align = kPbAlign;
         const size_t cap = (size_t)nnz + (size_t)(align - 1) * (size_t)p.NCB + 16;
         if (vd && vd->n > 0) {
             if ((rc = dalloc(&p.pvi, cap))) break;
@@ -406,122 +401,28 @@ int pb_build(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, 
 }
 
 // ------------------------------------------------------------------ phase 1
-// The streaming loop and the memory counter (round 3, from the ISA).  gfx950 has ONE counter (vmcnt) for loads and
-// stores; the compiler cannot tell whether a pending operation it waits behind is a load or a store and puts
-// `s_waitcnt vmcnt(0)` in front of every use of a loaded value while a store is pending.  The plain loop below (4 steps:
-// 8 loads, then 4 x {wait, LDS reads, products, store}) therefore drains the wave's queue FOUR times per iteration --
-// each store's completion sits on the wave's path, a wave has ~2 KB in flight on average, 16 waves per compute unit (the
-// x tile fills the LDS) move 19.8 GB/s per unit: 1.83 ms for the 9.3 GB of a C4 launch (5.08 TB/s).  That looks
-// latency-bound, and the remedy was built: the hardware retires a wave's vector-memory operations in issue order, so with
-// loads and waits written as inline assembly (`s_waitcnt vmcnt(U)`: wait for the loads, leave the U younger stores in
-// flight) a wave keeps U = 4 loads AND 4 stores in flight at all times, no drain in the loop (ISA checked: 8 loads,
-// 4 stores, `s_waitcnt vmcnt(4)`, nothing else).  Bit-identical results -- and 7 % SLOWER on the GPU, twice in
-// alternation on one box (3.07 / 2.86 ms per SpMV against 2.85 / 2.67): as with the chunked body of the dictionary kernel
-// on fp64 values (round 2: 10 % slower), MORE traffic in flight per wave lowers this kernel's throughput.  So the launch
-// is not bound by its waves' round trips; its time is close to reading its input (5.3 GB at ~6 TB/s) plus writing its
-// output (4 GB at ~6 TB/s) one after the other, which is how the memory system treats a 10-read : 8-write mix.  The
-// pipelined form stays selectable (CUDAMAT_PB_PIPELINE=1) for other parts and mixes; the plain loop is the default.
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ v2d p1_load_vals(const double *p)
-{
-    v2d v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ unsigned p1_load_u32(const void *p)
-{
-    unsigned v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ unsigned p1_load_u16(const void *p)
-{
-    unsigned v;
-    asm volatile("global_load_ushort %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-// wait until all but the N youngest vector-memory operations of this wave are done; the loaded registers pass THROUGH the
-// statement, so that no use of them can be scheduled above it
-template <int N>
-__device__ __forceinline__ void p1_wait4(v2d &a, v2d &b, v2d &c, v2d &d, unsigned &e, unsigned &f, unsigned &g, unsigned &h)
-{
-    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void p1_wait4i(unsigned &a, unsigned &b, unsigned &c, unsigned &d, unsigned &e, unsigned &f, unsigned &g,
-                                          unsigned &h)
-{
-    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N) : "memory");
-}
-
-constexpr int kP1U = 4;                // steps per chunk of the pipelined loop (registers: 2 sets x 4 x (4 + 1))
-
+// The streaming loop: two entries per lane per step (16-byte value loads), four steps in flight, every bound checked.
+// gfx950 has ONE counter (vmcnt) for loads and stores, and the compiler drains it before every use of a loaded value
+// while a store is pending, so this loop's queue empties four times per iteration.  The remedy -- loads and waits as
+// inline assembly, `s_waitcnt vmcnt(4)`, 8 loads AND 4 stores in flight per wave at all times -- was built in round 3
+// and measured 7 % SLOWER (as the chunked body of the dictionary kernel is on fp64 values, 10 %): the launch is not bound
+// by its waves' round trips; its time is close to reading its input (5.3 GB at ~6 TB/s) plus writing its output (4 GB
+// at ~6 TB/s) one after the other, which is how the memory system treats a 10-read : 8-write mix (HISTORY.md round 3;
+// the variant is in the history of this file, commit 5f8463c and before).
 __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const int *col0, const int *list,
                                                           const int *cstart, const double *pv, const u16 *pc,
-                                                          double *P, const LoopState *st, int pipelined, int split, int cb0)
+                                                          double *P, const LoopState *st, int cb0)
 {
     extern __shared__ __attribute__((aligned(16))) double xs[];
     if (st && st->state != 0) return;
-    // split > 1: `split` workgroups share a column block (each stages the x tile and streams one slice of the block's
-    // entries): a finer grain for the dispatcher at the end of the launch
-    const int bi = (int)blockIdx.x / split, part = (int)blockIdx.x - bi * split;
-    const int cb = list ? list[bi] : bi + cb0;
-    int s = cstart[cb], e = cstart[cb + 1];
-    if (split > 1) {
-        const int len = e - s, per = ((len + split - 1) / split + 1) & ~1;
-        const int s1 = s + part * per;
-        e = s1 + per < e ? s1 + per : e;
-        s = s1;
-    }
-    if (s >= e) return;                                    // (block-uniform) nothing stored in this block / slice
+    const int cb = list ? list[blockIdx.x] : (int)blockIdx.x + cb0;
+    const int s = cstart[cb], e = cstart[cb + 1];
+    if (s >= e) return;                                    // (block-uniform) nothing stored in this block
     const int c0 = col0[cb], cn = col0[cb + 1] - c0;
     for (int i = threadIdx.x; i < cn; i += kP1Threads) xs[i] = x[c0 + i];
     __syncthreads();
-    constexpr int STEP = 2 * kP1Threads, U = kP1U, CH = U * STEP;
-    int k_plain = s & ~1;                                  // where the plain loop starts (pairs at even entries)
-    // ---- whole chunks, software-pipelined against the memory counter (see above)
-    const int a0 = (s + 1) & ~1;
-    const int nch = pipelined ? (e - a0) / CH : 0;         // (workgroup-uniform)
-    if (nch >= 2) {
-        if (threadIdx.x == 0 && s < a0) P[s] = pv[s] * xs[pc[s]];
-        const int t2 = 2 * (int)threadIdx.x;
-        v2d va0, va1, va2, va3, vb0, vb1, vb2, vb3;
-        unsigned ca0, ca1, ca2, ca3, cb0, cb1, cb2, cb3;
-#define CM_P1_LOADS(V0, V1, V2, V3, C0, C1, C2, C3, K)                                              \
-        V0 = p1_load_vals(pv + (K));            C0 = p1_load_u32(pc + (K));                          \
-        V1 = p1_load_vals(pv + (K) + STEP);     C1 = p1_load_u32(pc + (K) + STEP);                   \
-        V2 = p1_load_vals(pv + (K) + 2 * STEP); C2 = p1_load_u32(pc + (K) + 2 * STEP);               \
-        V3 = p1_load_vals(pv + (K) + 3 * STEP); C3 = p1_load_u32(pc + (K) + 3 * STEP);
-#define CM_P1_PROD(O, V, C) O.x = V.x * xs[C & 0xffffu]; O.y = V.y * xs[C >> 16];
-#define CM_P1_STORES(O0, O1, O2, O3, K)                                                             \
-        *(v2d *)(P + (K)) = O0; *(v2d *)(P + (K) + STEP) = O1; *(v2d *)(P + (K) + 2 * STEP) = O2;   \
-        *(v2d *)(P + (K) + 3 * STEP) = O3;
-        int k = a0 + t2;
-        CM_P1_LOADS(va0, va1, va2, va3, ca0, ca1, ca2, ca3, k)
-        p1_wait4<0>(va0, va1, va2, va3, ca0, ca1, ca2, ca3);                  // (first chunk: nothing younger)
-        for (int i = 0; i < nch; i += 2) {
-            v2d o0, o1, o2, o3;
-            // chunk i lives in set A (already waited for)
-            CM_P1_PROD(o0, va0, ca0) CM_P1_PROD(o1, va1, ca1) CM_P1_PROD(o2, va2, ca2) CM_P1_PROD(o3, va3, ca3)
-            if (i + 1 < nch) { CM_P1_LOADS(vb0, vb1, vb2, vb3, cb0, cb1, cb2, cb3, k + CH) }
-            CM_P1_STORES(o0, o1, o2, o3, k)
-            if (i + 1 >= nch) break;
-            p1_wait4<U>(vb0, vb1, vb2, vb3, cb0, cb1, cb2, cb3);              // the U stores above stay in flight
-            CM_P1_PROD(o0, vb0, cb0) CM_P1_PROD(o1, vb1, cb1) CM_P1_PROD(o2, vb2, cb2) CM_P1_PROD(o3, vb3, cb3)
-            if (i + 2 < nch) { CM_P1_LOADS(va0, va1, va2, va3, ca0, ca1, ca2, ca3, k + 2 * CH) }
-            CM_P1_STORES(o0, o1, o2, o3, k + CH)
-            if (i + 2 < nch) p1_wait4<U>(va0, va1, va2, va3, ca0, ca1, ca2, ca3);
-            k += 2 * CH;
-        }
-#undef CM_P1_LOADS
-#undef CM_P1_PROD
-#undef CM_P1_STORES
-        k_plain = a0 + nch * CH;
-    }
-    // ---- the plain loop: two entries per lane per step (16-byte value loads), four steps in flight, every bound checked
-    const int lo = nch >= 2 ? k_plain : s;                 // entries below lo are done
-    const int k0 = k_plain + 2 * (int)threadIdx.x;
+    constexpr int STEP = 2 * kP1Threads;
+    const int k0 = (s & ~1) + 2 * (int)threadIdx.x;        // pairs at even entries (16-byte aligned)
     for (int k = k0; k < e; k += 4 * STEP) {
         double2 v[4];
         ushort2 c[4];
@@ -529,7 +430,7 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int kk = k + u * STEP;
-            full[u] = kk >= lo && kk + 1 < e;
+            full[u] = kk >= s && kk + 1 < e;
             if (full[u]) {
                 v[u] = *(const double2 *)(pv + kk);
                 c[u] = *(const ushort2 *)(pc + kk);
@@ -544,8 +445,8 @@ __global__ __launch_bounds__(kP1Threads) void k_pb_phase1(const double *x, const
                 o.y = v[u].y * xs[c[u].y];
                 *(double2 *)(P + kk) = o;
             } else {
-                if (kk >= lo && kk < e) P[kk] = pv[kk] * xs[pc[kk]];
-                if (kk + 1 >= lo && kk + 1 < e) P[kk + 1] = pv[kk + 1] * xs[pc[kk + 1]];
+                if (kk >= s && kk < e) P[kk] = pv[kk] * xs[pc[kk]];
+                if (kk + 1 >= s && kk + 1 < e) P[kk + 1] = pv[kk + 1] * xs[pc[kk + 1]];
             }
         }
     }
@@ -658,7 +559,7 @@ struct Pb2Args {
 // sorted by row, then column), and a row must receive its products in column order, one rounding per addition.
 //  * default: one ds_add_f64 instruction, relying on the OBSERVED property that the LDS serves equal addresses of one
 //    instruction in lane order.
-//  * strict (CUDAMAT_PB_STRICT=1; round 3): lanes are ranked inside their run of equal rows and every rank is its own
+//  * strict (option PB_STRICT = 1; round 3): lanes are ranked inside their run of equal rows and every rank is its own
 //    instruction -- within an instruction all addresses are distinct, and a wave's LDS instructions execute in issue
 //    order, so the order of the additions is ARCHITECTED.  Bit-identical results on gfx950 (the guard test runs both
 //    against the oracle) at a price: +10 % per C4 SpMV (2.70 -> 2.97 ms), +25 % per iteration of a G = 8 rank -- phase 2
@@ -849,10 +750,8 @@ static int launch_pb_phase1_blocks(hipStream_t st, const PbPlan &p, const SpmvAr
         return CUDAMAT_OK;
     }
     CM_TRY(set_max_lds((const void *)k_pb_phase1));
-    static const int pipelined = [] { const char *e = getenv("CUDAMAT_PB_PIPELINE"); return e && e[0] == '1' ? 1 : 0; }();
-    static const int split = [] { const char *e = getenv("CUDAMAT_PB_SPLIT"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
-    hipLaunchKernelGGL(k_pb_phase1, dim3((last - first) * split), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x, p.col0,
-                       list ? list + first : (const int *)nullptr, p.cstart, p.pv, p.pc, p.P, a.loop.st, pipelined, split, list ? 0 : first);
+    hipLaunchKernelGGL(k_pb_phase1, dim3(last - first), dim3(kP1Threads), sizeof(double) * (size_t)p.CB, st, a.x, p.col0,
+                       list ? list + first : (const int *)nullptr, p.cstart, p.pv, p.pc, p.P, a.loop.st, list ? 0 : first);
     CM_HIP(hipGetLastError());
     return CUDAMAT_OK;
 }
@@ -862,18 +761,6 @@ int launch_pb_phase1(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int par
     // part < 0: every block in index order; otherwise the blocks of one launch part (PbPlan::order)
     if (part < 0) return launch_pb_phase1_blocks(st, p, a, nullptr, 0, p.NCB);
     return launch_pb_phase1_blocks(st, p, a, p.order, p.part_off[part], p.part_off[part + 1]);
-}
-
-// phase 1 of the column blocks [b0, b1) only (the triangular solves run the blocks whose columns are final early)
-int launch_pb_phase1_range(hipStream_t st, const PbPlan &p, const SpmvArgs &a, int b0, int b1)
-{
-    return launch_pb_phase1_blocks(st, p, a, nullptr, b0 < 0 ? 0 : b0, b1 > p.NCB ? p.NCB : b1);
-}
-
-// bytes of dynamic LDS a phase-1 workgroup of this plan asks for (what a co-resident kernel must leave free)
-size_t pb_phase1_lds_bytes(const PbPlan &p)
-{
-    return p.pvi ? sizeof(double) * (size_t)(((p.CB + 1) & ~1) + kDictMax) : sizeof(double) * (size_t)p.CB;
 }
 
 int launch_spmv_pb(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
@@ -893,10 +780,7 @@ int launch_pb_phase2(hipStream_t st, const PbPlan &p, const SpmvArgs &a)
     b.alpha = a.alpha; b.beta = a.beta;
     b.y = a.y; b.dot = a.dot; b.w = a.w; b.parts = a.parts;
     b.st = a.loop.st;
-    {
-        const char *e = getenv("CUDAMAT_PB_STRICT");          // (read per launch: the guard test switches it inside one process)
-        b.strict = e && e[0] == '1' ? 1 : 0;
-    }
+    b.strict = a.pb_strict;
     const size_t lds = sizeof(double) * ((size_t)p.NW * p.SR + 2 * (size_t)p.NW);
 #define CM_P2D(NWV, LPSV, DV)                                                                             \
     do {                                                                                                  \

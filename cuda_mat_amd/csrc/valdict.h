@@ -14,7 +14,7 @@ struct ValDict {
 
 // Scan the values (device array, nnz entries); when at most kDictMax distinct bit patterns occur, build the
 // dictionary and the per-entry indices.  out->n == 0 afterwards means "no dictionary" (not an error).
-int valdict_build(hipStream_t st, int64_t nnz, const double *val, ValDict *out);
+int valdict_build(hipStream_t st, const Config &cfg, int64_t nnz, const double *val, ValDict *out);
 void valdict_free(ValDict *d);
 
 }  // namespace cm

@@ -94,11 +94,10 @@ void valdict_free(ValDict *v)
     *v = ValDict();
 }
 
-int valdict_build(hipStream_t st, int64_t nnz, const double *val, ValDict *out)
+int valdict_build(hipStream_t st, const Config &cfg, int64_t nnz, const double *val, ValDict *out)
 {
     *out = ValDict();
-    const char *env = getenv("CUDAMAT_VALUE_DICT");
-    if ((env && env[0] == '0') || nnz < 4096) return CUDAMAT_OK;      // (tiny matrices live in caches anyway)
+    if (!cfg.value_dict || nnz < 4096) return CUDAMAT_OK;      // (tiny matrices live in caches anyway)
     unsigned long long *table = nullptr;
     int *flags = nullptr;
     int h[2] = {0, 0};

@@ -208,6 +208,16 @@ int         cudamat_device_count(int *count);
  * NULL to let the context create and own one.                                       */
 int cudamat_ctx_create(int device, void *stream, cudamat_ctx **out);
 int cudamat_ctx_destroy(cudamat_ctx *ctx);
+/* Switches (testing / probing; the defaults are what ships).  A context reads CUDAMAT_<NAME> from the environment ONCE,
+ * when it is created; afterwards a switch changes only through this call (name with or without the CUDAMAT_ prefix,
+ * value as it would stand in the environment).  Whatever runs on the context after the call sees the new value: set
+ * SpMV-form switches before the first use of a solver, ILU(0) ones before cudamat_solver_ilu0, loop ones before
+ * cudamat_solver_solve.  CUDAMAT_ERR_ARG for an unknown name or a value outside the option's range.  cudamat_solve and
+ * cudamat_solve_sharded (no caller-made context) read the environment per call.  cudamat_options_help(): one line per
+ * switch -- name, accepted values, meaning (the table of csrc/config.cpp).                                            */
+int cudamat_ctx_set_option(cudamat_ctx *ctx, const char *name, const char *value);
+int cudamat_ctx_reset_options(cudamat_ctx *ctx);   /* back to what a context created now would hold (defaults + environment) */
+const char *cudamat_options_help(void);
 int cudamat_ctx_sync(cudamat_ctx *ctx);
 int cudamat_ctx_stream(cudamat_ctx *ctx, void **stream);
 
@@ -283,7 +293,7 @@ int cudamat_solver_spmv_mode(cudamat_solver *s, int *mode);
 /* Value dictionary: *distinct = number of distinct fp64 bit patterns among the matrix values when the SELECTED SpMV form
  * reads 8-bit indices into a dictionary of them instead of the 8-byte values (large matrices with at most 256 distinct
  * values; results are bit-identical, HBM traffic drops by 7 bytes per entry), 0 when it reads the values themselves.
- * CUDAMAT_VALUE_DICT=0 in the environment disables the dictionary.                                                  */
+ * The switch VALUE_DICT = 0 (cudamat_ctx_set_option / CUDAMAT_VALUE_DICT in the environment) disables the dictionary. */
 int cudamat_solver_value_dict(cudamat_solver *s, int *distinct);
 /* name(s) of the HIP kernel(s) one SpMV launch of this solver runs (e.g. "k_pb_phase1 + k_pb_phase2", "k_spmv_stream_c<256>",
  * "k_spmv<32>"): what a rocprofv3 kernel trace of the loop shows, for the bench line's `roofline.kernel`            */
@@ -311,16 +321,18 @@ int cudamat_solve(int n, int nnz, const double *A, const int *iA, const int *jA,
                   int loop, int maxit, double tol, int debug, double *x,
                   cudamat_stats *st);
 
-/* The same over `ngpu` GPUs of this node, from one process: uniform row blocks, one host
+/* cudamat_solve keeps the solver of its LAST call (CSR copies, SpMV plan, ILU(0) factors: device memory on device 0 --
+ * about 16 GB at 1e7 rows x 50 entries, 50 GB with ILU(0)) so that a caller who solves with the same matrix again --
+ * time steps, several right-hand sides: the reference's per-call shape, pbicgstab.cu:157-409 -- pays the upload and a
+ * device-side comparison but no analysis.  The next call with a different matrix (or different CUDAMAT_* switches)
+ * replaces it; a call that runs out of device memory releases it and tries once more; cudamat_solve_sharded releases
+ * it before it starts; cudamat_plan_cache_clear() (or CUDAMAT_PLAN_CACHE=0 in the environment) releases / disables it.  */
+int cudamat_plan_cache_clear(void);
+
+/* The same solve over `ngpu` GPUs of this node, from one process: uniform row blocks, one host
  * thread and one RCCL rank per device (csrc/sharded.cpp).  precond: NONE or BLOCK_ILU0 (each
  * rank's diagonal block; ILU0 of the whole matrix does not shard => CUDAMAT_ERR_ARG).
  * ngpu <= 1 is cudamat_solve.  st receives rank 0's statistics (all ranks decide alike).     */
-/* cudamat_solve keeps the solver of its LAST call (CSR copies, SpMV plan, ILU(0) factors: device memory) so that a
- * caller who solves with the same matrix again -- time steps, several right-hand sides: the reference's per-call shape,
- * pbicgstab.cu:157-409 -- pays the upload and a device-side comparison but no analysis.  The next call with a different
- * matrix replaces it; cudamat_plan_cache_clear() (or CUDAMAT_PLAN_CACHE=0 in the environment) releases / disables it. */
-int cudamat_plan_cache_clear(void);
-
 int cudamat_solve_sharded(int ngpu, int n, int nnz, const double *A, const int *iA, const int *jA,
                           const double *d, const double *x0, const double *b, int precond,
                           int loop, int maxit, double tol, int debug, double *x,

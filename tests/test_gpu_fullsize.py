@@ -103,20 +103,26 @@ def test_full_size_spmv_vs_oracle(cm, kind, values, monkeypatch):
         assert np.array_equal(_bits(got), _bits(want)), "max |diff| = %g" % np.abs(got - want).max()
     s.close()
     if kind == "rand50" and values == "fp64":
-        # the one-wavefront-per-row kernel of north_star on the same matrix: exact on integer data, SURVEY 8c's bound otherwise
-        monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
-        s = cm.Solver(ctx, N, N, nnz, rp, ci, va, 0)
-        assert s.spmv_kernel() == "k_spmv<64>", s.spmv_kernel()
-        d_x.upload(x_int)
-        s.spmv(d_x, d_y)
-        assert np.array_equal(_bits(d_y.download()), _bits(O.spmv(A, x_int)))
-        d_x.upload(x_real)
-        s.spmv(d_x, d_y)
-        want = O.spmv(A, x_real)
+        # the lanes-per-row CSR kernel on the same matrix -- the plan's own choice for 50 entries per row (32 lanes) and
+        # north_star's literal one-wavefront-per-row form (64 lanes): exact on integer data, SURVEY 8c's bound otherwise
+        monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")          # (read by the contexts created below)
         absA = O.Csr(A.n, A.rowptr, A.colidx, np.abs(A.val), A.m)
         bound = 4 * 50 * np.finfo(float).eps * O.spmv(absA, np.abs(x_real))
-        assert np.all(np.abs(d_y.download() - want) <= bound)
-        s.close()
+        want_int, want_real = O.spmv(A, x_int), O.spmv(A, x_real)
+        for lanes in (None, "64"):
+            if lanes:
+                monkeypatch.setenv("CUDAMAT_SPMV_LANES", lanes)
+            c2 = cm.Context(0)
+            s = cm.Solver(c2, N, N, nnz, rp, ci, va, 0)
+            assert s.spmv_kernel() == ("k_spmv<%s>" % (lanes or "32")), s.spmv_kernel()
+            d_x.upload(x_int)
+            s.spmv(d_x, d_y)
+            assert np.array_equal(_bits(d_y.download()), _bits(want_int))
+            d_x.upload(x_real)
+            s.spmv(d_x, d_y)
+            assert np.all(np.abs(d_y.download() - want_real) <= bound)
+            s.close()
+            c2.close()
     for t in (rp, ci, va, d_x, d_y):
         t.free()
     ctx.close()
@@ -133,7 +139,7 @@ def test_full_size_spmv_properties(cm, kind, values, monkeypatch):
     ctx.gen_xstar(0, N, 8, x2)
     ys = {}
     for mode in ("csr", "pb"):
-        monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
+        ctx.set_option("SPMV_MODE", mode)
         s = cm.Solver(ctx, N, N, nnz, rp, ci, va, 0)
         assert s.spmv_mode() == (1 if mode == "pb" else 0)
         # the name the bench line's roofline.kernel carries = the kernel(s) a trace of this SpMV shows
@@ -221,7 +227,7 @@ def _host_row(h_rp, h_ci, vals, i):
     return h_ci[a:e], vals[a:e]
 
 
-def test_full_size_ilu0_c5(cm, monkeypatch):
+def test_full_size_ilu0_c5(cm):
     """BASELINE configs[4]: the 1e7 x 50 matrix with ILU(0) on one GPU (pbicgstab.cu:336-374).  The oracle cannot
     factor 5e8 entries in seconds, so: (1) sampled rows of the factor are re-eliminated on the host from A's row and
     the GPU's final pivot rows (the IKJ definition of csrilu0, row by row); (2) the dependency-driven and the
@@ -280,7 +286,7 @@ def test_full_size_ilu0_c5(cm, monkeypatch):
             acc += wk if pos == d else v[pos] * wk
         worst = max(worst, abs(acc - h_rhs[i]) / abs(h_rhs[i]))
     assert worst <= 1e-10, worst
-    monkeypatch.setenv("CUDAMAT_TRSV_SYNCFREE", "0")
+    ctx.set_option("TRSV_SYNCFREE", "0")
     s.close()
     del lu
     # the level-by-level form needs its own plans: a second solver over the same system
@@ -293,7 +299,7 @@ def test_full_size_ilu0_c5(cm, monkeypatch):
     s0.precond_apply(rhs, out0)
     np.testing.assert_array_equal(out0.download(), h_out)
     s0.close()
-    monkeypatch.delenv("CUDAMAT_TRSV_SYNCFREE")
+    ctx.reset_options()
 
     # (4) the preconditioned solve (default forms)
     rp, ci, va = ctx.array(h_rp.astype(np.int32)), ctx.array(h_ci), ctx.array(h_va)
@@ -311,26 +317,15 @@ def test_full_size_ilu0_c5(cm, monkeypatch):
     s.spmv(x, ax)
     assert np.linalg.norm(b.download() - ax.download()) <= 1e-7 * st.nrm0
     # the loop in the level-major spaces (default, used above) and the one that permutes around every application of M^-1
-    # return the same solution; and the optional form with the early far blocks on a side stream gives the same bits as
-    # the default triangular solves
+    # return the same solution
     x_perm = x.download()
-    monkeypatch.setenv("CUDAMAT_TRSV_PERM", "0")
+    ctx.set_option("TRSV_PERM", "0")
     st0 = s.solve(b, x, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PBICGSTAB, maxit=100, tol=1e-8, flags=cm.FLAG_X0_ONES)
-    monkeypatch.delenv("CUDAMAT_TRSV_PERM")
+    ctx.reset_options()
     assert st0.converged and abs(st0.iters - st.iters) <= 1
     np.testing.assert_allclose(x.download(), x_perm, rtol=1e-8)
     s.precond_apply(rhs, out1)
     h_default = out1.download()
     np.testing.assert_array_equal(h_default, h_out)               # level-major storage, same bits as at the top
     s.close()
-    monkeypatch.setenv("CUDAMAT_TRSV_OVERLAP", "1")
-    nnz2, rp, ci, va = _system(cm, ctx, "rand50")
-    s2 = cm.Solver(ctx, N, N, nnz2, rp, ci, va, 0)
-    for t in (rp, ci, va):
-        t.free()
-    s2.ilu0()
-    s2.precond_apply(rhs, out0)
-    np.testing.assert_array_equal(out0.download(), h_default)
-    s2.close()
-    monkeypatch.delenv("CUDAMAT_TRSV_OVERLAP")
     ctx.close()

@@ -27,6 +27,24 @@ def ctx(cm):
     c.close()
 
 
+@pytest.fixture
+def sw(ctx, monkeypatch):
+    """Set (value) or unset (None) a library switch for the rest of this test -- on the module's shared context
+    (cudamat_ctx_set_option: a context reads the CUDAMAT_* environment only when it is created) AND in the environment
+    (for contexts the test or the library creates later: cudamat_solve).  Afterwards the context is back to what the
+    environment outside the test says."""
+    def _sw(name, value):
+        if value is None:
+            monkeypatch.delenv("CUDAMAT_" + name, raising=False)
+            ctx.reset_options()                 # = the environment, which still holds the test's other switches
+        else:
+            monkeypatch.setenv("CUDAMAT_" + name, str(value))
+            ctx.set_option(name, value)
+    yield _sw
+    monkeypatch.undo()
+    ctx.reset_options()
+
+
 @pytest.fixture(autouse=True)
 def _serial_oracle(oracle):
     """one OpenMP thread for the checker: its `reduction(+)` dots are then summed in one fixed order,
@@ -94,12 +112,12 @@ def test_xstar_matches_oracle(ctx, oracle):
 # ------------------------------------------------------------------------ SpMV
 @pytest.mark.parametrize("name", ["mat3", "mat900", "mat10000", "rand20000x50", "poisson300x200"])
 @pytest.mark.parametrize("lanes", [None, 2, 16, 64])
-def test_spmv_bit_exact_on_integer_data(ctx, oracle, golden_dir, name, lanes, monkeypatch):
+def test_spmv_bit_exact_on_integer_data(ctx, oracle, golden_dir, name, lanes, sw):
     """integer-valued A and x: every product and partial sum is exact in fp64, so the
     result is independent of summation order => bit-exact against MatrixVectorMult
     (bicstab.cpp:69-80) for every lanes-per-row variant of the kernel."""
     if lanes:
-        monkeypatch.setenv("CUDAMAT_SPMV_LANES", str(lanes))
+        sw("SPMV_LANES", str(lanes))
     if name == "rand20000x50":
         A = oracle.rand_rows(20000, 50, 0x5EED)
     elif name == "poisson300x200":
@@ -448,11 +466,11 @@ def _spmv_via_solver(cm, ctx, A, x, d=None):
 
 
 @pytest.mark.parametrize("case", ["rand_real", "rand_int_base1", "poisson", "ragged", "tiny"])
-def test_blocked_spmv_is_bit_exact(cm, ctx, oracle, case, monkeypatch):
+def test_blocked_spmv_is_bit_exact(cm, ctx, oracle, case, sw):
     """the two-phase kernels (csrc/spmv_pb.hip) add each row's products in increasing column order,
     one rounding per product and per addition: the SAME sequence of roundings as the reference CPU
     loop b[i] += A.Value[j] * x[A.Col[j]] (bicstab.cpp:72-77) => bit-exact even on real-valued data."""
-    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "pb")
+    sw("SPMV_MODE", "pb")
     rng = np.random.default_rng(9)
     if case == "rand_real":
         A = oracle.rand_rows(20000, 50, 0x5EED)
@@ -481,19 +499,15 @@ def test_blocked_spmv_is_bit_exact(cm, ctx, oracle, case, monkeypatch):
     # architected.  Both must reproduce the reference loop bit for bit (the 20000-column cases have runs of ~25 equal rows
     # per step, the dense row of `ragged` runs that cross the 64-entry cut): this is the guard of the observed property.
     for strict in ("0", "1"):
-        monkeypatch.setenv("CUDAMAT_PB_STRICT", strict)
+        sw("PB_STRICT", strict)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
         d = rng.standard_normal(A.n)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
-    # the layout with the column blocks packed back to back (default: every block starts on a 128-byte line boundary)
-    monkeypatch.setenv("CUDAMAT_PB_STRICT", "0")
-    monkeypatch.setenv("CUDAMAT_PB_ALIGN", "1")
-    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
 
 
-def test_blocked_spmv_in_the_solver_loop(cm, ctx, oracle, golden_dir, monkeypatch):
+def test_blocked_spmv_in_the_solver_loop(cm, ctx, oracle, golden_dir, sw):
     """same solves as above with the blocked kernels forced: fused dots, freeze prologue, ILU path"""
-    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "pb")
+    sw("SPMV_MODE", "pb")
     A = oracle.rand_rows(20000, 50, 0x5EED)
     xs = oracle.xstar(20000, 0x5EEE)
     b = oracle.spmv(A, xs)
@@ -568,7 +582,7 @@ def test_degenerate_systems(cm, ctx, oracle):
 
 # ------------------------------------------------- randomized shapes through every SpMV form
 @pytest.mark.parametrize("seed", range(12))
-def test_spmv_random_shapes_all_forms(cm, ctx, oracle, seed, monkeypatch):
+def test_spmv_random_shapes_all_forms(cm, ctx, oracle, seed, sw):
     """random rectangular-free CSR shapes (ragged rows, empty rows, 0/1 base) through the lanes-per-row,
     the LDS-staged stream and the blocked two-phase kernels: integer data => all bit-exact vs the oracle"""
     import scipy.sparse as sp
@@ -587,20 +601,20 @@ def test_spmv_random_shapes_all_forms(cm, ctx, oracle, seed, monkeypatch):
     want = oracle.spmv(A, x)
     want_d = oracle.csrmv(A, 1.0, x, 1.0, x * d)
     for mode in ("csr", "pb", "sell"):
-        monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
+        sw("SPMV_MODE", mode)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), want_d)
-    monkeypatch.delenv("CUDAMAT_SPMV_MODE")
+    sw("SPMV_MODE", None)
     for lanes in ("4", "32"):
-        monkeypatch.setenv("CUDAMAT_SPMV_LANES", lanes)     # forces the lanes-per-row kernel (no stream tiles)
+        sw("SPMV_LANES", lanes)     # forces the lanes-per-row kernel (no stream tiles)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
 
 
 @pytest.mark.parametrize("name", ["rand20000x50", "real3000", "mat10000"])
-def test_hybrid_triangular_solve_vs_oracle(cm, ctx, oracle, golden_dir, name, monkeypatch):
+def test_hybrid_triangular_solve_vs_oracle(cm, ctx, oracle, golden_dir, name, sw):
     """the group-split triangular solve (far entries through the blocked SpMV, near entries through the
     level kernels; csrc/ilu.hip split_factor) forced on small systems: same L^-1 U^-1 as the oracle"""
-    monkeypatch.setenv("CUDAMAT_TRSV_HYBRID", "1")
+    sw("TRSV_HYBRID", "1")
     if name == "rand20000x50":
         A = oracle.rand_rows(20000, 50, 0x5EED)
     elif name == "real3000":
@@ -628,13 +642,13 @@ def test_hybrid_triangular_solve_vs_oracle(cm, ctx, oracle, golden_dir, name, mo
 
 
 @pytest.mark.parametrize("name", ["rand20000x50", "real3000", "mat10000"])
-def test_loop_in_level_major_spaces_matches_the_permuting_loop(cm, ctx, oracle, golden_dir, name, monkeypatch):
+def test_loop_in_level_major_spaces_matches_the_permuting_loop(cm, ctx, oracle, golden_dir, name, sw):
     """hybrid factors live in level-major index spaces; the reference loop then runs with its residual-side vectors in
     L's order, its solution-side vectors in U's, and A stored with rows in L's order and columns in U's positions (no
     vector is permuted inside the loop).  Same mathematics as the loop that permutes around every M^-1 application
     (CUDAMAT_TRSV_PERM=0): same iteration count (+-1: the dot products are summed in another order), solutions equal to
     1e-9, histories to 1e-8 over the first iterations; both agree with the oracle (solution 1e-5, count +-10 %)."""
-    monkeypatch.setenv("CUDAMAT_TRSV_HYBRID", "1")
+    sw("TRSV_HYBRID", "1")
     if name == "rand20000x50":
         A = oracle.rand_rows(20000, 50, 0x5EED)
     elif name == "real3000":
@@ -647,7 +661,7 @@ def test_loop_in_level_major_spaces_matches_the_permuting_loop(cm, ctx, oracle, 
     xo, so, ho = oracle.pbicgstab(A, b, x0=x0, vm=oracle.ilu0(A), maxit=500, tol=1e-8, want_hist=True)
     res = {}
     for perm in ("1", "0"):
-        monkeypatch.setenv("CUDAMAT_TRSV_PERM", perm)
+        sw("TRSV_PERM", perm)
         res[perm] = _solve_dev(cm, ctx, A, b, x0=x0, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PBICGSTAB, maxit=500, tol=1e-8)
     (x1, st1, h1), (x0_, st0, h0) = res["1"], res["0"]
     assert st1.converged and st0.converged and abs(st1.iters - st0.iters) <= 1
@@ -678,7 +692,7 @@ def _chain_matrix(oracle, n, width, seed):
 
 @pytest.mark.parametrize("name", ["chain3000", "poisson160x90", "rand20000x50", "rand20000x50_hybrid", "longrows",
                                   "mat10000"])
-def test_dependency_driven_trsv_equals_level_solve(cm, ctx, oracle, golden_dir, name, monkeypatch):
+def test_dependency_driven_trsv_equals_level_solve(cm, ctx, oracle, golden_dir, name, sw):
     """k_trsv_syncfree (one launch per group, rows wait for their dependencies' values) against the
     level-by-level kernels on the same factors: every row is summed by the same lanes in the same order,
     so L^-1 U^-1 must be BIT-identical -- deep chains inside one wavefront (chain3000: every row waits for
@@ -693,17 +707,14 @@ def test_dependency_driven_trsv_equals_level_solve(cm, ctx, oracle, golden_dir, 
         A = _real_sparse(oracle, 400, 0.6, 5)
     else:
         A = _load(oracle, golden_dir, name)
-    monkeypatch.setenv("CUDAMAT_TRSV_HYBRID", "1" if name.endswith("hybrid") else "0")
+    sw("TRSV_HYBRID", "1" if name.endswith("hybrid") else "0")
     if name.endswith("hybrid"):
-        # (also the optional form that runs the early column blocks of a group's far phase 1 on a side stream, beside the
-        # previous group's dependency-driven launch: same data, same order of additions => the same bits)
-        monkeypatch.setenv("CUDAMAT_TRSV_OVERLAP", "1")
-        monkeypatch.setenv("CUDAMAT_TRSV_GROUPS", "5")
+        sw("TRSV_GROUPS", "5")
     rng = np.random.default_rng(4)
     rhs = [rng.standard_normal(A.n) for _ in range(3)]
     got = {}
     for form in ("0", "1"):
-        monkeypatch.setenv("CUDAMAT_TRSV_SYNCFREE", form)
+        sw("TRSV_SYNCFREE", form)
         s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
         s.ilu0()
         outs = []
@@ -726,7 +737,7 @@ def test_dependency_driven_trsv_equals_level_solve(cm, ctx, oracle, golden_dir, 
     np.testing.assert_allclose(got["1"][0], ref, rtol=1e-10, atol=1e-12)
 
 
-def test_spmv_skewed_rows(cm, ctx, oracle, monkeypatch):
+def test_spmv_skewed_rows(cm, ctx, oracle, sw):
     """a few rows with tens of thousands of entries among short ones: the lanes-per-row
     kernel hands them to the whole workgroup; results stay exact, the fused dots stay right"""
     import scipy.sparse as sp
@@ -749,16 +760,16 @@ def test_spmv_skewed_rows(cm, ctx, oracle, monkeypatch):
     dx, dy = ctx.array(x), ctx.empty(n)
     for lanes in (None, "4", "64"):
         if lanes:
-            monkeypatch.setenv("CUDAMAT_SPMV_LANES", lanes)
+            sw("SPMV_LANES", lanes)
         dy.zero()
         ctx.spmv(n, rp, ci, v, 0, dx, dy)
         np.testing.assert_array_equal(dy.download(), want)
-    monkeypatch.delenv("CUDAMAT_SPMV_LANES")
+    sw("SPMV_LANES", None)
     for mode in ("csr", "pb"):
-        monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
+        sw("SPMV_MODE", mode)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
     # inside a solve (fused dot partials include the long rows): make the system dominant and solve it
-    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
+    sw("SPMV_MODE", "csr")
     S2 = (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() + 1.0)).tocsr()
     S2.sort_indices()
     A2 = oracle.Csr(n, S2.indptr.astype(np.int32), S2.indices.astype(np.int32), S2.data.astype(np.float64), n)
@@ -773,7 +784,7 @@ def test_spmv_skewed_rows(cm, ctx, oracle, monkeypatch):
     np.testing.assert_allclose(xg, xs, rtol=1e-6)
 
 
-def test_trsv_timeout_redoes_the_solve_with_level_kernels(cm, ctx, oracle, monkeypatch):
+def test_trsv_timeout_redoes_the_solve_with_level_kernels(cm, ctx, oracle, sw):
     """a dependency-driven triangular solve whose wait times out (here: an absurdly small spin limit on a matrix
     whose rows form one long chain) must not produce an answer: the solve is redone from x0 with the
     level-by-level kernels, which then stay selected; results equal the level-only run bit for bit"""
@@ -783,9 +794,9 @@ def test_trsv_timeout_redoes_the_solve_with_level_kernels(cm, ctx, oracle, monke
     x0 = np.full(A.n, 0.5)
     res = {}
     for form, limit in (("0", None), ("1", "1")):
-        monkeypatch.setenv("CUDAMAT_TRSV_SYNCFREE", form)
+        sw("TRSV_SYNCFREE", form)
         if limit:
-            monkeypatch.setenv("CUDAMAT_TRSV_SPIN_LIMIT", limit)
+            sw("TRSV_SPIN_LIMIT", limit)
         s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
         s.ilu0()
         assert s.trsv_form() == int(form)
@@ -793,7 +804,7 @@ def test_trsv_timeout_redoes_the_solve_with_level_kernels(cm, ctx, oracle, monke
         st = s.solve(db, dx, precond=cm.PRECOND_ILU0, maxit=100, tol=1e-10)       # caller's x0 (no X0_ONES flag)
         res[form] = (dx.download(), st.iters, st.converged, s.trsv_form(), st.trsv_fallbacks, st.trsv_form)
         s.close()
-    monkeypatch.delenv("CUDAMAT_TRSV_SPIN_LIMIT")
+    sw("TRSV_SPIN_LIMIT", None)
     assert res["1"][3] == 0, "the timeout should have switched the solver to the level kernels"
     # the redo is reported, not hidden: one fallback, and the stats name the form the solve ended with
     assert res["0"][4] == 0 and res["1"][4] == 1
@@ -838,7 +849,7 @@ def _skewed_matrix(oracle, kind, rng):
 
 
 @pytest.mark.parametrize("kind", ["pareto", "hubs", "empties", "mixed"])
-def test_spmv_nnz_balanced_tiles(cm, ctx, oracle, kind, monkeypatch):
+def test_spmv_nnz_balanced_tiles(cm, ctx, oracle, kind, sw):
     """k_spmv_tiles / k_spmv_tiles_fix (tiles of 2048 ENTRIES; rows spanning tiles finished from head / tail
     partials): exact on integer data for every row-length pathology -- standalone entry point with alpha, beta
     and the diagonal term, solver entry point, base 0 and 1, auto-selected and forced"""
@@ -852,7 +863,7 @@ def test_spmv_nnz_balanced_tiles(cm, ctx, oracle, kind, monkeypatch):
     want_full = oracle.csrmv(A, 2.0, x, -1.0, y0.copy() * 1.0)          # y = 2 A x - y0
     for form in (None, "tiles", "lanes"):
         if form:
-            monkeypatch.setenv("CUDAMAT_SPMV_FORM", form)
+            sw("SPMV_FORM", form)
         for base in (0, 1):
             rp, ci, v = ctx.array((A.rowptr + base).astype(np.int32)), ctx.array((A.colidx + base).astype(np.int32)), ctx.array(A.val)
             dx, dy = ctx.array(x), ctx.array(y0)
@@ -861,13 +872,13 @@ def test_spmv_nnz_balanced_tiles(cm, ctx, oracle, kind, monkeypatch):
             dy.zero()
             ctx.spmv(n, rp, ci, v, base, dx, dy, d=ctx.array(d))
             np.testing.assert_array_equal(dy.download(), want + d * x)
-        monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
+        sw("SPMV_MODE", "csr")
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
-        monkeypatch.delenv("CUDAMAT_SPMV_MODE")
-    monkeypatch.delenv("CUDAMAT_SPMV_FORM")
+        sw("SPMV_MODE", None)
+    sw("SPMV_FORM", None)
 
 
-def test_solve_with_tile_spmv(cm, ctx, oracle, monkeypatch):
+def test_solve_with_tile_spmv(cm, ctx, oracle, sw):
     """the fused dot partials of the tile kernels (main launch + the launch that finishes spanning rows) inside
     the BiCGSTAB loop: same iterates as the oracle"""
     import scipy.sparse as sp
@@ -879,8 +890,8 @@ def test_solve_with_tile_spmv(cm, ctx, oracle, monkeypatch):
     A2 = oracle.Csr(A.n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), A.n)
     xs = oracle.xstar(A.n, 5)
     b = oracle.spmv(A2, xs)
-    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
-    monkeypatch.setenv("CUDAMAT_SPMV_FORM", "tiles")
+    sw("SPMV_MODE", "csr")
+    sw("SPMV_FORM", "tiles")
     xg, st, h = _solve_dev(cm, ctx, A2, b, loop=cm.LOOP_PBICGSTAB, maxit=200, tol=1e-10)
     xo, so, ho = oracle.pbicgstab(A2, b, maxit=200, tol=1e-10, want_hist=True)
     assert st.converged and so.converged and abs(st.iters - so.iters) <= max(3, 0.3 * so.iters)
@@ -888,7 +899,7 @@ def test_solve_with_tile_spmv(cm, ctx, oracle, monkeypatch):
     np.testing.assert_allclose(xg, xs, rtol=1e-6)
 
 
-def test_solver_validates_its_csr(cm, ctx, oracle, monkeypatch):
+def test_solver_validates_its_csr(cm, ctx, oracle, sw):
     """malformed inputs become CUDAMAT_ERR_ARG at creation (never a stray device access); rows with unsorted
     columns are accepted by the un-preconditioned path and refused by ILU(0) and by the blocked SpMV"""
     A = oracle.rand_rows(5000, 12, 3)
@@ -918,7 +929,7 @@ def test_solver_validates_its_csr(cm, ctx, oracle, monkeypatch):
         s.ilu0()
     assert e.value.code == 2
     s.close()
-    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "pb")
+    sw("SPMV_MODE", "pb")
     s = cm.Solver.from_host_csr(ctx, A.rowptr, ci, v)
     with pytest.raises(cm.CudamatError) as e:
         s.spmv(dx, dy)
@@ -927,7 +938,7 @@ def test_solver_validates_its_csr(cm, ctx, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["mat10000", "rand20000x50", "longrows"])
-def test_ilu0_prefetching_kernel_equals_simple_kernel(cm, ctx, oracle, golden_dir, name, monkeypatch):
+def test_ilu0_prefetching_kernel_equals_simple_kernel(cm, ctx, oracle, golden_dir, name, sw):
     """k_ilu0_level_fast (columns, pivot table and next pivot row staged / prefetched) performs the same
     updates in the same order as k_ilu0_level: bit-identical factors; both within 1e-12 of the oracle"""
     if name == "rand20000x50":
@@ -938,7 +949,7 @@ def test_ilu0_prefetching_kernel_equals_simple_kernel(cm, ctx, oracle, golden_di
         A = _load(oracle, golden_dir, name)
     got = []
     for simple in ("0", "1"):
-        monkeypatch.setenv("CUDAMAT_ILU0_SIMPLE", simple)
+        sw("ILU0_SIMPLE", simple)
         s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
         s.ilu0()
         got.append(s.ilu0_values())
@@ -948,7 +959,7 @@ def test_ilu0_prefetching_kernel_equals_simple_kernel(cm, ctx, oracle, golden_di
 
 
 @pytest.mark.parametrize("name", ["mat900", "mat10000", "chain3000", "longrows", "rand9000x30"])
-def test_lds_resident_trsv_equals_level_kernels(cm, ctx, oracle, golden_dir, name, monkeypatch):
+def test_lds_resident_trsv_equals_level_kernels(cm, ctx, oracle, golden_dir, name, sw):
     """k_trsv_lds (n <= 16384: one workgroup, solution vector in LDS, next level's operands prefetched across the
     barrier) against the level kernels with the vector in global memory: bit-identical L^-1 U^-1, and both within
     1e-10 of the oracle's substitutions"""
@@ -960,12 +971,12 @@ def test_lds_resident_trsv_equals_level_kernels(cm, ctx, oracle, golden_dir, nam
         A = oracle.rand_rows(9000, 30, 77)          # levels of ~100-300 rows: several rows per team and level
     else:
         A = _load(oracle, golden_dir, name)
-    monkeypatch.setenv("CUDAMAT_TRSV_SYNCFREE", "0")
+    sw("TRSV_SYNCFREE", "0")
     rng = np.random.default_rng(8)
     rhs = [rng.standard_normal(A.n) for _ in range(2)]
     got = {}
     for lds in ("0", "1"):
-        monkeypatch.setenv("CUDAMAT_TRSV_LDS", lds)
+        sw("TRSV_LDS", lds)
         s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
         s.ilu0()
         outs = []
@@ -983,7 +994,7 @@ def test_lds_resident_trsv_equals_level_kernels(cm, ctx, oracle, golden_dir, nam
 
 
 @pytest.mark.parametrize("case", ["poisson300x210", "banded_ragged", "too_wide", "long_row_255", "base1"])
-def test_stream_spmv_with_compressed_indices(cm, ctx, oracle, case, monkeypatch):
+def test_stream_spmv_with_compressed_indices(cm, ctx, oracle, case, sw):
     """k_spmv_stream_c (16-bit column offsets from the tile's first row, 8-bit row lengths) = k_spmv_stream bit for
     bit, and exact against the oracle on integer data; matrices whose offsets do not fit keep the plain kernel"""
     import scipy.sparse as sp
@@ -1022,13 +1033,13 @@ def test_stream_spmv_with_compressed_indices(cm, ctx, oracle, case, monkeypatch)
     # plain stream kernel; compressed indices + value dictionary (k_spmv_stream_d); compressed indices on the fp64 values
     # with the line-aligned copies of the two entry streams (k_spmv_stream_c, plan_spmv_align) and with the packed arrays
     for comp, vdict, align in (("0", "1", "1"), ("1", "1", "1"), ("1", "0", "1"), ("1", "0", "0")):
-        monkeypatch.setenv("CUDAMAT_SPMV_COMPRESS", comp)
-        monkeypatch.setenv("CUDAMAT_VALUE_DICT", vdict)
-        monkeypatch.setenv("CUDAMAT_SPMV_ALIGN", align)
-        monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
+        sw("SPMV_COMPRESS", comp)
+        sw("VALUE_DICT", vdict)
+        sw("SPMV_ALIGN", align)
+        sw("SPMV_MODE", "csr")
         got[comp + vdict + align] = (_spmv_via_solver(cm, ctx, A, x), _spmv_via_solver(cm, ctx, A, x, d=d))
-    monkeypatch.delenv("CUDAMAT_VALUE_DICT")
-    monkeypatch.delenv("CUDAMAT_SPMV_ALIGN")
+    sw("VALUE_DICT", None)
+    sw("SPMV_ALIGN", None)
     for comp in got:
         np.testing.assert_array_equal(got[comp][0], want)
         np.testing.assert_array_equal(got[comp][1], want + d * x)
@@ -1037,7 +1048,7 @@ def test_stream_spmv_with_compressed_indices(cm, ctx, oracle, case, monkeypatch)
         b = oracle.spmv(A, 1.0 + np.sin(np.arange(A.n)))
         hist = []
         for comp in ("0", "1"):
-            monkeypatch.setenv("CUDAMAT_SPMV_COMPRESS", comp)
+            sw("SPMV_COMPRESS", comp)
             xg, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=400, tol=1e-8)
             assert st.converged
             hist.append((xg, h))
@@ -1077,7 +1088,7 @@ def test_ilu0_very_long_rows(cm, ctx, oracle, n, longest):
 
 @pytest.mark.parametrize("name", ["mat900", "mat10000", "rand3000x40", "tiny5"])
 @pytest.mark.parametrize("loop", ["pbicgstab", "pbicgstab2_d"])
-def test_fused_small_system_loop_equals_five_launch_loop(cm, ctx, oracle, golden_dir, name, loop, monkeypatch):
+def test_fused_small_system_loop_equals_five_launch_loop(cm, ctx, oracle, golden_dir, name, loop, sw):
     """three launches per iteration (vector updates folded into the SpMVs, csrc/kernels.hip 'fused loop') against
     the five-launch loop: same expressions element by element, only ||s||^2 is summed per SpMV workgroup instead of
     per vector chunk; both forms (stream tiles / lanes per row), both loops, with and without the diagonal shift"""
@@ -1096,10 +1107,10 @@ def test_fused_small_system_loop_equals_five_launch_loop(cm, ctx, oracle, golden
         kw = dict(loop=cm.LOOP_PBICGSTAB2, maxit=400, tol=1e-9)
     b = oracle.spmv(A, xs) + (d * xs if d is not None else 0.0)
     res = {}
-    monkeypatch.setenv("CUDAMAT_RESIDENT", "0")      # (the single-launch form of the same loop has its own test below)
+    sw("RESIDENT", "0")      # (the single-launch form of the same loop has its own test below)
     for fused in ("0", "1000000"):
-        monkeypatch.setenv("CUDAMAT_FUSED", fused)
-        monkeypatch.setenv("CUDAMAT_SPMV_MODE", "csr")
+        sw("FUSED", fused)
+        sw("SPMV_MODE", "csr")
         x, st, h = _solve_dev(cm, ctx, A, b, d=d, **kw)
         res[fused] = (x, st, h)
     (x0, st0, h0), (x1, st1, h1) = res["0"], res["1000000"]
@@ -1180,27 +1191,27 @@ def test_pipelined_bicgstab_vs_oracle(cm, ctx, oracle, golden_dir, name, tol):
     assert np.linalg.norm(x - x2) / np.linalg.norm(x2) <= 1e-5
 
 
-def test_half_step_update_of_x_rides_in_the_full_step_kernel(cm, ctx, oracle, golden_dir, monkeypatch):
+def test_half_step_update_of_x_rides_in_the_full_step_kernel(cm, ctx, oracle, golden_dir, sw):
     """the five-launch reference loop leaves pbicgstab.cu:110 (x += alpha p) to k_full of the same iteration, and to one
-    axpy after the loop when the solve leaves through the half-step test; CUDAMAT_DEFER_X=0 does it in k_half as the
-    reference orders it.  Same operations on the same operands: solutions and histories must be bit-identical, through
-    both exits, with and without ILU(0), and equal to the oracle's within its tolerance."""
-    monkeypatch.setenv("CUDAMAT_FUSED", "0")                # the five-launch form also on small systems
-    monkeypatch.setenv("CUDAMAT_RESIDENT", "0")
+    axpy after the loop when the solve leaves through the half-step test (x is then streamed once per iteration).  Same
+    operations on the same operands as the reference's two updates: through both exits, with and without ILU(0), the
+    iterate must be the oracle's (same iteration count, same exit, x to 1e-9) and the residual the loop reports must be
+    the TRUE residual of the x it returns -- an update of x that was dropped or applied twice on either exit would show
+    there at once.  (Round 3 kept the two-pass form as a switch and compared the two bit for bit; it was removed in
+    round 4.)"""
+    sw("FUSED", "0")                # the five-launch form also on small systems
+    sw("RESIDENT", "0")
     A = oracle.rand_rows(5000, 12, 7)
     xs = oracle.xstar(A.n, 3)
     b = oracle.spmv(A, xs)
     seen_half = seen_full = False
     for precond in (cm.PRECOND_NONE, cm.PRECOND_ILU0):
         for tol in (1e-3, 1e-5, 1e-7, 1e-8, 1e-11):
-            got = {}
-            for defer in ("1", "0"):
-                monkeypatch.setenv("CUDAMAT_DEFER_X", defer)
-                got[defer] = _solve_dev(cm, ctx, A, b, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=100, tol=tol)
-            (x1, st1, h1), (x0, st0, h0) = got["1"], got["0"]
-            assert st1.converged and (st1.iters, st1.half_exit) == (st0.iters, st0.half_exit)
-            np.testing.assert_array_equal(x1, x0)
-            np.testing.assert_array_equal(h1, h0)
+            x1, st1, h1 = _solve_dev(cm, ctx, A, b, precond=precond, loop=cm.LOOP_PBICGSTAB, maxit=100, tol=tol)
+            assert st1.converged and st1.loop_form == 0
+            r_true = np.linalg.norm(b - oracle.spmv(A, x1))
+            assert abs(r_true - st1.nrm) <= 1e-10 * st1.nrm0, (tol, r_true, st1.nrm)
+            assert st1.nrm == h1[-1]
             xo, so = oracle.pbicgstab(A, b, vm=oracle.ilu0(A) if precond else None, maxit=100, tol=tol)
             assert (st1.iters, st1.half_exit) == (so.iters, so.half_exit), (tol, st1.iters, so.iters)
             np.testing.assert_allclose(x1, xo, rtol=1e-9, atol=1e-12)
@@ -1294,11 +1305,11 @@ def test_residual_replacement_keeps_the_pipelined_loop_on_the_true_residual(cm, 
 
 # ------------------------------------------------------------- SELL-C-sigma
 @pytest.mark.parametrize("case", ["rand_real", "poisson_real", "pareto", "hubs", "empties", "mixed", "tiny", "window_edge"])
-def test_sell_spmv_is_bit_exact(cm, ctx, oracle, case, monkeypatch):
+def test_sell_spmv_is_bit_exact(cm, ctx, oracle, case, sw):
     """SELL-64-1024 (csrc/spmv_sell.hip): one lane per row, products added in column order with one rounding each =
     the rounding sequence of bicstab.cpp:72-77 => bit-exact vs the oracle on REAL-valued data, whatever the row
     lengths; padding slots are never multiplied, so an Inf in x only reaches the rows that reference it"""
-    monkeypatch.setenv("CUDAMAT_SPMV_MODE", "sell")
+    sw("SPMV_MODE", "sell")
     rng = np.random.default_rng(21)
     if case == "rand_real":
         A = oracle.rand_rows(20000, 50, 0x5EED)
@@ -1317,7 +1328,7 @@ def test_sell_spmv_is_bit_exact(cm, ctx, oracle, case, monkeypatch):
     # architected.  Both must reproduce the reference loop bit for bit (the 20000-column cases have runs of ~25 equal rows
     # per step, the dense row of `ragged` runs that cross the 64-entry cut): this is the guard of the observed property.
     for strict in ("0", "1"):
-        monkeypatch.setenv("CUDAMAT_PB_STRICT", strict)
+        sw("PB_STRICT", strict)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
         d = rng.standard_normal(A.n)
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
@@ -1331,7 +1342,7 @@ def test_sell_spmv_is_bit_exact(cm, ctx, oracle, case, monkeypatch):
     assert np.all(np.isfinite(y2[untouched])) and not np.any(np.isfinite(y2[rows]))
 
 
-def test_sell_in_the_solver_loop_and_auto_selection(cm, ctx, oracle, monkeypatch):
+def test_sell_in_the_solver_loop_and_auto_selection(cm, ctx, oracle, sw):
     """(a) forced: the BiCGSTAB loop on the SELL form (fused dot partials, half-step test launch) reproduces the CSR
     run's iterates to rounding and the oracle's solution; (b) not forced: on a matrix with varying row lengths
     the tuner times SELL against the CSR forms and keeps the faster one -- either way the result is the oracle's."""
@@ -1354,9 +1365,9 @@ def test_sell_in_the_solver_loop_and_auto_selection(cm, ctx, oracle, monkeypatch
     res = {}
     for mode in ("sell", "csr", None):
         if mode:
-            monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
+            sw("SPMV_MODE", mode)
         else:
-            monkeypatch.delenv("CUDAMAT_SPMV_MODE")
+            sw("SPMV_MODE", None)
         s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
         chosen = s.spmv_mode()
         assert s.spmv_kernel() == "k_spmv_sell" if chosen == 2 else s.spmv_kernel().startswith("k_spmv")
@@ -1478,7 +1489,7 @@ def test_a_failing_rank_does_not_strand_its_peers(cm, oracle, golden_dir, monkey
     assert ok
 
 
-def test_single_launch_loop_matches_the_three_launch_loop(cm, ctx, oracle, golden_dir, monkeypatch):
+def test_single_launch_loop_matches_the_three_launch_loop(cm, ctx, oracle, golden_dir, sw):
     """systems of at most one stream tile per compute unit run the whole loop in ONE launch (grid barriers between
     the phases, cudamat_stats.loop_form == 2): same stopping decisions and iterates as one launch per phase"""
     for name, loop, tol in (("mat10000", cm.LOOP_PBICGSTAB, 1e-8), ("mat900", cm.LOOP_PBICGSTAB, 1e-8),
@@ -1488,7 +1499,7 @@ def test_single_launch_loop_matches_the_three_launch_loop(cm, ctx, oracle, golde
         b = oracle.spmv(A, xs)
         res = {}
         for resident in ("1", "0"):
-            monkeypatch.setenv("CUDAMAT_RESIDENT", resident)
+            sw("RESIDENT", resident)
             s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
             db, dx = ctx.array(b), ctx.empty(A.n)
             st = s.solve(db, dx, loop=loop, maxit=2000, tol=tol, flags=cm.FLAG_X0_ONES)
@@ -1515,7 +1526,7 @@ def test_single_launch_loop_matches_the_three_launch_loop(cm, ctx, oracle, golde
     b = oracle.spmv(A, xs) + d * xs
     out = {}
     for resident in ("1", "0"):
-        monkeypatch.setenv("CUDAMAT_RESIDENT", resident)
+        sw("RESIDENT", resident)
         x, st, h = _solve_dev(cm, ctx, A, b, d=d, loop=cm.LOOP_PBICGSTAB2, maxit=400, tol=1e-9)
         out[resident] = (x, st, h)
     assert (out["1"][1].loop_form, out["0"][1].loop_form) == (2, 1)
@@ -1525,7 +1536,7 @@ def test_single_launch_loop_matches_the_three_launch_loop(cm, ctx, oracle, golde
     # fixed iteration windows (the bench's mode): exactly maxit iterations, odd and even, also across launch chunks
     A = _load(oracle, golden_dir, "mat10000")
     b = oracle.spmv(A, 1.0 + np.sin(np.arange(A.n)))
-    monkeypatch.setenv("CUDAMAT_RESIDENT", "1")
+    sw("RESIDENT", "1")
     s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
     db, dx = ctx.array(b), ctx.empty(A.n)
     for maxit in (1, 2, 7, 8193):
@@ -1534,27 +1545,27 @@ def test_single_launch_loop_matches_the_three_launch_loop(cm, ctx, oracle, golde
     s.close()
 
 
-def test_single_launch_loop_timeout_redoes_the_solve(cm, ctx, oracle, golden_dir, monkeypatch):
+def test_single_launch_loop_timeout_redoes_the_solve(cm, ctx, oracle, golden_dir, sw):
     """a grid barrier whose wait runs into its bound (forced here: a bound of one poll) voids the attempt: the solve
     is redone from the caller's x0 with one launch per phase, the solver stays with that form, the stats say so"""
     A = _load(oracle, golden_dir, "mat10000")
     xs = 1.0 + np.sin(np.arange(A.n))
     b = oracle.spmv(A, xs)
     x0 = np.full(A.n, 0.25)
-    monkeypatch.setenv("CUDAMAT_RESIDENT", "0")
+    sw("RESIDENT", "0")
     s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
     db, dx = ctx.array(b), ctx.array(x0)
     ref = s.solve(db, dx, maxit=2000, tol=1e-8)
     xref = dx.download()
     s.close()
-    monkeypatch.setenv("CUDAMAT_RESIDENT", "1")
-    monkeypatch.setenv("CUDAMAT_RESIDENT_SPIN_LIMIT", "0")
+    sw("RESIDENT", "1")
+    sw("RESIDENT_SPIN_LIMIT", "0")
     s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
     dx2 = ctx.array(x0)
     st = s.solve(db, dx2, maxit=2000, tol=1e-8)
     assert st.loop_fallbacks == 1 and st.loop_form == 1 and st.converged and st.iters == ref.iters
     np.testing.assert_array_equal(dx2.download(), xref)
-    monkeypatch.delenv("CUDAMAT_RESIDENT_SPIN_LIMIT")
+    sw("RESIDENT_SPIN_LIMIT", None)
     dx3 = ctx.array(x0)
     st = s.solve(db, dx3, maxit=2000, tol=1e-8)          # the solver keeps to the three-launch loop
     assert st.loop_fallbacks == 1 and st.loop_form == 1
@@ -1562,7 +1573,7 @@ def test_single_launch_loop_timeout_redoes_the_solve(cm, ctx, oracle, golden_dir
     s.close()
 
 
-def test_value_dictionary_is_bit_exact(cm, ctx, oracle, monkeypatch):
+def test_value_dictionary_is_bit_exact(cm, ctx, oracle, sw):
     """matrices with at most 256 distinct values: the blocked kernels and the compressed stream kernel read 8-bit
     indices into a dictionary of the distinct bit patterns (csrc/valdict.hip) -- same doubles, same order, so the
     products are bit-identical to the run on the fp64 values and to the oracle; 257 distinct values: no dictionary"""
@@ -1589,8 +1600,8 @@ def test_value_dictionary_is_bit_exact(cm, ctx, oracle, monkeypatch):
         want = oracle.spmv(A, x)
         got = {}
         for vd in ("1", "0"):
-            monkeypatch.setenv("CUDAMAT_VALUE_DICT", vd)
-            monkeypatch.setenv("CUDAMAT_SPMV_MODE", mode)
+            sw("VALUE_DICT", vd)
+            sw("SPMV_MODE", mode)
             s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
             dx, dy = ctx.array(x), ctx.empty(n)
             s.spmv(dx, dy)
@@ -1638,7 +1649,7 @@ def _soak_case(oracle, seed, want):
     return A, xs, oracle.spmv(A, xs)
 
 
-def test_pipelined_loop_verifies_its_iterate(cm, ctx, oracle, monkeypatch):
+def test_pipelined_loop_verifies_its_iterate(cm, ctx, oracle, sw):
     """the pipelined loop's recurrences drift: on this system (case 41 of `tests/soak.py 21`: 11 881 rows of Pareto
     lengths with three hub rows) the recursive residual of the loop WITHOUT residual replacement passes a 1e-9 test after
     319 iterations while the true one is 5.6e-3.  Two defences: (1) residual replacement every 32 iterations (the
@@ -1658,10 +1669,10 @@ def test_pipelined_loop_verifies_its_iterate(cm, ctx, oracle, monkeypatch):
     assert np.linalg.norm(b - oracle.spmv(A, x)) <= 2.5 * tol * st.nrm0
     np.testing.assert_allclose(x, xs, rtol=1e-6)
     # (2) without: the verify-and-restart rule still makes 'converged' mean what it means for the other loops
-    monkeypatch.setenv("CUDAMAT_PIPE_RR", "0")
+    sw("PIPE_RR", "0")
     xo, so = oracle.pipelined_bicgstab(A, b, maxit=1000, tol=tol, rr=0)
     x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PIPELINED, maxit=1000, tol=tol)
-    monkeypatch.delenv("CUDAMAT_PIPE_RR")
+    sw("PIPE_RR", None)
     assert st.converged and so.converged
     assert np.linalg.norm(b - oracle.spmv(A, x)) <= 2.5 * tol * st.nrm0          # twice the target is the acceptance bound
     assert np.linalg.norm(b - oracle.spmv(A, xo)) <= 2.5 * tol * so.nrm0
@@ -1672,3 +1683,44 @@ def test_pipelined_loop_verifies_its_iterate(cm, ctx, oracle, monkeypatch):
     # the standard loop on the same system needs no such help
     x1, st1, _ = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=1000, tol=tol)
     assert st1.converged and st1.restarts == 0 and np.linalg.norm(b - oracle.spmv(A, x1)) <= 2.5 * tol * st1.nrm0
+
+
+def test_context_options(cm, oracle):
+    """csrc/config.h: a context reads CUDAMAT_* once, when it is created; afterwards a switch changes only through
+    cudamat_ctx_set_option, and whatever runs on the context next sees it.  Unknown names and values outside an option's
+    range are errors, not silently ignored."""
+    import os
+    A = oracle.rand_rows(70000, 20, 3)
+    x = np.arange(A.n) % 7 + 1.0
+    want = oracle.spmv(A, x)
+    os.environ["CUDAMAT_SPMV_MODE"] = "pb"
+    try:
+        c = cm.Context(0)                      # reads the environment here ...
+    finally:
+        del os.environ["CUDAMAT_SPMV_MODE"]
+    s = cm.Solver.from_host_csr(c, A.rowptr, A.colidx, A.val)
+    assert s.spmv_mode() == 1                  # ... so the switch holds although the variable is gone
+    s.close()
+    os.environ["CUDAMAT_SPMV_MODE"] = "csr"    # a later change of the environment does not reach the context
+    try:
+        s = cm.Solver.from_host_csr(c, A.rowptr, A.colidx, A.val)
+        assert s.spmv_mode() == 1
+        s.close()
+        c.reset_options()                      # ... unless the host asks for it
+        s = cm.Solver.from_host_csr(c, A.rowptr, A.colidx, A.val)
+        assert s.spmv_mode() == 0
+        s.close()
+    finally:
+        del os.environ["CUDAMAT_SPMV_MODE"]
+    c.set_option("CUDAMAT_SPMV_MODE", "sell").set_option("SPMV_SELL", 1)
+    s = cm.Solver.from_host_csr(c, A.rowptr, A.colidx, A.val)
+    assert s.spmv_mode() == 2
+    dx, dy = c.array(x), c.empty(A.n)
+    s.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), want)
+    s.close()
+    for name, value in (("NO_SUCH_SWITCH", "1"), ("SPMV_MODE", "ell"), ("SPMV_LANES", "3"), ("PB_DEPTH", "5"), ("VERBOSE", "yes"),
+                        ("TEST_COMM_FAIL", "1"), ("TRSV_GROUPS", "1")):
+        with pytest.raises(cm.CudamatError):
+            c.set_option(name, value)
+    c.close()
