@@ -47,6 +47,7 @@ struct cudamat_solver {
     cm::SellPlan sell{};
     double ms_csr = 0.0, ms_pb = 0.0, ms_sell = 0.0;   // auto-tune timings
     double t_create = 0.0;       // s: upload-side copies, validation, CSR launch plan (cudamat_solver_create)
+    double t_create0 = 0.0;      // wall clock at the start of the creation
     double t_spmv_setup = 0.0;   // s: ensure_spmv_mode in all (copies of the matrix in other layouts + timing of candidates)
     double t_spmv_timing = 0.0;  // s: of that, the timed candidate launches
     double col_span_bytes = -1.0; // mean (last - first column) * 8 over sampled rows (-1: not sampled)
@@ -145,6 +146,16 @@ struct cudamat_solver {
 namespace cm {
 // ---- solver.hip: what the loops (loops.hip) and the drop-in entry point (dropin.hip) use of the resident system
 int dev_alloc(void **p, size_t bytes);
+// creation in stages (cudamat_solver_create = all three on device arrays; dropin.hip runs them beside the upload)
+int solver_alloc(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz, cudamat_solver **out);   // rp / ci / val allocated, EMPTY
+int solver_setup_pattern(cudamat_solver *s);         // rp, ci in place (0-based): validation, CSR plan, compressed indices
+int solver_setup_values(cudamat_solver *s);          // val in place: value-dependent parts of the CSR plan
+// the blocked form is the clear choice for this matrix (scattered columns: ensure_spmv_mode would select it without timing
+// anything), judged from the pattern alone; *blocked = false: leave the choice to ensure_spmv_mode
+int spmv_mode_is_blocked_early(cudamat_solver *s, bool *blocked);
+// take a finished blocked copy as this solver's SpMV form (built beside the upload, dropin.hip)
+void spmv_mode_adopt_blocked(cudamat_solver *s, const PbPlan &pb, double seconds);
+int ensure_valdict(cudamat_solver *s);               // the matrix's value dictionary, looked for once
 int ensure_work(cudamat_solver *s);                  // the seven work vectors (+ the gather buffer when sharded)
 int ensure_spmv_mode(cudamat_solver *s);             // choose the SpMV form (once per system / partition)
 int setup_agree(cudamat_solver *s, int rc_local);    // sharded: the ranks compare their set-up outcomes (collective)

@@ -135,40 +135,31 @@ static int validate_csr(cudamat_solver *s)
     return CUDAMAT_OK;
 }
 
-namespace cm { static int ensure_valdict(cudamat_solver *s); }
+namespace cm {
 
-extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz,
-                                     const int *rowptr, const int *colidx, const double *val,
-                                     int base, cudamat_solver **out)
+// ---- creation in stages.  cudamat_solver_create runs them back to back on device arrays; the host-pointer entry
+// point (dropin.hip) runs the pattern stage as soon as the row pointers and column indices have been uploaded and the
+// value stage when the values have.
+// (1) the solver and its allocations; rp / ci / val are EMPTY (the caller fills them: 0-based)
+int solver_alloc(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz, cudamat_solver **out)
 {
-    CM_ARG(ctx && out, "null pointer");
     *out = nullptr;
     CM_ARG(n_local >= 0 && n_cols >= n_local && nnz >= 0, "sizes");
     CM_ARG(nnz < (1LL << 31) && n_cols < (1LL << 31), "local nnz and dimension must fit int32");
-    CM_ARG(base == 0 || base == 1, "base in {0,1}");
-    CM_ARG(rowptr && (nnz == 0 || (colidx && val)), "null CSR array");
     CM_HIP(hipSetDevice(ctx->device));
-    Range range_create("cudamat: solver create (copies, validation, CSR plan)");
-    const double t_create0 = now_s();
     cudamat_solver *s = new cudamat_solver();
     s->ctx = ctx;
     s->n = n_local;
     s->n_pad = n_local;
     s->n_cols = n_cols;
     s->nnz = nnz;
+    s->t_create0 = now_s();
     hipStream_t st = ctx->stream;
     int rc = CUDAMAT_OK;
     do {
         if ((rc = dev_alloc((void **)&s->rp, sizeof(int) * ((size_t)n_local + 1)))) break;
         if ((rc = dev_alloc((void **)&s->ci, sizeof(int) * (size_t)nnz))) break;
         if ((rc = dev_alloc((void **)&s->val, sizeof(double) * (size_t)nnz))) break;
-        if ((rc = launch_rebase(st, (int64_t)n_local + 1, rowptr, -base, s->rp))) break;
-        if (nnz) {
-            if ((rc = launch_rebase(st, nnz, colidx, -base, s->ci))) break;
-            if (hipMemcpyAsync(s->val, val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-                rc = CUDAMAT_ERR_HIP; set_error("val copy failed"); break;
-            }
-        }
         if ((rc = dev_alloc((void **)&s->parts_full, sizeof(double) * 2 * kMaxParts))) break;
         if ((rc = dev_alloc((void **)&s->parts_rv, sizeof(double) * 2 * kMaxParts))) break;
         if ((rc = dev_alloc((void **)&s->parts_half, sizeof(double) * 2 * kMaxParts))) break;
@@ -183,12 +174,20 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
             rc = CUDAMAT_ERR_HIP; set_error("pinned progress words unavailable"); break;
         }
         if (hipMemsetAsync(s->st, 0, sizeof(LoopState), st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
-        if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("sync after upload failed"); break; }
     } while (0);
     if (rc) {
         cudamat_solver_destroy(s);
         return rc;
     }
+    *out = s;
+    return CUDAMAT_OK;
+}
+
+// (2) rp and ci are in place (0-based): validation, CSR launch plan, compressed indices
+int solver_setup_pattern(cudamat_solver *s)
+{
+    cudamat_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
     const bool verbose = ctx->cfg.verbose != 0;
     double t_mark = now_s();
     auto stamp = [&](const char *what) {
@@ -197,42 +196,60 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
         fprintf(stderr, "[cudamat] create %-34s %8.3f ms\n", what, (t - t_mark) * 1e3);
         t_mark = t;
     };
-    if (verbose) fprintf(stderr, "[cudamat] create %-34s %8.3f ms\n", "allocations + copies", (t_mark - t_create0) * 1e3);
-    if (int rcv = validate_csr(s)) {
-        cudamat_solver_destroy(s);
-        return rcv;
-    }
+    if (verbose) fprintf(stderr, "[cudamat] create %-34s %8.3f ms\n", "allocations + copies", (t_mark - s->t_create0) * 1e3);
+    CM_TRY(validate_csr(s));
     stamp("validation");
-    s->plan = plan_spmv(ctx->cfg, n_local, nnz);
-    if (int rc2 = plan_spmv_refine(st, ctx->cfg, n_local, nnz, s->rp, 0, &s->plan)) {
-        cudamat_solver_destroy(s);
-        return rc2;
-    }
+    s->plan = plan_spmv(ctx->cfg, s->n, s->nnz);
+    CM_TRY(plan_spmv_refine(st, ctx->cfg, s->n, s->nnz, s->rp, 0, &s->plan));
     stamp("CSR launch plan (refine)");
-    if (int rc3 = plan_spmv_compress(st, ctx->cfg, n_local, nnz, s->rp, s->ci, &s->plan)) {
-        cudamat_solver_destroy(s);
-        return rc3;
-    }
+    CM_TRY(plan_spmv_compress(st, ctx->cfg, s->n, s->nnz, s->rp, s->ci, &s->plan));
     stamp("compressed-index attempt");
+    return CUDAMAT_OK;
+}
+
+// (3) val is in place: the value-dependent parts of the CSR launch plan
+int solver_setup_values(cudamat_solver *s)
+{
+    cudamat_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
     if (s->plan.c_off16) {          // compressed stream kernel: 8-bit value indices too when the matrix has a dictionary
-        if (int rc4 = ensure_valdict(s)) {
-            cudamat_solver_destroy(s);
-            return rc4;
-        }
-        if (s->vd.n > 0) {
-            if (int rc5 = plan_spmv_dict(st, n_local, nnz, s->rp, s->vd.idx, s->vd.dict, &s->plan)) {
-                cudamat_solver_destroy(s);
-                return rc5;
-            }
-        }
-        if (!s->plan.d_pbase) {     // fp64 values: line-aligned copies of the two entry streams
-            if (int rc6 = plan_spmv_align(st, ctx->cfg, n_local, nnz, s->rp, s->val, &s->plan)) {
-                cudamat_solver_destroy(s);
-                return rc6;
-            }
+        CM_TRY(ensure_valdict(s));
+        if (s->vd.n > 0) CM_TRY(plan_spmv_dict(st, s->n, s->nnz, s->rp, s->vd.idx, s->vd.dict, &s->plan));
+        if (!s->plan.d_pbase)       // fp64 values: line-aligned copies of the two entry streams
+            CM_TRY(plan_spmv_align(st, ctx->cfg, s->n, s->nnz, s->rp, s->val, &s->plan));
+    }
+    s->t_create = now_s() - s->t_create0;
+    return CUDAMAT_OK;
+}
+
+}  // namespace cm
+
+extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz,
+                                     const int *rowptr, const int *colidx, const double *val,
+                                     int base, cudamat_solver **out)
+{
+    CM_ARG(ctx && out, "null pointer");
+    *out = nullptr;
+    CM_ARG(base == 0 || base == 1, "base in {0,1}");
+    CM_ARG(rowptr && (nnz == 0 || (colidx && val)), "null CSR array");
+    Range range_create("cudamat: solver create (copies, validation, CSR plan)");
+    cudamat_solver *s = nullptr;
+    CM_TRY(solver_alloc(ctx, n_local, n_cols, nnz, &s));
+    hipStream_t st = ctx->stream;
+    int rc = launch_rebase(st, (int64_t)n_local + 1, rowptr, -base, s->rp);
+    if (!rc && nnz) {
+        rc = launch_rebase(st, nnz, colidx, -base, s->ci);
+        if (!rc && hipMemcpyAsync(s->val, val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            rc = CUDAMAT_ERR_HIP; set_error("val copy failed");
         }
     }
-    s->t_create = now_s() - t_create0;
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("sync after upload failed"); }
+    if (!rc) rc = solver_setup_pattern(s);
+    if (!rc) rc = solver_setup_values(s);
+    if (rc) {
+        cudamat_solver_destroy(s);
+        return rc;
+    }
     *out = s;
     return CUDAMAT_OK;
 }
@@ -451,7 +468,7 @@ int spmv_local(cudamat_solver *s, const double *x_local, double *y, int dot, con
 
 // the matrix's value dictionary (valdict.hip), looked for once: large systems only (small ones live in caches and the
 // small-system loops keep their values in registers)
-static int ensure_valdict(cudamat_solver *s)
+int ensure_valdict(cudamat_solver *s)
 {
     if (s->vd_tried) return CUDAMAT_OK;
     s->vd_tried = true;
@@ -510,6 +527,34 @@ static int col_span_bytes(cudamat_solver *s, double *out)
 // or timing anything (a sharded solver still times the blocked form alone: ms_spmv_alone feeds the exposed-gather
 // figure).  CUDAMAT_SPMV_TUNE=full restores the timing of every candidate.
 static int ensure_spmv_mode_inner(cudamat_solver *s);
+
+// The part of the choice below that needs the PATTERN only: is the blocked form what ensure_spmv_mode will select without
+// timing anything?  (one GPU, sorted rows, a candidate by size, not forced elsewhere, and either forced or a mean column
+// span >= 16 MB of x with rows of >= 8 entries).  Same rules as ensure_spmv_mode_inner -- it calls this.
+int spmv_mode_is_blocked_early(cudamat_solver *s, bool *blocked)
+{
+    *blocked = false;
+    const Config &cfg = s->ctx->cfg;
+    if (s->sharded || s->n == 0 || s->nnz == 0 || !s->cols_sorted) return CUDAMAT_OK;
+    if (cfg.spmv_mode == 0 || cfg.spmv_mode == 2) return CUDAMAT_OK;
+    if (cfg.spmv_mode == 1) { *blocked = true; return CUDAMAT_OK; }
+    if (!pb_candidate(s->ctx->stream, s->n, s->n_cols, s->nnz, s->rp, s->ci)) return CUDAMAT_OK;
+    if (cfg.spmv_tune_full || s->nnz < 8 * (int64_t)s->n) return CUDAMAT_OK;
+    if (s->col_span_bytes < 0.0) CM_TRY(col_span_bytes(s, &s->col_span_bytes));
+    *blocked = s->col_span_bytes >= 16.0 * 1024 * 1024;
+    return CUDAMAT_OK;
+}
+
+void spmv_mode_adopt_blocked(cudamat_solver *s, const PbPlan &pb, double seconds)
+{
+    s->pb = pb;
+    s->spmv_mode = 1;
+    s->t_spmv_setup = seconds;
+    if (s->ctx->cfg.verbose)
+        fprintf(stderr, "[cudamat] SpMV form 1 (blocked) built beside the upload in %.3f ms (a row's columns span %.1f MB of x)\n",
+                seconds * 1e3, s->col_span_bytes / 1048576.0);
+}
+
 int ensure_spmv_mode(cudamat_solver *s)
 {
     if (s->spmv_mode >= 0) return CUDAMAT_OK;
@@ -560,7 +605,7 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
     bool scattered = false;
     {
         if (have[1] && !force_pb && !force_sell && !cfg.spmv_tune_full && s->nnz >= 8 * (int64_t)s->n) {
-            CM_TRY(col_span_bytes(s, &s->col_span_bytes));
+            if (s->col_span_bytes < 0.0) CM_TRY(col_span_bytes(s, &s->col_span_bytes));
             scattered = s->col_span_bytes >= 16.0 * 1024 * 1024;
         }
         if (scattered) {

@@ -51,6 +51,24 @@ struct PbPlan {
     double build_seconds = 0.0;
 };
 
+struct PbCut {          // device copy of the column cut: slice -> piece -> block
+    int per, chunks, chunk_len, bpc, CB;
+};
+// a blocked copy under construction (pb_build_begin .. pb_build_values .. pb_build_fill .. pb_build_end)
+struct PbBuild {
+    PbPlan p;
+    int *bins = nullptr;       // [column block][sub-block] fill cursors (device)
+    PbCut cut{};
+    size_t cap = 0;            // entries of the value / column / row / product arrays (with the blocks' alignment pads)
+    double t0 = 0.0;
+};
+int pb_build_begin(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
+                   const PbCols *cols, PbBuild *b);
+int pb_build_values(hipStream_t st, PbBuild *b, const ValDict *vd);
+int pb_build_fill(hipStream_t st, PbBuild *b, const int *rp, const int *ci, const double *val, const ValDict *vd, int sub0, int sub1);
+int pb_build_end(hipStream_t st, PbBuild *b, PbPlan *out);
+void pb_build_abort(PbBuild *b);
+
 // decide whether the matrix is a candidate (large x, scattered columns) -- cheap estimate
 bool pb_candidate(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci);
 // build the blocked copy from 0-based CSR on the device

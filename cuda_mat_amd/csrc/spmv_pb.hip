@@ -82,9 +82,6 @@ bool pb_candidate(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int 
 // FILL: place every entry at cursor[cb]++ (cursor in LDS, seeded with the global start of the
 // (cb, sub) segment) -- deterministic, no global atomics.  Equal-cb lanes of one load are adjacent
 // (columns are sorted), so a lane's rank inside its run is lane - (first lane of the run).
-struct PbCut {          // device copy of the column cut: slice -> piece -> block
-    int per, chunks, chunk_len, bpc, CB;
-};
 __device__ __forceinline__ int col_to_cb(const PbCut &c, int col)
 {
     const int q = col / c.per, w = col - q * c.per;
@@ -92,16 +89,18 @@ __device__ __forceinline__ int col_to_cb(const PbCut &c, int col)
     return (q * c.chunks + ch) * c.bpc + off / c.CB;
 }
 
+// The launch covers the sub-blocks [sub0, sub1) (the drop-in entry point fills a blocked copy piece by piece while the
+// values are still being uploaded: rows are independent here).
 template <bool FILL>
 __global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_rows(int n, const int *rp, const int *ci,
                                                                const double *val, PbCut cut, const int *col0, int NCB,
                                                                int SR, int NSUB, int *bins, double *pv, u16 *pc, u16 *pr,
-                                                               const unsigned char *vidx, unsigned char *pvi)
+                                                               const unsigned char *vidx, unsigned char *pvi, int sub0, int sub1)
 {
     extern __shared__ int lds_i[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int sub = blockIdx.x * kPbBuildWaves + wave;
-    if (sub >= NSUB) return;
+    const int sub = sub0 + blockIdx.x * kPbBuildWaves + wave;
+    if (sub >= sub1) return;
     int *cur = lds_i + (size_t)wave * NCB;
     for (int c = lane; c < NCB; c += 64) cur[c] = FILL ? bins[(size_t)c * NSUB + sub] : 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -234,11 +233,22 @@ static int round_blocks(int64_t n, int tile_max)
     return (int)(256 * m);
 }
 
-int pb_build(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
-             const double *val, PbPlan *out, const PbCols *cols, const ValDict *vd)
+// ---- staged construction: pb_build_begin (geometry, tables, count pass, scans: the PATTERN only) -> pb_build_values (the
+// value array: fp64 or 8-bit dictionary indices) -> pb_build_fill over sub-block ranges (any partition of [0, NSUB)) ->
+// pb_build_end.  pb_build is the four in a row; the drop-in entry point runs them while the matrix is still being uploaded.
+void pb_build_abort(PbBuild *b)
 {
-    const double t0 = now_s();
-    PbPlan p;
+    if (b->bins) hipFree(b->bins);
+    b->bins = nullptr;
+    pb_free(&b->p);
+}
+
+int pb_build_begin(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
+                   const PbCols *cols, PbBuild *b)
+{
+    b->t0 = now_s();
+    PbPlan &p = b->p;
+    p = PbPlan();
     p.n = n;
     p.n_cols = n_cols;
     p.nnz = nnz;
@@ -306,21 +316,14 @@ int pb_build(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t n
         return CUDAMAT_ERR_ARG;
     }
     const size_t nbins = (size_t)p.NCB * p.NSUB;
-    int *bins = nullptr;
+    int *&bins = b->bins;
+    bins = nullptr;
     int rc = CUDAMAT_OK;
     do {
         if ((rc = dalloc(&bins, nbins))) break;
         constexpr int align = kPbAlign;
         const size_t cap = (size_t)nnz + (size_t)(align - 1) * (size_t)p.NCB + 16;
-        if (vd && vd->n > 0) {
-            if ((rc = dalloc(&p.pvi, cap))) break;
-            if (align > 1 && hipMemsetAsync(p.pvi, 0, cap, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
-            p.dict = vd->dict;
-            p.ndict = vd->n;
-        } else {
-            if ((rc = dalloc(&p.pv, cap))) break;
-            if (align > 1 && hipMemsetAsync(p.pv, 0, sizeof(double) * cap, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
-        }
+        b->cap = cap;
         if ((rc = dalloc(&p.pc, cap))) break;
         if (align > 1 && hipMemsetAsync(p.pc, 0, sizeof(u16) * cap, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
         if ((rc = dalloc(&p.pr, cap))) break;
@@ -364,15 +367,17 @@ int pb_build(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t n
                 hipMemcpyAsync(p.order, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb column cut upload failed"); break; }
         }
-        const PbCut cut{(int)p.per, p.chunks, (int)p.chunk_len, p.bpc, p.CB};
+        b->cut = PbCut{(int)p.per, p.chunks, (int)p.chunk_len, p.bpc, p.CB};
+        const PbCut cut = b->cut;
         if ((rc = dalloc(&p.sstart, nbins))) break;
         if ((rc = dalloc(&p.slen, nbins))) break;
         const unsigned grid = (unsigned)((p.NSUB + kPbBuildWaves - 1) / kPbBuildWaves);
         const size_t lds = sizeof(int) * (size_t)kPbBuildWaves * p.NCB;
         if ((rc = set_max_lds((const void *)k_pb_rows<false>))) break;
         if ((rc = set_max_lds((const void *)k_pb_rows<true>))) break;
-        hipLaunchKernelGGL(k_pb_rows<false>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, cut, p.col0,
-                           p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr, (const unsigned char *)nullptr, (unsigned char *)nullptr);
+        hipLaunchKernelGGL(k_pb_rows<false>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, (const double *)nullptr, cut, p.col0,
+                           p.NCB, p.SR, p.NSUB, bins, (double *)nullptr, p.pc, p.pr, (const unsigned char *)nullptr, (unsigned char *)nullptr,
+                           0, p.NSUB);
         if (hipGetLastError() != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb count launch failed"); break; }
         hipLaunchKernelGGL(k_pb_colsum, dim3(p.NCB), dim3(kBlock), 0, st, p.NSUB, bins, p.cstart);   // cstart doubles as scratch
         hipLaunchKernelGGL(k_pb_colscan, dim3(1), dim3(kBlock), 0, st, p.NCB, p.cstart, p.cstart, align);
@@ -384,21 +389,62 @@ int pb_build(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t n
         if ((int64_t)counted < nnz || (int64_t)counted > nnz + (int64_t)(align - 1) * p.NCB) {
             rc = CUDAMAT_ERR_ARG; set_error("pb_build: counted %d entries, expected %lld", counted, (long long)nnz); break;
         }
-        hipLaunchKernelGGL(k_pb_rows<true>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, val, cut, p.col0,
-                           p.NCB, p.SR, p.NSUB, bins, p.pv, p.pc, p.pr, p.pvi ? vd->idx : (const unsigned char *)nullptr, p.pvi);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-            rc = CUDAMAT_ERR_HIP; set_error("pb fill failed"); break;
-        }
     } while (0);
-    if (bins) hipFree(bins);
-    if (rc) {
-        pb_free(&p);
-        return rc;
+    if (rc) pb_build_abort(b);
+    return rc;
+}
+
+// the value array of the copy under construction: 8-bit indices into vd's dictionary when it has one, else fp64 values
+int pb_build_values(hipStream_t st, PbBuild *b, const ValDict *vd)
+{
+    PbPlan &p = b->p;
+    int rc = CUDAMAT_OK;
+    if (vd && vd->n > 0) {
+        if ((rc = dalloc(&p.pvi, b->cap)) == CUDAMAT_OK && hipMemsetAsync(p.pvi, 0, b->cap, st) != hipSuccess) rc = CUDAMAT_ERR_HIP;
+        p.dict = vd->dict;
+        p.ndict = vd->n;
+    } else {
+        if ((rc = dalloc(&p.pv, b->cap)) == CUDAMAT_OK && hipMemsetAsync(p.pv, 0, sizeof(double) * b->cap, st) != hipSuccess) rc = CUDAMAT_ERR_HIP;
     }
-    p.build_seconds = now_s() - t0;
-    *out = p;
+    if (rc) pb_build_abort(b);
+    return rc;
+}
+
+// place the entries of the sub-blocks [sub0, sub1) (rows [sub0 * SR, sub1 * SR)): needs rp, ci and val (or vd->idx) of those rows only
+int pb_build_fill(hipStream_t st, PbBuild *b, const int *rp, const int *ci, const double *val, const ValDict *vd, int sub0, int sub1)
+{
+    PbPlan &p = b->p;
+    if (sub1 > p.NSUB) sub1 = p.NSUB;
+    if (sub1 <= sub0) return CUDAMAT_OK;
+    const unsigned grid = (unsigned)((sub1 - sub0 + kPbBuildWaves - 1) / kPbBuildWaves);
+    const size_t lds = sizeof(int) * (size_t)kPbBuildWaves * p.NCB;
+    hipLaunchKernelGGL(k_pb_rows<true>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, p.n, rp, ci, val, b->cut, p.col0,
+                       p.NCB, p.SR, p.NSUB, b->bins, p.pv, p.pc, p.pr, p.pvi ? vd->idx : (const unsigned char *)nullptr, p.pvi, sub0, sub1);
+    if (hipGetLastError() != hipSuccess) { set_error("pb fill launch failed"); pb_build_abort(b); return CUDAMAT_ERR_HIP; }
     return CUDAMAT_OK;
 }
+
+int pb_build_end(hipStream_t st, PbBuild *b, PbPlan *out)
+{
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("pb fill failed"); pb_build_abort(b); return CUDAMAT_ERR_HIP; }
+    hipFree(b->bins);
+    b->bins = nullptr;
+    b->p.build_seconds = now_s() - b->t0;
+    *out = b->p;
+    b->p = PbPlan();
+    return CUDAMAT_OK;
+}
+
+int pb_build(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
+             const double *val, PbPlan *out, const PbCols *cols, const ValDict *vd)
+{
+    PbBuild b;
+    CM_TRY(pb_build_begin(st, cfg, n, n_cols, nnz, rp, ci, cols, &b));
+    CM_TRY(pb_build_values(st, &b, vd));
+    CM_TRY(pb_build_fill(st, &b, rp, ci, val, vd, 0, b.p.NSUB));
+    return pb_build_end(st, &b, out);
+}
+
 
 // ------------------------------------------------------------------ phase 1
 // The streaming loop: two entries per lane per step (16-byte value loads), four steps in flight, every bound checked.

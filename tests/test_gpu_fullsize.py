@@ -117,9 +117,11 @@ def test_full_size_spmv_vs_oracle(cm, kind, values, monkeypatch):
             assert s.spmv_kernel() == ("k_spmv<%s>" % (lanes or "32")), s.spmv_kernel()
             d_x.upload(x_int)
             s.spmv(d_x, d_y)
+            c2.sync()                       # (the vectors belong to ctx: its stream knows nothing of c2's)
             assert np.array_equal(_bits(d_y.download()), _bits(want_int))
             d_x.upload(x_real)
             s.spmv(d_x, d_y)
+            c2.sync()
             assert np.all(np.abs(d_y.download() - want_real) <= bound)
             s.close()
             c2.close()
