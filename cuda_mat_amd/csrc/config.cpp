@@ -32,7 +32,7 @@ struct Option {
 const Option kOptions[] = {
     OPT_FLAG("VERBOSE", verbose, "set-up breakdowns and auto-tune timings on stderr"),
     OPT_FLAG("ROCTX", roctx, "roctx ranges around solver creation, SpMV-form choice, ILU(0) set-up, the loop, SpMVs and all-reduces"),
-    OPT_ENUM("SPMV_MODE", spmv_mode, "csr=0,pb=1,sell=2", "force the CSR forms / the blocked two-phase form / SELL-C-sigma"),
+    OPT_ENUM("SPMV_MODE", spmv_mode, "csr=0,pb=1,sell=2,pat=3", "force the CSR forms / the blocked two-phase form / SELL-C-sigma / the row-pattern dictionary"),
     OPT_FLAG("SPMV_SELL", spmv_sell, "0: keep SELL-C-sigma out of the candidates"),
     OPT_ENUM("SPMV_FORM", spmv_form, "lanes=1,tiles=2", "inside the CSR forms: lanes per row / nnz-balanced tiles"),
     OPT_INT("SPMV_LANES", spmv_lanes, 2, 64, "lanes per row, a power of two (and no stream tiles)"),
@@ -65,7 +65,8 @@ const Option kOptions[] = {
     OPT_FLAG("SHARDED_ONE_DEVICE", sharded_one_device,
              "1: cudamat_solve_sharded with every rank on device 0 and host-synchronised copies in place of RCCL (debugging aid)"),
     OPT_FLAG("PLAN_CACHE", plan_cache, "0: cudamat_solve does not keep the solver of its last call"),
-    OPT_INT("UPLOAD_THREADS", upload_threads, 1, 64, "host threads that stage cudamat_solve's arrays into pinned buffers"),
+    OPT_INT("UPLOAD_THREADS", upload_threads, 0, 64,
+            "cudamat_solve: N > 0 host threads stage the caller's arrays into pinned buffers; 0 (default): the runtime reads the caller's memory directly"),
     {"TEST_COMM_FAIL", K_FAIL, nullptr, nullptr, 0, 0, nullptr, "rank:k -- fault injection: that rank's k-th all-reduce reports an error (tests)"},
 };
 

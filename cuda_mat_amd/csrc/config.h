@@ -18,7 +18,7 @@ struct Config {
     int verbose = 0;              // VERBOSE            set-up breakdowns and auto-tune timings on stderr
     int roctx = 0;                // ROCTX              roctx ranges around the phases of a solve
     // ---- SpMV form
-    int spmv_mode = -1;           // SPMV_MODE          csr | pb | sell: force the CSR forms / blocked two-phase / SELL-C-sigma (-1: choose)
+    int spmv_mode = -1;           // SPMV_MODE          csr | pb | sell | pat: force the CSR forms / blocked two-phase / SELL-C-sigma / row patterns (-1: choose)
     int spmv_sell = 1;            // SPMV_SELL          0: keep SELL out of the candidates
     int spmv_form = 0;            // SPMV_FORM          lanes | tiles: inside the CSR forms, lanes per row / nnz-balanced tiles (0: choose)
     int spmv_lanes = 0;           // SPMV_LANES         2..64 lanes per row (and no stream tiles)
@@ -53,7 +53,7 @@ struct Config {
     int sharded_one_device = 0;   // SHARDED_ONE_DEVICE 1: cudamat_solve_sharded with every rank on device 0, host-synchronised copies for RCCL
     // ---- drop-in entry point
     int plan_cache = 1;           // PLAN_CACHE         0: cudamat_solve does not keep the solver of its last call
-    int upload_threads = 0;       // UPLOAD_THREADS     host threads staging cudamat_solve's arrays into pinned buffers (0: up to 8)
+    int upload_threads = 0;       // UPLOAD_THREADS     cudamat_solve: N > 0 threads stage the arrays into pinned buffers; 0: the runtime reads the caller's memory
     // ---- fault injection (tests)
     int fail_rank = -1, fail_call = -1;   // TEST_COMM_FAIL = rank:k   that rank's k-th all-reduce reports an error
 

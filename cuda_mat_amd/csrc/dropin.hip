@@ -35,6 +35,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------- uploader
 constexpr size_t kSlotBytes = 8u << 20;      // one staging slot / one PCIe transfer
 constexpr int kSlots = 8;                    // 64 MB of pinned host memory, kept with the plan cache
+constexpr size_t kDirectBytes = 128u << 20;  // one piece of the caller's memory handed to the runtime (direct form)
 
 struct PinnedPool {
     char *slot[kSlots] = {};
@@ -66,9 +67,17 @@ struct PinnedPool {
     }
 };
 
+// Two ways to move the caller's (pageable) arrays, chosen per call (upload_mode):
+//   direct   the issuer thread hands the runtime 128 MB pieces of the caller's memory (hipMemcpyAsync from pageable memory:
+//            the runtime pins the pages piece by piece and lets the DMA engines read them; 41 GB/s on the development
+//            box) -- no host copy, one thread;
+//   staged   T threads copy 8 MB chunks into pinned slots, the issuer enqueues slot -> HBM copies: pays a host-side copy
+//            of every byte but keeps the PCIe link busy with pure DMA transfers; needs T free cores to win.
 struct Uploader {
     struct Chunk { char *dst; const char *src; size_t bytes; int milestone; };     // milestone: recorded AFTER this chunk (-1: none)
     std::vector<Chunk> chunks;
+    size_t chunk_bytes = kSlotBytes;             // staged: one slot; direct: kDirectBytes
+    bool direct = false;
     std::vector<hipEvent_t> ms_event;
     std::vector<std::atomic<int>> ms_recorded;
     std::vector<std::atomic<int>> filled;       // per chunk: staged into its slot
@@ -86,8 +95,8 @@ struct Uploader {
     {
         const char *sp = (const char *)src;
         char *dp = (char *)dst;
-        for (size_t off = 0; off < bytes; off += kSlotBytes)
-            chunks.push_back(Chunk{dp + off, sp + off, bytes - off < kSlotBytes ? bytes - off : kSlotBytes, -1});
+        for (size_t off = 0; off < bytes; off += chunk_bytes)
+            chunks.push_back(Chunk{dp + off, sp + off, bytes - off < chunk_bytes ? bytes - off : chunk_bytes, -1});
         return mark();
     }
     // a milestone after everything added so far
@@ -101,10 +110,19 @@ struct Uploader {
         return chunks.back().milestone;
     }
 
+    // before the first add(): nthreads == 0 selects the direct form
+    void configure(int nthreads)
+    {
+        direct = nthreads <= 0;
+        chunk_bytes = direct ? kDirectBytes : kSlotBytes;
+    }
+
     int start(PinnedPool *p, int dev, int nthreads)
     {
         pool = p;
         device = dev;
+        if (direct) nthreads = 0;
+        else CM_TRY(p->acquire());
         CM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (hipEvent_t &e : ms_event) CM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ms_recorded = std::vector<std::atomic<int>>(ms_event.size());
@@ -141,13 +159,18 @@ struct Uploader {
     {
         hipSetDevice(device);
         for (size_t c = 0; c < chunks.size(); c++) {
-            while (!filled[c].load(std::memory_order_acquire)) {
+            if (direct) {
                 if (failed) return;
-                std::this_thread::yield();
+                if (hipMemcpyAsync(chunks[c].dst, chunks[c].src, chunks[c].bytes, hipMemcpyHostToDevice, stream) != hipSuccess) { failed = 1; return; }
+            } else {
+                while (!filled[c].load(std::memory_order_acquire)) {
+                    if (failed) return;
+                    std::this_thread::yield();
+                }
+                const int sl = (int)(c % kSlots);
+                if (hipMemcpyAsync(chunks[c].dst, pool->slot[sl], chunks[c].bytes, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                    hipEventRecord(pool->done[sl], stream) != hipSuccess) { failed = 1; return; }
             }
-            const int sl = (int)(c % kSlots);
-            if (hipMemcpyAsync(chunks[c].dst, pool->slot[sl], chunks[c].bytes, hipMemcpyHostToDevice, stream) != hipSuccess ||
-                hipEventRecord(pool->done[sl], stream) != hipSuccess) { failed = 1; return; }
             const int m = chunks[c].milestone;
             if (m >= 0) {
                 if (hipEventRecord(ms_event[(size_t)m], stream) != hipSuccess) { failed = 1; return; }
@@ -189,12 +212,10 @@ struct Uploader {
     ~Uploader() { if (!threads.empty()) failed = 1; join(); }      // (an early exit: tell the threads to stop; never touches the error string)
 };
 
+// staging threads of this call; 0 = the direct form (the default: measured on the development box, alternating, C4 arrays)
 int upload_threads(const Config &cfg)
 {
-    if (cfg.upload_threads) return cfg.upload_threads;
-    unsigned hw = std::thread::hardware_concurrency();
-    int t = (int)(hw / 2);
-    return t < 2 ? 2 : t > 8 ? 8 : t;
+    return cfg.upload_threads > 0 ? cfg.upload_threads : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------- plan cache
@@ -276,9 +297,9 @@ int build_or_reuse_candidate(cudamat_ctx *ctx, const Config &cfg, const HostSyst
         if ((rc = cudamat_malloc(ctx, sizeof(int) * ((size_t)n + 1), (void **)&d_rp))) break;
         if ((rc = cudamat_malloc(ctx, sizeof(int) * (size_t)nnz, (void **)&d_ci))) break;
         if ((rc = cudamat_malloc(ctx, sizeof(double) * (size_t)nnz, (void **)&d_val))) break;
-        if ((rc = g_cache.pinned.acquire())) break;
         {
             Uploader up;
+            up.configure(upload_threads(cfg));
             up.add(d_rp, h.iA, sizeof(int) * ((size_t)n + 1));            // pbicgstab.cu:313-315
             up.add(d_ci, h.jA, sizeof(int) * (size_t)nnz);
             up.add(d_val, h.A, sizeof(double) * (size_t)nnz);
@@ -328,13 +349,13 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
     hipStream_t st = ctx->stream;
     cudamat_solver *s = nullptr;
     *s_out = nullptr;
-    CM_TRY(g_cache.pinned.acquire());
     CM_TRY(solver_alloc(ctx, n, n, nnz, &s));
     PbBuild pb;
     bool pb_open = false;
     int rc = CUDAMAT_OK;
     {
         Uploader up;
+        up.configure(upload_threads(cfg));
         const int m_rp = up.add(s->rp, h.iA, sizeof(int) * ((size_t)n + 1));             // pbicgstab.cu:313-315
         const int m_pattern = nnz ? up.add(s->ci, h.jA, sizeof(int) * (size_t)nnz) : m_rp;
         // the values in pieces that end on row boundaries (~256 MB each): a piece's rows can be placed in the blocked

@@ -6,6 +6,7 @@
 #include "spmv_pb.h"
 #include "valdict.h"
 #include "spmv_sell.h"
+#include "spmv_pat.h"
 
 namespace cm {
 
@@ -41,11 +42,12 @@ struct cudamat_solver {
     double *val = nullptr;
     const double *d = nullptr;
     cm::SpmvPlan plan{};
-    int spmv_mode = -1;        // -1 undecided, 0 CSR forms, 1 blocked two-phase kernels, 2 SELL-C-sigma
+    int spmv_mode = -1;        // -1 undecided, 0 CSR forms, 1 blocked two-phase kernels, 2 SELL-C-sigma, 3 row-pattern dictionary
     bool cols_sorted = true;   // every row's columns strictly increasing (checked at creation)
     cm::PbPlan pb{};
     cm::SellPlan sell{};
-    double ms_csr = 0.0, ms_pb = 0.0, ms_sell = 0.0;   // auto-tune timings
+    cm::PatPlan pat{};
+    double ms_csr = 0.0, ms_pb = 0.0, ms_sell = 0.0, ms_pat = 0.0;   // auto-tune timings
     double t_create = 0.0;       // s: upload-side copies, validation, CSR launch plan (cudamat_solver_create)
     double t_create0 = 0.0;      // wall clock at the start of the creation
     double t_spmv_setup = 0.0;   // s: ensure_spmv_mode in all (copies of the matrix in other layouts + timing of candidates)

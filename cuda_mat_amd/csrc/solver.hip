@@ -262,6 +262,7 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     ilu0_release(s);
     pb_free(&s->pb);
     sell_free(&s->sell);
+    pat_free(&s->pat);
     free_work(s);
     plan_spmv_free(&s->plan);
     void *ptrs[] = {s->rp, s->ci, s->val, s->parts_full, s->parts_rv, s->parts_half, s->parts_tt,
@@ -306,6 +307,7 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     free_work(s);
     pb_free(&s->pb);
     sell_free(&s->sell);
+    pat_free(&s->pat);
     ilu0_release(s);           // factors belong to the old partition
     s->spmv_mode = -1;
     s->overlap = false;
@@ -463,6 +465,7 @@ int spmv_local(cudamat_solver *s, const double *x_local, double *y, int dot, con
     if (s->perm_active) return launch_spmv_pb(s->ctx->stream, s->pb_perm, a);      // rows in L's space, columns in U's
     if (s->spmv_mode == 1) return launch_spmv_pb(s->ctx->stream, s->pb, a);
     if (s->spmv_mode == 2) return launch_spmv_sell(s->ctx->stream, s->sell, a);
+    if (s->spmv_mode == 3) return launch_spmv_pat(s->ctx->stream, s->pat, a);
     return launch_spmv(s->ctx->stream, s->plan, a);
 }
 
@@ -480,7 +483,7 @@ int ensure_valdict(cudamat_solver *s)
 int spmv_parts(const cudamat_solver *s)
 {
     if (s->perm_active) return s->pb_perm.NRB;
-    return s->spmv_mode == 1 ? s->pb.NRB : s->spmv_mode == 2 ? s->sell.grid : plan_spmv_parts(s->plan);
+    return s->spmv_mode == 1 ? s->pb.NRB : s->spmv_mode == 2 ? s->sell.grid : s->spmv_mode == 3 ? s->pat.grid : plan_spmv_parts(s->plan);
 }
 
 // How scattered are a row's columns?  Mean of (last - first column) over <= 4096 evenly spaced rows (sorted rows: the
@@ -518,8 +521,10 @@ static int col_span_bytes(cudamat_solver *s, double *out)
 //   0  the CSR forms (lanes per row / stream tiles / nnz-balanced tiles, plan_spmv_refine) -- always a candidate;
 //   1  the blocked two-phase kernels, when the columns are scattered over a vector far larger than L2 (pb_candidate);
 //   2  SELL-C-sigma, for rows of 8 entries and more whose padded copy stays below 1.5 x the entries (banded
-//      matrices: 2-2.7 x the lanes-per-row kernel; short rows belong to the stream kernel).
-// CUDAMAT_SPMV_MODE=csr|pb|sell overrides.
+//      matrices: 2-2.7 x the lanes-per-row kernel; short rows belong to the stream kernel);
+//   3  the row-pattern dictionary (spmv_pat.hip), for big matrices of short rows that repeat at most 255 shapes
+//      (stencils): 8 B per entry + 1 B per row, no column indices.
+// The switch SPMV_MODE = csr | pb | sell | pat overrides.
 // Candidates that cannot win are not timed (round 3; the drop-in entry points pay this on every call): when a row's
 // columns span far more than the L2s hold (mean span >= 16 MB of x; C4: 77 MB) and rows have >= 8 entries, every gather
 // of the lanes-per-row kernel and of SELL misses L2 -- measured 9.8 / 9.1 ms against 2.8 ms blocked at C4, the same
@@ -576,11 +581,12 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
     const bool force_csr = cfg.spmv_mode == 0;
     const bool force_pb = cfg.spmv_mode == 1;
     const bool force_sell = cfg.spmv_mode == 2;
+    const bool force_pat = cfg.spmv_mode == 3;
     s->spmv_mode = 0;
     if (force_csr || s->n == 0 || s->nnz == 0) return CUDAMAT_OK;
-    bool have[3] = {true, false, false};
+    bool have[4] = {true, false, false, false};
     // ---- blocked two-phase copy
-    if (!force_sell) {
+    if (!force_sell && !force_pat) {
         if (!s->cols_sorted) {    // the blocked builder ranks entries by runs of equal column block: needs sorted rows
             if (force_pb) { set_error("the blocked SpMV needs rows with increasing column indices"); return CUDAMAT_ERR_ARG; }
         } else if (force_pb || pb_candidate(st, s->n, s->n_cols, s->nnz, s->rp, s->ci)) {
@@ -604,7 +610,7 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
     // scattered columns: the gather-based forms cannot win (see above)
     bool scattered = false;
     {
-        if (have[1] && !force_pb && !force_sell && !cfg.spmv_tune_full && s->nnz >= 8 * (int64_t)s->n) {
+        if (have[1] && !force_pb && !force_sell && !force_pat && !cfg.spmv_tune_full && s->nnz >= 8 * (int64_t)s->n) {
             if (s->col_span_bytes < 0.0) CM_TRY(col_span_bytes(s, &s->col_span_bytes));
             scattered = s->col_span_bytes >= 16.0 * 1024 * 1024;
         }
@@ -623,25 +629,35 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
     // matrices (scripts/sell_probe.py): row lengths 14..70 0.46 ms vs 0.94 (CSR forms) / 0.66 (blocked); 13..20 0.18
     // vs 0.40 / 0.26; with scattered columns the blocked form wins (0.48 vs 1.07) -- hence: time them.
     const bool sell_off = !cfg.spmv_sell;
-    if (force_sell || (!force_pb && !scattered && !sell_off && s->n >= 4096 && s->nnz >= (1 << 16) && s->plan.stream_rows == 0 && s->nnz >= 8 * (int64_t)s->n)) {
+    if (force_sell || (!force_pb && !force_pat && !scattered && !sell_off && s->n >= 4096 && s->nnz >= (1 << 16) && s->plan.stream_rows == 0 && s->nnz >= 8 * (int64_t)s->n)) {
         const int rc = sell_build(st, s->n, s->nnz, s->rp, s->ci, s->val, &s->sell, force_sell ? 0.0 : 1.5);
         if (rc != CUDAMAT_OK && force_sell) return rc;
         have[2] = rc == CUDAMAT_OK;
         if (force_sell) { s->spmv_mode = 2; return CUDAMAT_OK; }
     }
-    if (!have[1] && !have[2]) return CUDAMAT_OK;
+    // ---- row-pattern dictionary: short rows (the stream-tile plan) of a system beyond the fused small-system loops whose
+    // rows repeat at most 255 shapes; 25 % padding at most.  At C3 it moves 0.58 GB per launch where the compressed
+    // stream kernel moves 0.77 GB -- timed like every other candidate.
+    if (force_pat || (!force_pb && !scattered && s->plan.stream_rows > 0 && s->n > 300000 && s->nnz >= (1 << 20))) {
+        const int rc = pat_build(st, s->n, s->nnz, s->rp, s->ci, s->val, &s->pat, force_pat ? 0.0 : 1.25);
+        if (rc != CUDAMAT_OK && (force_pat || rc != CUDAMAT_ERR_ARG) && rc != CUDAMAT_ERR_NOMEM) return rc;
+        if (rc != CUDAMAT_OK && force_pat) return rc;
+        have[3] = rc == CUDAMAT_OK;
+        if (force_pat) { s->spmv_mode = 3; return CUDAMAT_OK; }
+    }
+    if (!have[1] && !have[2] && !have[3]) return CUDAMAT_OK;
     if (force_pb && !have[1]) { set_error("the blocked copy could not be built"); return CUDAMAT_ERR_NOMEM; }
-    if (force_pb) have[2] = false;
+    if (force_pb) have[2] = have[3] = false;
     const LoopArgs la_none{nullptr, nullptr, 0, 0, 0};
     const ScalarSrc nosrc{nullptr, 0, 1};
     const double *xin = s->sharded ? s->gather : s->p;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    float ms[3] = {0.f, 0.f, 0.f};
+    float ms[4] = {0.f, 0.f, 0.f, 0.f};
     int rc = CUDAMAT_OK;
     const double t_timing0 = now_s();
-    for (int mode = 0; mode < 3 && rc == CUDAMAT_OK; mode++) {
+    for (int mode = 0; mode < 4 && rc == CUDAMAT_OK; mode++) {
         if (!have[mode]) continue;
         SpmvArgs a{};
         a.n = s->n; a.rp = s->rp; a.ci = s->ci; a.val = s->val; a.x = xin; a.d = nullptr; a.xd = s->p;
@@ -649,7 +665,8 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
         a.pb_strict = cfg.pb_strict;
         for (int rep = 0; rep < 3 && rc == CUDAMAT_OK; rep++) {
             if (rep == 1) hipEventRecord(e0, st);
-            rc = mode == 1 ? launch_spmv_pb(st, s->pb, a) : mode == 2 ? launch_spmv_sell(st, s->sell, a) : launch_spmv(st, s->plan, a);
+            rc = mode == 1 ? launch_spmv_pb(st, s->pb, a) : mode == 2 ? launch_spmv_sell(st, s->sell, a) :
+                 mode == 3 ? launch_spmv_pat(st, s->pat, a) : launch_spmv(st, s->plan, a);
         }
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
@@ -662,19 +679,22 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
     s->ms_csr = ms[0] / 2;
     s->ms_pb = ms[1] / 2;
     s->ms_sell = ms[2] / 2;
+    s->ms_pat = ms[3] / 2;
     int best = have[0] ? 0 : 1;
     if (rc == CUDAMAT_OK)
-        for (int mode = 1; mode < 3; mode++)
+        for (int mode = 1; mode < 4; mode++)
             if (have[mode] && (!have[best] || ms[mode] < ms[best])) best = mode;
     s->spmv_mode = best;
     s->ms_spmv_alone = ms[best] / 2;
     const double sell_fill = s->sell.fill;
     if (best != 1) pb_free(&s->pb);
     if (best != 2) sell_free(&s->sell);
+    const int npat = s->pat.npat;
+    if (best != 3) pat_free(&s->pat);
     if (cfg.verbose)
-        fprintf(stderr, "cudamat: SpMV auto-tune csr %.3f ms, blocked %s%.3f ms, sell %s%.3f ms (fill %.2f) -> %s\n", s->ms_csr,
-                have[1] ? "" : "(n/a) ", s->ms_pb, have[2] ? "" : "(n/a) ", s->ms_sell, sell_fill,
-                best == 1 ? "blocked" : best == 2 ? "sell" : "csr");
+        fprintf(stderr, "cudamat: SpMV auto-tune csr %.3f ms, blocked %s%.3f ms, sell %s%.3f ms (fill %.2f), row patterns %s%.3f ms (%d patterns) -> %s\n",
+                s->ms_csr, have[1] ? "" : "(n/a) ", s->ms_pb, have[2] ? "" : "(n/a) ", s->ms_sell, sell_fill, have[3] ? "" : "(n/a) ", s->ms_pat,
+                npat, best == 1 ? "blocked" : best == 2 ? "sell" : best == 3 ? "row patterns" : "csr");
     return CUDAMAT_OK;
 }
 
@@ -864,6 +884,7 @@ extern "C" int cudamat_solver_spmv_kernel(cudamat_solver *s, char *name, int cap
     const SpmvPlan &p = s->plan;
     if (s->spmv_mode == 1) snprintf(name, (size_t)cap, "%s + k_pb_phase2", s->pb.pvi ? "k_pb_phase1_dict" : "k_pb_phase1");
     else if (s->spmv_mode == 2) snprintf(name, (size_t)cap, "k_spmv_sell");
+    else if (s->spmv_mode == 3) snprintf(name, (size_t)cap, "k_spmv_pat<%d>", s->pat.W <= 8 ? 8 : 16);
     else if (p.tiles > 0) snprintf(name, (size_t)cap, "k_spmv_tiles");
     else if (p.stream_rows && p.c_off16) snprintf(name, (size_t)cap, "%s<%d>", p.d_pbase ? "k_spmv_stream_d" : "k_spmv_stream_c", p.stream_rows);
     else if (p.stream_rows) snprintf(name, (size_t)cap, "k_spmv_stream<%d>", p.stream_rows);

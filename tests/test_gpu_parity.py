@@ -1724,3 +1724,95 @@ def test_context_options(cm, oracle):
         with pytest.raises(cm.CudamatError):
             c.set_option(name, value)
     c.close()
+
+
+def _stencil9(oracle, nx, ny, rng):
+    """9-point stencil on an nx x ny grid with real values: rows of 4 / 6 / 9 entries, 9 row shapes"""
+    import scipy.sparse as sp
+    ex, ey = np.ones(nx), np.ones(ny)
+    Tx = sp.diags([ex[:-1], ex, ex[:-1]], [-1, 0, 1])
+    Ty = sp.diags([ey[:-1], ey, ey[:-1]], [-1, 0, 1])
+    S = sp.kron(Ty, Tx).tocsr()
+    S.sort_indices()
+    S.data[:] = rng.standard_normal(S.nnz)
+    return oracle.Csr(S.shape[0], S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), S.shape[0])
+
+
+@pytest.mark.parametrize("case", ["poisson_real", "nine_point", "empty_rows_base1", "tiny"])
+def test_row_pattern_spmv_is_bit_exact(cm, ctx, oracle, case, sw):
+    """the row-pattern dictionary form (csrc/spmv_pat.hip: one byte per row instead of column indices) adds a row's
+    products in column order with one rounding each -- the rounding sequence of `b[i] += A.Value[j] * x[A.Col[j]]`
+    (bicstab.cpp:72-77): bit for bit the oracle's result on real-valued data, with the diagonal term, with rows of
+    different lengths, empty rows, a row count that is no multiple of the 64-row chunks, index base 1"""
+    sw("SPMV_MODE", "pat")
+    rng = np.random.default_rng(12)
+    if case == "poisson_real":
+        A = oracle.poisson5(733, 417)
+        A.val[:] = rng.standard_normal(A.nnz)
+    elif case == "nine_point":
+        A = _stencil9(oracle, 211, 97, rng)
+    elif case == "tiny":
+        A = oracle.poisson5(3, 2)
+    else:
+        import scipy.sparse as sp
+        n = 10007
+        S = sp.diags([rng.standard_normal(n - 7), rng.standard_normal(n), rng.standard_normal(n - 3)], [-7, 0, 3]).tolil()
+        for r in (0, 5, 64, 4099, n - 1):
+            S[r, :] = 0                     # empty rows
+        S = S.tocsr()
+        S.eliminate_zeros()
+        S.sort_indices()
+        A = oracle.Csr(n, (S.indptr + 1).astype(np.int32), (S.indices + 1).astype(np.int32), S.data.astype(np.float64), n)
+    x = rng.standard_normal(A.n)
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val, n_cols=A.m)
+    assert s.spmv_mode() == 3 and s.spmv_kernel().startswith("k_spmv_pat<") and s.value_dict() == 0
+    s.close()
+    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
+    d = rng.standard_normal(A.n)
+    np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
+
+
+def test_row_pattern_form_refuses_what_it_cannot_describe(cm, ctx, oracle, sw):
+    """more than 255 row shapes, or a row longer than 15 entries: forced, the builder reports it; left to the tuner, the
+    matrix simply keeps its column indices"""
+    rng = np.random.default_rng(13)
+    A = oracle.rand_rows(5000, 6, 21)              # random columns: every row its own shape
+    B = oracle.rand_rows(400, 40, 22)              # rows of 40 entries
+    for M in (A, B):
+        sw("SPMV_MODE", "pat")
+        s = cm.Solver.from_host_csr(ctx, M.rowptr, M.colidx, M.val, n_cols=M.m)
+        with pytest.raises(cm.CudamatError):
+            s.spmv_mode()
+        s.close()
+        sw("SPMV_MODE", None)
+        x = rng.standard_normal(M.n)
+        s = cm.Solver.from_host_csr(ctx, M.rowptr, M.colidx, M.val, n_cols=M.m)
+        assert s.spmv_mode() != 3
+        s.close()
+
+
+def test_row_pattern_form_in_the_solver_loop_and_auto_selection(cm, ctx, oracle, sw):
+    """a Poisson system beyond the fused small-system loops (400 000 rows): the tuner TIMES the row-pattern form against
+    the compressed stream kernel and keeps the faster; whichever it is, and with the pattern form forced, the
+    reference loop converges like the oracle's and returns its solution (fused dots, half-step test in the prologue)"""
+    A = oracle.poisson5(1000, 400)
+    xs = oracle.xstar(A.n, 5)
+    b = oracle.spmv(A, xs)
+    sw("VALUE_DICT", "0")
+    s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+    auto = s.spmv_kernel()
+    assert auto.startswith("k_spmv_pat<") or auto.startswith("k_spmv_stream_c<"), auto
+    s.close()
+    ref = None
+    for mode in ("csr", "pat"):
+        sw("SPMV_MODE", mode)
+        x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=60, tol=0.0)
+        assert st.iters == 60 and np.all(np.isfinite(h))
+        if ref is None:
+            ref = (x, h)
+        else:
+            # same products, same order inside every row; the dot partials are summed per workgroup in another grouping
+            np.testing.assert_allclose(h[:20], ref[1][:20], rtol=1e-9)
+            np.testing.assert_allclose(x, ref[0], rtol=1e-6, atol=1e-9)
+    xo, so, ho = oracle.pbicgstab(A, b, maxit=60, tol=0.0, want_hist=True)
+    np.testing.assert_allclose(h[:20], ho[:20], rtol=1e-8)
