@@ -55,6 +55,7 @@ constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 constexpr int kMaxParts = 2048;      // upper bound on partial sums per reduction stage
 constexpr int kVecGridMax = 1024;    // workgroups of a streaming vector kernel
 constexpr int kSpmvGridMax = 2048;   // workgroups of an SpMV launch (256 CUs x 8)
+constexpr size_t kCtxScratchBytes = 64 << 10;   // cudamat_ctx::scratch
 
 // A scalar that lives on the device: either `count` per-workgroup partial sums
 // (interleaved with stride `stride`, summed in a fixed order by every consumer
@@ -91,5 +92,9 @@ struct cudamat_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     double *parts = nullptr;   // kMaxParts * 2 doubles scratch for the standalone dot/nrm2
+    // 64 KB of device scratch for the small read-backs of the set-up stages (flags, counters, a value-dictionary probe table):
+    // those stages then neither allocate nor free -- hipFree waits for EVERY stream of the device, and the host-pointer entry
+    // point runs them while an upload is in flight on another stream (dropin.hip).  One user at a time: the context's stream.
+    void *scratch = nullptr;
     cm::Config cfg;            // the switches everything running on this context reads (config.h)
 };

@@ -128,7 +128,9 @@ extern "C" int cudamat_ctx_create(int device, void *stream, cudamat_ctx **out)
         c->own_stream = true;
     }
     hipError_t e = hipMalloc((void **)&c->parts, sizeof(double) * 2 * kMaxParts);
+    if (e == hipSuccess) e = hipMalloc(&c->scratch, kCtxScratchBytes);
     if (e != hipSuccess) {
+        if (c->parts) hipFree(c->parts);
         if (c->own_stream) hipStreamDestroy(c->stream);
         delete c;
         return fail_hip(e, "hipMalloc(parts)", __FILE__, __LINE__);
@@ -143,6 +145,7 @@ extern "C" int cudamat_ctx_destroy(cudamat_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     hipFree(ctx->parts);
+    hipFree(ctx->scratch);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return CUDAMAT_OK;
@@ -299,7 +302,7 @@ extern "C" int cudamat_spmv(cudamat_ctx *ctx, int n, const int *rowptr, const in
     CM_HIP(hipMemcpyAsync(&last, rowptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CM_HIP(hipStreamSynchronize(ctx->stream));
     SpmvPlan plan = plan_spmv(ctx->cfg, n, (int64_t)last - base);
-    CM_TRY(plan_spmv_refine(ctx->stream, ctx->cfg, n, (int64_t)last - base, rowptr, base, &plan));
+    CM_TRY(plan_spmv_refine(ctx->stream, ctx->cfg, n, (int64_t)last - base, rowptr, base, &plan, ctx->scratch));
     SpmvArgs a{};
     a.n = n;
     a.rp = rowptr;

@@ -111,10 +111,10 @@ struct Uploader {
     }
 
     // before the first add(): nthreads == 0 selects the direct form
-    void configure(int nthreads)
+    void configure(int nthreads, int piece_mb = 0)
     {
         direct = nthreads <= 0;
-        chunk_bytes = direct ? kDirectBytes : kSlotBytes;
+        chunk_bytes = direct ? (piece_mb > 0 ? (size_t)piece_mb << 20 : kDirectBytes) : kSlotBytes;
     }
 
     int start(PinnedPool *p, int dev, int nthreads)
@@ -123,7 +123,13 @@ struct Uploader {
         device = dev;
         if (direct) nthreads = 0;
         else CM_TRY(p->acquire());
-        CM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        {
+            // the transfers go first: should the runtime move a piece with a copy kernel, it must not queue behind the set-up
+            // kernels that run beside the upload
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+            CM_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
+        }
         for (hipEvent_t &e : ms_event) CM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ms_recorded = std::vector<std::atomic<int>>(ms_event.size());
         for (auto &a : ms_recorded) a = 0;
@@ -299,7 +305,7 @@ int build_or_reuse_candidate(cudamat_ctx *ctx, const Config &cfg, const HostSyst
         if ((rc = cudamat_malloc(ctx, sizeof(double) * (size_t)nnz, (void **)&d_val))) break;
         {
             Uploader up;
-            up.configure(upload_threads(cfg));
+            up.configure(upload_threads(cfg), cfg.upload_piece_mb);
             up.add(d_rp, h.iA, sizeof(int) * ((size_t)n + 1));            // pbicgstab.cu:313-315
             up.add(d_ci, h.jA, sizeof(int) * (size_t)nnz);
             up.add(d_val, h.A, sizeof(double) * (size_t)nnz);
@@ -340,7 +346,10 @@ int build_or_reuse_candidate(cudamat_ctx *ctx, const Config &cfg, const HostSyst
     return rc;
 }
 
-// ---- a call with a new matrix: the set-up runs beside the upload (see the top of this file)
+// ---- a call with a new matrix: the set-up runs beside the upload (see the top of this file).
+// Everything is ALLOCATED before the first byte travels (the blocked copy's geometry depends on the sizes only) and
+// nothing is freed until the last byte has landed: hipMalloc / hipFree take process-wide locks (hipFree waits for every
+// stream of the device), and an upload that shares the process with them was measured at a sixth of its speed.
 int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h, double *d_b, double *d_x, double *d_d,
                         cudamat_solver **s_out, double *t_up)
 {
@@ -349,13 +358,30 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
     hipStream_t st = ctx->stream;
     cudamat_solver *s = nullptr;
     *s_out = nullptr;
+    const bool verbose = cfg.verbose != 0;
+    auto stamp = [&](const char *what) {
+        if (verbose) fprintf(stderr, "[cudamat] drop-in %-52s at %8.3f ms\n", what, (now_s() - t0) * 1e3);
+    };
     CM_TRY(solver_alloc(ctx, n, n, nnz, &s));
+    // the blocked copy is a candidate by size (pb_candidate looks at sizes only): allocate it now, decide when the
+    // pattern is there; a matrix that ends up with another form frees it after the upload
     PbBuild pb;
     bool pb_open = false;
+    const bool want_pb = cfg.spmv_mode != 0 && cfg.spmv_mode != 2 && cfg.spmv_mode != 3 && (cfg.spmv_mode == 1 || !cfg.spmv_tune_full) &&
+                         pb_candidate(st, n, n, nnz, nullptr, nullptr) && (cfg.spmv_mode == 1 || (int64_t)nnz >= 8 * (int64_t)n);
+    if (want_pb) {
+        const int rcb = pb_build_alloc(st, cfg, n, n, nnz, nullptr, &pb);
+        pb_open = rcb == CUDAMAT_OK;                     // (no room / outside the form's limits: ensure_spmv_mode decides later)
+        if (pb_open && pb_build_values(st, &pb, nullptr) != CUDAMAT_OK) pb_open = false;      // fp64 value array (4 GB at C4); a matrix
+    }                                                                                        // with a dictionary swaps it afterwards
     int rc = CUDAMAT_OK;
-    {
+    if (hipStreamSynchronize(st) != hipSuccess) rc = CUDAMAT_ERR_HIP;
+    stamp("allocations done (solver, blocked copy)");
+    double t_pb0 = 0.0;
+    bool piecewise = false, blocked = false;
+    if (rc == CUDAMAT_OK) {
         Uploader up;
-        up.configure(upload_threads(cfg));
+        up.configure(upload_threads(cfg), cfg.upload_piece_mb);
         const int m_rp = up.add(s->rp, h.iA, sizeof(int) * ((size_t)n + 1));             // pbicgstab.cu:313-315
         const int m_pattern = nnz ? up.add(s->ci, h.jA, sizeof(int) * (size_t)nnz) : m_rp;
         // the values in pieces that end on row boundaries (~256 MB each): a piece's rows can be placed in the blocked
@@ -388,41 +414,32 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
         const int m_all = up.mark();
         do {
             if ((rc = up.start(&g_cache.pinned, ctx->device, upload_threads(cfg)))) break;
+            stamp(up.direct ? "uploader started (direct)" : "uploader started (staged, pinned slots ready)");
             // ---- pattern landed: index base, validation, CSR plan, the SpMV form
             if ((rc = up.wait_on(st, m_pattern))) break;
+            stamp("pattern milestone recorded");
             if (base) {
                 if ((rc = launch_rebase(st, (int64_t)n + 1, s->rp, -base, s->rp))) break;
                 if (nnz && (rc = launch_rebase(st, nnz, s->ci, -base, s->ci))) break;
             }
             if ((rc = solver_setup_pattern(s))) break;
-            bool blocked = false;
-            if ((rc = spmv_mode_is_blocked_early(s, &blocked))) break;
-            double t_pb0 = now_s();
-            bool piecewise = false;
-            if (blocked) {
-                const int rcb = pb_build_begin(st, cfg, n, n, nnz, s->rp, s->ci, nullptr, &pb);
-                if (rcb == CUDAMAT_OK) {
-                    pb_open = true;
-                    // does the matrix look like it has a value dictionary?  (a sample of the first values; arbitrary
-                    // coefficients overflow the 256-entry table within the first thousands)
-                    bool maybe_dict = false;
-                    if (cfg.value_dict && (int64_t)nnz >= (1 << 20)) {
-                        if ((rc = up.wait_on(st, m_first))) break;
-                        ValDict probe;
-                        const int64_t sample = (int64_t)(h.iA[pieces[0].row_end] - base);
-                        if (sample >= 4096 && (rc = valdict_build(st, cfg, sample, s->val, &probe))) break;
-                        maybe_dict = probe.n > 0;
-                        valdict_free(&probe);
-                    }
-                    if (!maybe_dict) {
-                        s->vd_tried = true;                      // (more than 256 distinct values, or the dictionary is switched off)
-                        if ((rc = pb_build_values(st, &pb, nullptr))) { pb_open = false; break; }
-                        piecewise = true;
-                    }
-                } else if (rcb != CUDAMAT_ERR_NOMEM && rcb != CUDAMAT_ERR_ARG) {
-                    rc = rcb;
-                    break;
-                }                                                // (no room / outside the form's limits: ensure_spmv_mode decides later)
+            stamp("pattern stage done (validation, CSR plan)");
+            if (pb_open && (rc = spmv_mode_is_blocked_early(s, &blocked))) break;
+            t_pb0 = now_s();
+            if (pb_open && blocked) {
+                if ((rc = pb_build_count(st, cfg, s->rp, s->ci, &pb))) { pb_open = false; break; }
+                stamp("blocked copy: count pass and scans done");
+                // does the matrix look like it has a value dictionary?  (a sample of the first values; arbitrary
+                // coefficients overflow the 256-entry table within the first thousands)
+                bool many = true;
+                if (cfg.value_dict && (int64_t)nnz >= (1 << 20)) {
+                    if ((rc = up.wait_on(st, m_first))) break;
+                    if ((rc = valdict_sample_overflows(st, (int64_t)(h.iA[pieces[0].row_end] - base), s->val, ctx->scratch, &many))) break;
+                }
+                if (many) {
+                    s->vd_tried = true;                  // (more than 256 distinct values, or the dictionary is switched off)
+                    piecewise = true;
+                }
             }
             // ---- values: piece by piece into the blocked copy, or all at once behind the dictionary
             if (piecewise) {
@@ -434,29 +451,41 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
                     if (sub_new > sub_done) sub_done = sub_new;
                 }
                 if (rc) break;
+                stamp("last fill piece enqueued");
             }
             if ((rc = up.wait_on(st, m_all))) break;
             if ((rc = up.finish())) break;
+            stamp("upload finished");
             *t_up = (up.t_done > 0.0 ? up.t_done : now_s()) - t0;
-            if ((rc = solver_setup_values(s))) break;
-            if (pb_open && !piecewise) {
-                if ((rc = ensure_valdict(s))) break;
-                if ((rc = pb_build_values(st, &pb, &s->vd))) { pb_open = false; break; }
-                if ((rc = pb_build_fill(st, &pb, s->rp, s->ci, s->val, &s->vd, 0, pb.p.NSUB))) { pb_open = false; break; }
-            }
-            if (pb_open) {
-                PbPlan plan;
-                pb_open = false;
-                if ((rc = pb_build_end(st, &pb, &plan))) break;
-                spmv_mode_adopt_blocked(s, plan, now_s() - t_pb0);
-            }
-            // what the statistics call set-up: the part of it that was NOT hidden behind the upload
-            if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("set-up beside the upload failed"); break; }
-            s->t_create = now_s() - (t0 + *t_up);
-            s->t_spmv_setup = 0.0;
         } while (0);
         if (rc) up.failed = 1;
     }      // (the uploader's threads are joined here whatever happened)
+    // ---- the rest may allocate and free again
+    do {
+        if (rc) break;
+        if ((rc = solver_setup_values(s))) break;
+        if (pb_open && !blocked) { pb_build_abort(&pb); pb_open = false; }        // another form: ensure_spmv_mode decides at the solve
+        if (pb_open && !piecewise) {
+            if ((rc = ensure_valdict(s))) break;
+            if (s->vd.n > 0) {                           // 8-bit indices instead of the fp64 values
+                hipFree(pb.p.pv);
+                pb.p.pv = nullptr;
+                if ((rc = pb_build_values(st, &pb, &s->vd))) { pb_open = false; break; }
+            }
+            if ((rc = pb_build_fill(st, &pb, s->rp, s->ci, s->val, &s->vd, 0, pb.p.NSUB))) { pb_open = false; break; }
+        }
+        if (pb_open) {
+            PbPlan plan;
+            pb_open = false;
+            if ((rc = pb_build_end(st, &pb, &plan))) break;
+            spmv_mode_adopt_blocked(s, plan, now_s() - t_pb0);
+        }
+        // what the statistics call set-up: the part of it that was NOT hidden behind the upload
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("set-up beside the upload failed"); break; }
+        s->t_create = now_s() - (t0 + *t_up);
+        s->t_spmv_setup = 0.0;
+        stamp("set-up complete");
+    } while (0);
     if (rc) {
         char saved[512];
         snprintf(saved, sizeof(saved), "%s", cudamat_last_error());

@@ -56,7 +56,8 @@ inline int plan_spmv_parts(const SpmvPlan &p) { return p.grid + (p.tiles ? p.til
 // `stream_rows` consecutive rows holds at most kStreamNnz entries (checked on the device); otherwise, when
 // the lanes-per-row kernel would spend > 2.5 lane-iterations per entry (skewed row lengths), switch it to the
 // nnz-balanced tile kernel.  CUDAMAT_SPMV_FORM=lanes|tiles forces one of the two.
-int plan_spmv_refine(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan);
+// scratch: >= 64 bytes of device memory for the plan's read-backs (cudamat_ctx::scratch); NULL: allocated and freed here
+int plan_spmv_refine(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan, void *scratch = nullptr);
 
 // y = alpha*(A x + d .* xd) + beta*y  on 0- or 1-based CSR (base folded into the
 // pointers by the caller).  dot: 0 none, 1: parts[2b] = sum y*w, 2: also

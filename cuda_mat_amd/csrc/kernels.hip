@@ -955,22 +955,22 @@ __global__ __launch_bounds__(kBlock) void k_tile_nnz_max(int n, const int *rp, i
 }
 
 // skewed row lengths: measure what the lanes-per-row plan would cost and switch to tiles when it is unbalanced
-static int plan_spmv_balance(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, SpmvPlan *plan)
+static int plan_spmv_balance(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, SpmvPlan *plan, void *scratch)
 {
     if (cfg.spmv_form == 1) return CUDAMAT_OK;          // lanes
     const bool force = cfg.spmv_form == 2;              // tiles
     if (nnz <= 0 || n_rows <= 0) return CUDAMAT_OK;
     if (!force) {
         if (nnz < 65536) return CUDAMAT_OK;
-        unsigned long long *d = nullptr, h = 0;
-        CM_HIP(hipMalloc((void **)&d, sizeof(h)));
+        unsigned long long *d = (unsigned long long *)scratch, h = 0;
+        if (!scratch) CM_HIP(hipMalloc((void **)&d, sizeof(h)));
         hipMemsetAsync(d, 0, sizeof(h), s);
         const long long groups = ((long long)n_rows + (64 / plan->lanes) - 1) / (64 / plan->lanes);
         hipLaunchKernelGGL(k_lane_cost, dim3((unsigned)((groups + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp,
                            plan->lanes, d);
         hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s);
         const hipError_t e = hipStreamSynchronize(s);
-        hipFree(d);
+        if (!scratch) hipFree(d);
         if (e != hipSuccess) return fail_hip(e, "lane cost", __FILE__, __LINE__);
         plan->lane_cost = (double)h * 64.0 / (double)nnz;
         // measured (scripts/skew_probe.py): at 2.0 (rows of 2 and 62 alternating) the lanes kernel is still memory-bound
@@ -980,28 +980,28 @@ static int plan_spmv_balance(hipStream_t s, const Config &cfg, int n_rows, int64
     return plan_spmv_tiles(s, n_rows, nnz, rp, plan);
 }
 
-int plan_spmv_refine(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan)
+int plan_spmv_refine(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, const int *rp, int base, SpmvPlan *plan, void *scratch)
 {
     (void)base;
     plan->stream_rows = 0;
     if (cfg.spmv_lanes) return CUDAMAT_OK;          // explicit lanes-per-row request
     const double mean = n_rows > 0 ? (double)nnz / n_rows : 0.0;
     if (n_rows < 64) return CUDAMAT_OK;
-    if (mean > 12.0) return plan_spmv_balance(s, cfg, n_rows, nnz, rp, plan);
-    int *d = nullptr, h[3] = {0, 0, 0};
-    CM_HIP(hipMalloc((void **)&d, 3 * sizeof(int)));
+    if (mean > 12.0) return plan_spmv_balance(s, cfg, n_rows, nnz, rp, plan, scratch);
+    int *d = (int *)scratch, h[3] = {0, 0, 0};
+    if (!scratch) CM_HIP(hipMalloc((void **)&d, 3 * sizeof(int)));
     hipMemsetAsync(d, 0, 3 * sizeof(int), s);
     const long long tiles = ((long long)n_rows + 63) / 64;
     hipLaunchKernelGGL(k_tile_nnz_max, dim3((unsigned)((tiles + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp, d);
     hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
-    hipFree(d);
+    if (!scratch) hipFree(d);
     if (e != hipSuccess) return fail_hip(e, "tile scan", __FILE__, __LINE__);
     int R = 0;
     if (h[2] <= kStreamNnz) R = 256;
     else if (h[1] <= kStreamNnz) R = 128;
     else if (h[0] <= kStreamNnz) R = 64;
-    if (!R) return plan_spmv_balance(s, cfg, n_rows, nnz, rp, plan);
+    if (!R) return plan_spmv_balance(s, cfg, n_rows, nnz, rp, plan, scratch);
     const long long tiles_r = ((long long)n_rows + R - 1) / R;
     int grid = (int)(tiles_r < kSpmvGridMax ? tiles_r : kSpmvGridMax);
     const long long per = (tiles_r + grid - 1) / grid;

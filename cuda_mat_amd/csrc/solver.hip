@@ -114,8 +114,7 @@ __global__ __launch_bounds__(kBlock) void k_check_columns(int n, long long n_col
 static int validate_csr(cudamat_solver *s)
 {
     hipStream_t st = s->ctx->stream;
-    int *d = nullptr, h[3] = {0, 0, 0};
-    CM_HIP(hipMalloc((void **)&d, sizeof(h)));
+    int *d = (int *)s->ctx->scratch, h[3] = {0, 0, 0};
     hipMemsetAsync(d, 0, sizeof(h), st);
     hipLaunchKernelGGL(k_check_rowptr, dim3((unsigned)(((long long)s->n + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, s->n,
                        (long long)s->nnz, s->rp, d);
@@ -127,7 +126,6 @@ static int validate_csr(cudamat_solver *s)
         hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
         e = hipStreamSynchronize(st);
     }
-    hipFree(d);
     if (e != hipSuccess) return fail_hip(e, "CSR validation", __FILE__, __LINE__);
     if (h[0]) { set_error("row pointers must start at the index base, never decrease and end at nnz"); return CUDAMAT_ERR_ARG; }
     if (h[1]) { set_error("a column index lies outside [base, base + n_cols)"); return CUDAMAT_ERR_ARG; }
@@ -200,7 +198,7 @@ int solver_setup_pattern(cudamat_solver *s)
     CM_TRY(validate_csr(s));
     stamp("validation");
     s->plan = plan_spmv(ctx->cfg, s->n, s->nnz);
-    CM_TRY(plan_spmv_refine(st, ctx->cfg, s->n, s->nnz, s->rp, 0, &s->plan));
+    CM_TRY(plan_spmv_refine(st, ctx->cfg, s->n, s->nnz, s->rp, 0, &s->plan, ctx->scratch));
     stamp("CSR launch plan (refine)");
     CM_TRY(plan_spmv_compress(st, ctx->cfg, s->n, s->nnz, s->rp, s->ci, &s->plan));
     stamp("compressed-index attempt");
@@ -503,14 +501,12 @@ static int col_span_bytes(cudamat_solver *s, double *out)
 {
     *out = 0.0;
     hipStream_t st = s->ctx->stream;
-    unsigned long long *d = nullptr, h[2] = {0ULL, 0ULL};
-    CM_HIP(hipMalloc((void **)&d, sizeof(h)));
+    unsigned long long *d = (unsigned long long *)s->ctx->scratch, h[2] = {0ULL, 0ULL};
     hipMemsetAsync(d, 0, sizeof(h), st);
     const int samples = s->n < 4096 ? s->n : 4096;
     hipLaunchKernelGGL(k_col_span, dim3((samples + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s->n, s->rp, s->ci, samples, d, (int *)(d + 1));
     hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(d);
     CM_HIP(e);
     const int cnt = (int)(h[1] & 0xffffffffULL);
     *out = cnt > 0 ? 8.0 * (double)h[0] / cnt : 0.0;

@@ -64,6 +64,9 @@ struct PbBuild {
 };
 int pb_build_begin(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
                    const PbCols *cols, PbBuild *b);
+// pb_build_begin in its two halves: every allocation (sizes only) / count pass + scans (needs rp, ci; allocates nothing)
+int pb_build_alloc(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const PbCols *cols, PbBuild *b);
+int pb_build_count(hipStream_t st, const Config &cfg, const int *rp, const int *ci, PbBuild *b);
 int pb_build_values(hipStream_t st, PbBuild *b, const ValDict *vd);
 int pb_build_fill(hipStream_t st, PbBuild *b, const int *rp, const int *ci, const double *val, const ValDict *vd, int sub0, int sub1);
 int pb_build_end(hipStream_t st, PbBuild *b, PbPlan *out);

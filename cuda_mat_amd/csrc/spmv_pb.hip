@@ -246,6 +246,13 @@ void pb_build_abort(PbBuild *b)
 int pb_build_begin(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
                    const PbCols *cols, PbBuild *b)
 {
+    CM_TRY(pb_build_alloc(st, cfg, n, n_cols, nnz, cols, b));
+    return pb_build_count(st, cfg, rp, ci, b);
+}
+
+// geometry and EVERY allocation of the copy except its value array: depends on the sizes only, not on the matrix
+int pb_build_alloc(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const PbCols *cols, PbBuild *b)
+{
     b->t0 = now_s();
     PbPlan &p = b->p;
     p = PbPlan();
@@ -368,13 +375,29 @@ int pb_build_begin(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int
                 hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb column cut upload failed"); break; }
         }
         b->cut = PbCut{(int)p.per, p.chunks, (int)p.chunk_len, p.bpc, p.CB};
-        const PbCut cut = b->cut;
         if ((rc = dalloc(&p.sstart, nbins))) break;
         if ((rc = dalloc(&p.slen, nbins))) break;
-        const unsigned grid = (unsigned)((p.NSUB + kPbBuildWaves - 1) / kPbBuildWaves);
-        const size_t lds = sizeof(int) * (size_t)kPbBuildWaves * p.NCB;
         if ((rc = set_max_lds((const void *)k_pb_rows<false>))) break;
         if ((rc = set_max_lds((const void *)k_pb_rows<true>))) break;
+    } while (0);
+    if (rc) pb_build_abort(b);
+    return rc;
+}
+
+// count pass and scans: the pattern (rp, ci) is in place.  No allocation, no free.
+int pb_build_count(hipStream_t st, const Config &cfg, const int *rp, const int *ci, PbBuild *b)
+{
+    PbPlan &p = b->p;
+    const int n = p.n;
+    const int64_t n_cols = p.n_cols, nnz = p.nnz;
+    const size_t nbins = (size_t)p.NCB * p.NSUB;
+    int *bins = b->bins;
+    constexpr int align = kPbAlign;
+    int rc = CUDAMAT_OK;
+    do {
+        const PbCut cut = b->cut;
+        const unsigned grid = (unsigned)((p.NSUB + kPbBuildWaves - 1) / kPbBuildWaves);
+        const size_t lds = sizeof(int) * (size_t)kPbBuildWaves * p.NCB;
         hipLaunchKernelGGL(k_pb_rows<false>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, (const double *)nullptr, cut, p.col0,
                            p.NCB, p.SR, p.NSUB, bins, (double *)nullptr, p.pc, p.pr, (const unsigned char *)nullptr, (unsigned char *)nullptr,
                            0, p.NSUB);
@@ -388,6 +411,23 @@ int pb_build_begin(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int
             hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb scan failed"); break; }
         if ((int64_t)counted < nnz || (int64_t)counted > nnz + (int64_t)(align - 1) * p.NCB) {
             rc = CUDAMAT_ERR_ARG; set_error("pb_build: counted %d entries, expected %lld", counted, (long long)nnz); break;
+        }
+        if (cfg.verbose) {
+            // the plan and how evenly the entries fall into its (sub-block, column block) segments: phase 2 is bound by fabric
+            // requests per segment, so a layout whose segments are much shorter or longer than the 48-entry target pays for it
+            std::vector<int> hl(nbins);
+            if (hipMemcpy(hl.data(), p.slen, sizeof(int) * nbins, hipMemcpyDeviceToHost) == hipSuccess) {
+                long long hist[7] = {0, 0, 0, 0, 0, 0, 0}, in_long = 0;
+                for (int v : hl) {
+                    hist[v == 0 ? 0 : v <= 8 ? 1 : v <= 24 ? 2 : v <= 48 ? 3 : v <= 64 ? 4 : v <= 128 ? 5 : 6]++;
+                    if (v > 64) in_long += v;
+                }
+                fprintf(stderr, "[cudamat] pb plan: %d x %lld, nnz %lld, NCB %d (CB %d), NSUB %d (NW %d, SR %d), LPS %d, depth %d; segments: "
+                                "empty %lld, 1-8 %lld, 9-24 %lld, 25-48 %lld, 49-64 %lld, 65-128 %lld, >128 %lld; %.1f %% of the entries in "
+                                "segments longer than a wave\n",
+                        n, (long long)n_cols, (long long)nnz, p.NCB, p.CB, p.NSUB, p.NW, p.SR, p.LPS, p.depth, hist[0], hist[1], hist[2], hist[3],
+                        hist[4], hist[5], hist[6], 100.0 * (double)in_long / (double)(nnz > 0 ? nnz : 1));
+            }
         }
     } while (0);
     if (rc) pb_build_abort(b);

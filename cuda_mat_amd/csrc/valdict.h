@@ -16,5 +16,8 @@ struct ValDict {
 // dictionary and the per-entry indices.  out->n == 0 afterwards means "no dictionary" (not an error).
 int valdict_build(hipStream_t st, const Config &cfg, int64_t nnz, const double *val, ValDict *out);
 void valdict_free(ValDict *d);
+// Do the first `count` values show more than kDictMax distinct bit patterns?  Uses `scratch` (>= 33 KB of device memory:
+// cudamat_ctx::scratch) for the probe table -- allocates nothing, frees nothing.  *many = true: no dictionary possible.
+int valdict_sample_overflows(hipStream_t st, int64_t count, const double *val, void *scratch, bool *many);
 
 }  // namespace cm

@@ -87,6 +87,26 @@ __global__ __launch_bounds__(kBlock) void k_dict_index(int64_t nnz, const double
     }
 }
 
+int valdict_sample_overflows(hipStream_t st, int64_t count, const double *val, void *scratch, bool *many)
+{
+    *many = false;
+    if (count <= 0) return CUDAMAT_OK;
+    unsigned long long *table = (unsigned long long *)scratch;
+    int *flags = (int *)((char *)scratch + sizeof(unsigned long long) * kTableSlots);
+    int h[2] = {0, 0};
+    hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) * kTableSlots, st);
+    hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+    int64_t g = (count + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_dict_probe, dim3((unsigned)g), dim3(kBlock), 0, st, (int64_t)0, count, val, table, flags);
+    if (hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        set_error("value dictionary: sample probe failed (%s)", hipGetErrorString(hipGetLastError()));
+        return CUDAMAT_ERR_HIP;
+    }
+    *many = h[1] != 0 || h[0] > kDictMax;
+    return CUDAMAT_OK;
+}
+
 void valdict_free(ValDict *v)
 {
     if (v->dict) hipFree(v->dict);

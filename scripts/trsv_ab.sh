@@ -5,6 +5,6 @@ R=$1; shift
 for r in $(seq $R); do for cfg in "$@"; do
   out=$(env $cfg timeout -k 10 300 python bench.py --precond ilu0 --steps 10 --warmup 2 --cpu-baseline off --drop-in off 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.3f ms per apply  %.2f it/s' % (d['trsv_ms_per_apply'], d['value']))")
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.3f ms per apply  %.2f it/s  SpMV in the loop %.4f ms' % (d['trsv_ms_per_apply'], d['value'], d['roofline']['avg_launch_ms']))")
   echo "run $r [$cfg] $out"
 done; done

@@ -1808,11 +1808,14 @@ def test_row_pattern_form_in_the_solver_loop_and_auto_selection(cm, ctx, oracle,
         sw("SPMV_MODE", mode)
         x, st, h = _solve_dev(cm, ctx, A, b, loop=cm.LOOP_PBICGSTAB, maxit=60, tol=0.0)
         assert st.iters == 60 and np.all(np.isfinite(h))
+        # the residual the loop carries is the true residual of the iterate it returns (fused dots and the half-step test in
+        # this form's prologue included)
+        assert abs(np.linalg.norm(b - oracle.spmv(A, x)) - st.nrm) <= 1e-9 * st.nrm0
         if ref is None:
-            ref = (x, h)
+            ref = h
         else:
-            # same products, same order inside every row; the dot partials are summed per workgroup in another grouping
-            np.testing.assert_allclose(h[:20], ref[1][:20], rtol=1e-9)
-            np.testing.assert_allclose(x, ref[0], rtol=1e-6, atol=1e-9)
+            # same products, same order inside every row; the dot partials are summed per workgroup in another grouping, and
+            # BiCGSTAB amplifies that over the iterations: the first 20 residuals agree to 1e-9
+            np.testing.assert_allclose(h[:20], ref[:20], rtol=1e-9)
     xo, so, ho = oracle.pbicgstab(A, b, maxit=60, tol=0.0, want_hist=True)
     np.testing.assert_allclose(h[:20], ho[:20], rtol=1e-8)
