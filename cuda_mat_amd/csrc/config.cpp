@@ -65,9 +65,6 @@ const Option kOptions[] = {
     OPT_FLAG("SHARDED_ONE_DEVICE", sharded_one_device,
              "1: cudamat_solve_sharded with every rank on device 0 and host-synchronised copies in place of RCCL (debugging aid)"),
     OPT_FLAG("PLAN_CACHE", plan_cache, "0: cudamat_solve does not keep the solver of its last call"),
-    OPT_INT("UPLOAD_THREADS", upload_threads, 0, 64,
-            "cudamat_solve: N > 0 host threads stage the caller's arrays into pinned buffers; 0 (default): the runtime reads the caller's memory directly"),
-    OPT_INT("UPLOAD_PIECE_MB", upload_piece_mb, 1, 4096, "cudamat_solve, direct upload: MB of the caller's memory handed to the runtime per call"),
     {"TEST_COMM_FAIL", K_FAIL, nullptr, nullptr, 0, 0, nullptr, "rank:k -- fault injection: that rank's k-th all-reduce reports an error (tests)"},
 };
 

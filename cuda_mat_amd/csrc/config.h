@@ -53,8 +53,6 @@ struct Config {
     int sharded_one_device = 0;   // SHARDED_ONE_DEVICE 1: cudamat_solve_sharded with every rank on device 0, host-synchronised copies for RCCL
     // ---- drop-in entry point
     int plan_cache = 1;           // PLAN_CACHE         0: cudamat_solve does not keep the solver of its last call
-    int upload_threads = 0;       // UPLOAD_THREADS     cudamat_solve: N > 0 threads stage the arrays into pinned buffers; 0: the runtime reads the caller's memory
-    int upload_piece_mb = 0;      // UPLOAD_PIECE_MB    direct upload: MB of the caller's memory handed to the runtime per call (0: 128)
     // ---- fault injection (tests)
     int fail_rank = -1, fail_call = -1;   // TEST_COMM_FAIL = rank:k   that rank's k-th all-reduce reports an error
 

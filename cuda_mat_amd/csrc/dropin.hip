@@ -4,14 +4,15 @@
 // The reference's wrappers allocate, upload, analyse, iterate and download one after the other (pbicgstab.cu:243-381).
 // At the BASELINE size the upload is 6.1 GB over PCIe -- four times the loop -- so here the rest of the set-up runs
 // BESIDE it:
-//   uploader    T host threads copy the caller's arrays chunk by chunk into pinned staging slots, one issuer enqueues the
-//               slot -> HBM copies on an upload stream in order: row pointers, column indices, values, b, x0, d;
-//               milestones (events) mark "pattern landed", "first values landed", "values up to row R landed", "all landed"
-//   this thread device allocations while the first bytes travel; at "pattern landed": validation, CSR launch plan, the
-//               choice of the SpMV form from the pattern and -- when that is the blocked two-phase form -- its geometry,
-//               tables and count pass; then the fill pass piece by piece behind the value milestones (or in one pass
-//               after the value dictionary is known, when the first values suggest the matrix has one)
-// so that when the last byte lands only the last piece of the fill, the loop and the download remain.
+//   uploader    one thread hands the caller's arrays to the runtime in order -- row pointers, column indices, values, b, x0,
+//               d -- on an upload stream; milestones (events) mark "pattern landed", "first values landed", "values up to
+//               row R landed", "all landed"
+//   this thread every device allocation FIRST (sizes only); at "pattern landed": validation, CSR launch plan, the choice of
+//               the SpMV form from the pattern and -- when that is the blocked two-phase form -- its count pass and scans;
+//               then the fill pass piece by piece behind the value milestones (or in one pass after the value dictionary
+//               is known, when the first values suggest the matrix has one).  No hipMalloc / hipFree while bytes travel.
+// so that when the last byte lands only the tail of the fill, the loop and the download remain: at C4 a first call takes
+// 0.171 s (upload 0.115 s at 53 GB/s, 17 ms of set-up not hidden, loop 0.031 s) where round 3 took 0.237 s.
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -33,70 +34,31 @@ static double now_s()
 namespace {
 
 // ---------------------------------------------------------------------------------------------------- uploader
-constexpr size_t kSlotBytes = 8u << 20;      // one staging slot / one PCIe transfer
-constexpr int kSlots = 8;                    // 64 MB of pinned host memory, kept with the plan cache
-constexpr size_t kDirectBytes = 128u << 20;  // one piece of the caller's memory handed to the runtime (direct form)
+// One thread hands the runtime the caller's (pageable) arrays in order, 128 MB at a time (hipMemcpyAsync from pageable
+// memory: the runtime pins the pages piece by piece and lets the DMA engines read them: 52-55 GB/s on the development
+// boxes); milestones (events recorded behind a piece) tell the set-up what has landed.  A second form -- host threads
+// staging 8 MB chunks into pinned slots -- was built and measured in round 4: 50 GB/s alone, 31-37 GB/s beside the set-up
+// kernels, 15 ms for its pinned slots; removed (HISTORY.md).
+constexpr size_t kPieceBytes = 128u << 20;
 
-struct PinnedPool {
-    char *slot[kSlots] = {};
-    hipEvent_t done[kSlots] = {};            // the slot's last slot -> HBM copy has completed
-    bool ready = false;
-    int acquire()
-    {
-        if (ready) return CUDAMAT_OK;
-        for (int i = 0; i < kSlots; i++) {
-            if (hipHostMalloc((void **)&slot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess ||
-                hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) {
-                set_error("pinned staging buffers unavailable");
-                release();
-                return CUDAMAT_ERR_HIP;
-            }
-        }
-        ready = true;
-        return CUDAMAT_OK;
-    }
-    void release()
-    {
-        for (int i = 0; i < kSlots; i++) {
-            if (slot[i]) hipHostFree(slot[i]);
-            if (done[i]) hipEventDestroy(done[i]);
-            slot[i] = nullptr;
-            done[i] = nullptr;
-        }
-        ready = false;
-    }
-};
-
-// Two ways to move the caller's (pageable) arrays, chosen per call (upload_mode):
-//   direct   the issuer thread hands the runtime 128 MB pieces of the caller's memory (hipMemcpyAsync from pageable memory:
-//            the runtime pins the pages piece by piece and lets the DMA engines read them; 41 GB/s on the development
-//            box) -- no host copy, one thread;
-//   staged   T threads copy 8 MB chunks into pinned slots, the issuer enqueues slot -> HBM copies: pays a host-side copy
-//            of every byte but keeps the PCIe link busy with pure DMA transfers; needs T free cores to win.
 struct Uploader {
     struct Chunk { char *dst; const char *src; size_t bytes; int milestone; };     // milestone: recorded AFTER this chunk (-1: none)
     std::vector<Chunk> chunks;
-    size_t chunk_bytes = kSlotBytes;             // staged: one slot; direct: kDirectBytes
-    bool direct = false;
     std::vector<hipEvent_t> ms_event;
     std::vector<std::atomic<int>> ms_recorded;
-    std::vector<std::atomic<int>> filled;       // per chunk: staged into its slot
-    std::atomic<size_t> next_fill{0};
-    std::atomic<size_t> issued{0};               // chunks whose slot -> HBM copy has been enqueued (and its slot event recorded)
     std::atomic<int> failed{0};
-    PinnedPool *pool = nullptr;
     hipStream_t stream = nullptr;
     int device = 0;
-    std::vector<std::thread> threads;
+    std::thread thread;
     double t_done = 0.0;
 
-    // append [src, src + bytes) -> dst in slot-sized chunks; returns the milestone id recorded after its last byte
+    // append [src, src + bytes) -> dst; returns the milestone id recorded after its last byte
     int add(void *dst, const void *src, size_t bytes)
     {
         const char *sp = (const char *)src;
         char *dp = (char *)dst;
-        for (size_t off = 0; off < bytes; off += chunk_bytes)
-            chunks.push_back(Chunk{dp + off, sp + off, bytes - off < chunk_bytes ? bytes - off : chunk_bytes, -1});
+        for (size_t off = 0; off < bytes; off += kPieceBytes)
+            chunks.push_back(Chunk{dp + off, sp + off, bytes - off < kPieceBytes ? bytes - off : kPieceBytes, -1});
         return mark();
     }
     // a milestone after everything added so far
@@ -110,79 +72,28 @@ struct Uploader {
         return chunks.back().milestone;
     }
 
-    // before the first add(): nthreads == 0 selects the direct form
-    void configure(int nthreads, int piece_mb = 0)
+    int start(int dev)
     {
-        direct = nthreads <= 0;
-        chunk_bytes = direct ? (piece_mb > 0 ? (size_t)piece_mb << 20 : kDirectBytes) : kSlotBytes;
-    }
-
-    int start(PinnedPool *p, int dev, int nthreads)
-    {
-        pool = p;
         device = dev;
-        if (direct) nthreads = 0;
-        else CM_TRY(p->acquire());
-        {
-            // the transfers go first: should the runtime move a piece with a copy kernel, it must not queue behind the set-up
-            // kernels that run beside the upload
-            int lo = 0, hi = 0;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
-            CM_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
-        }
+        CM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (hipEvent_t &e : ms_event) CM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ms_recorded = std::vector<std::atomic<int>>(ms_event.size());
         for (auto &a : ms_recorded) a = 0;
-        filled = std::vector<std::atomic<int>>(chunks.size());
-        for (auto &a : filled) a = 0;
-        threads.emplace_back([this] { issue(); });
-        for (int t = 0; t < nthreads; t++) threads.emplace_back([this] { stage(); });
+        thread = std::thread([this] { issue(); });
         return CUDAMAT_OK;
     }
 
-    // worker: claim the next chunk, wait until its slot is free again, copy the caller's bytes into it
-    void stage()
-    {
-        hipSetDevice(device);
-        for (;;) {
-            const size_t c = next_fill.fetch_add(1);
-            if (c >= chunks.size() || failed) return;
-            const int sl = (int)(c % kSlots);
-            if (c >= (size_t)kSlots) {
-                while (issued.load(std::memory_order_acquire) <= c - kSlots) {          // the slot's previous use has been enqueued ...
-                    if (failed) return;
-                    std::this_thread::yield();
-                }
-                if (hipEventSynchronize(pool->done[sl]) != hipSuccess) { failed = 1; return; }   // ... and has completed
-            }
-            memcpy(pool->slot[sl], chunks[c].src, chunks[c].bytes);
-            filled[c].store(1, std::memory_order_release);
-        }
-    }
-
-    // issuer: the slot -> HBM copies in chunk order on the upload stream
     void issue()
     {
         hipSetDevice(device);
         for (size_t c = 0; c < chunks.size(); c++) {
-            if (direct) {
-                if (failed) return;
-                if (hipMemcpyAsync(chunks[c].dst, chunks[c].src, chunks[c].bytes, hipMemcpyHostToDevice, stream) != hipSuccess) { failed = 1; return; }
-            } else {
-                while (!filled[c].load(std::memory_order_acquire)) {
-                    if (failed) return;
-                    std::this_thread::yield();
-                }
-                const int sl = (int)(c % kSlots);
-                if (hipMemcpyAsync(chunks[c].dst, pool->slot[sl], chunks[c].bytes, hipMemcpyHostToDevice, stream) != hipSuccess ||
-                    hipEventRecord(pool->done[sl], stream) != hipSuccess) { failed = 1; return; }
-            }
+            if (failed) return;
+            if (hipMemcpyAsync(chunks[c].dst, chunks[c].src, chunks[c].bytes, hipMemcpyHostToDevice, stream) != hipSuccess) { failed = 1; return; }
             const int m = chunks[c].milestone;
             if (m >= 0) {
                 if (hipEventRecord(ms_event[(size_t)m], stream) != hipSuccess) { failed = 1; return; }
                 ms_recorded[(size_t)m].store(1, std::memory_order_release);
             }
-            issued.store(c + 1, std::memory_order_release);
         }
         if (hipStreamSynchronize(stream) != hipSuccess) failed = 1;
         t_done = now_s();
@@ -194,7 +105,7 @@ struct Uploader {
         if (m < 0) return CUDAMAT_OK;
         while (!ms_recorded[(size_t)m].load(std::memory_order_acquire)) {
             if (failed) { set_error("upload failed"); return CUDAMAT_ERR_HIP; }
-            std::this_thread::yield();
+            std::this_thread::sleep_for(std::chrono::microseconds(50));      // (the uploader may share this thread's core)
         }
         CM_HIP(hipStreamWaitEvent(st, ms_event[(size_t)m], 0));
         return CUDAMAT_OK;
@@ -202,8 +113,7 @@ struct Uploader {
 
     void join()
     {
-        for (std::thread &t : threads) t.join();
-        threads.clear();
+        if (thread.joinable()) thread.join();
         for (hipEvent_t e : ms_event)
             if (e) hipEventDestroy(e);
         ms_event.clear();
@@ -215,14 +125,8 @@ struct Uploader {
         if (failed) { set_error("host-to-device upload failed (%s)", hipGetErrorString(hipGetLastError())); return CUDAMAT_ERR_HIP; }
         return CUDAMAT_OK;
     }
-    ~Uploader() { if (!threads.empty()) failed = 1; join(); }      // (an early exit: tell the threads to stop; never touches the error string)
+    ~Uploader() { if (thread.joinable()) failed = 1; join(); }      // (an early exit: tell the thread to stop; never touches the error string)
 };
-
-// staging threads of this call; 0 = the direct form (the default: measured on the development box, alternating, C4 arrays)
-int upload_threads(const Config &cfg)
-{
-    return cfg.upload_threads > 0 ? cfg.upload_threads : 0;
-}
 
 // ---------------------------------------------------------------------------------------------------- plan cache
 // The reference allocates, analyses, solves and frees per call (pbicgstab.cu:157-409).  Here the solver of the last
@@ -235,11 +139,10 @@ struct PlanCache {
     cudamat_solver *s = nullptr;
     int n = 0, nnz = 0, base = 0;
     double *d_d = nullptr;          // the (A0 + I d) diagonal the cached solver points at
-    PinnedPool pinned;              // the uploader's staging slots (kept across calls, released with the cache)
 };
 PlanCache g_cache;
 
-void cache_drop_locked(bool keep_pinned = false)
+void cache_drop_locked()
 {
     if (g_cache.s) cudamat_solver_destroy(g_cache.s);
     if (g_cache.d_d) cudamat_free(g_cache.ctx, g_cache.d_d);
@@ -247,7 +150,6 @@ void cache_drop_locked(bool keep_pinned = false)
     g_cache.s = nullptr;
     g_cache.d_d = nullptr;
     g_cache.ctx = nullptr;
-    if (!keep_pinned) g_cache.pinned.release();
 }
 
 }  // namespace
@@ -305,14 +207,13 @@ int build_or_reuse_candidate(cudamat_ctx *ctx, const Config &cfg, const HostSyst
         if ((rc = cudamat_malloc(ctx, sizeof(double) * (size_t)nnz, (void **)&d_val))) break;
         {
             Uploader up;
-            up.configure(upload_threads(cfg), cfg.upload_piece_mb);
-            up.add(d_rp, h.iA, sizeof(int) * ((size_t)n + 1));            // pbicgstab.cu:313-315
+                        up.add(d_rp, h.iA, sizeof(int) * ((size_t)n + 1));            // pbicgstab.cu:313-315
             up.add(d_ci, h.jA, sizeof(int) * (size_t)nnz);
             up.add(d_val, h.A, sizeof(double) * (size_t)nnz);
             up.add(d_b, h.b, sizeof(double) * (size_t)n);
             if (h.x0) up.add(d_x, h.x0, sizeof(double) * (size_t)n);
             if (h.d) up.add(d_d, h.d, sizeof(double) * (size_t)n);
-            if ((rc = up.start(&g_cache.pinned, ctx->device, upload_threads(cfg)))) break;
+            if ((rc = up.start(ctx->device))) break;
             if ((rc = up.finish())) break;
         }
         *t_up = now_s() - t0;
@@ -381,8 +282,7 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
     bool piecewise = false, blocked = false;
     if (rc == CUDAMAT_OK) {
         Uploader up;
-        up.configure(upload_threads(cfg), cfg.upload_piece_mb);
-        const int m_rp = up.add(s->rp, h.iA, sizeof(int) * ((size_t)n + 1));             // pbicgstab.cu:313-315
+                const int m_rp = up.add(s->rp, h.iA, sizeof(int) * ((size_t)n + 1));             // pbicgstab.cu:313-315
         const int m_pattern = nnz ? up.add(s->ci, h.jA, sizeof(int) * (size_t)nnz) : m_rp;
         // the values in pieces that end on row boundaries (~256 MB each): a piece's rows can be placed in the blocked
         // copy as soon as it has landed; the first piece is the value dictionary's sample
@@ -413,8 +313,8 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
         if (h.d) up.add(d_d, h.d, sizeof(double) * (size_t)n);
         const int m_all = up.mark();
         do {
-            if ((rc = up.start(&g_cache.pinned, ctx->device, upload_threads(cfg)))) break;
-            stamp(up.direct ? "uploader started (direct)" : "uploader started (staged, pinned slots ready)");
+            if ((rc = up.start(ctx->device))) break;
+            stamp("uploader started");
             // ---- pattern landed: index base, validation, CSR plan, the SpMV form
             if ((rc = up.wait_on(st, m_pattern))) break;
             stamp("pattern milestone recorded");
@@ -505,11 +405,11 @@ int solve_host_locked(const Config &cfg, const HostSystem &h, int precond, int l
     const int n = h.n, nnz = h.nnz, base = h.base;
     const double t0 = now_s();
     const bool use_cache = cfg.plan_cache != 0;
-    if (!use_cache) cache_drop_locked(true);
+    if (!use_cache) cache_drop_locked();
     // same shape as the cached system, same switches?  then its context (device, stream, options) carries this call too
     const bool candidate = use_cache && g_cache.s && g_cache.n == n && g_cache.nnz == nnz && g_cache.base == base &&
                            g_cache.ctx->cfg == cfg;
-    if (!candidate) cache_drop_locked(true);
+    if (!candidate) cache_drop_locked();
     cudamat_ctx *ctx = candidate ? g_cache.ctx : nullptr;
     if (!ctx) CM_TRY(cudamat_ctx_create(0, nullptr, &ctx));
     double *d_b = nullptr, *d_x = nullptr, *d_d = nullptr;
@@ -571,7 +471,6 @@ int solve_host_locked(const Config &cfg, const HostSystem &h, int precond, int l
         if (g_cache.d_d) { cudamat_free(ctx, g_cache.d_d); g_cache.d_d = nullptr; }
         cudamat_ctx_destroy(ctx);
         g_cache.ctx = nullptr;
-        if (!use_cache) g_cache.pinned.release();
     }
     if (rc) set_error("%s", saved);
     st.t_total = now_s() - t0;

@@ -1,6 +1,6 @@
-"""GPU box: what a drop-in call (cudamat_solve on host arrays, the C4 matrix) costs with the caller's memory read directly by the
-runtime (CUDAMAT_UPLOAD_THREADS=0, the default) and staged through pinned buffers by N host threads -- alternating, in a
-process whose threads are not bound to one core (no torch, OMP_PROC_BIND unset).   usage: python scripts/upload_probe.py [rows] [rounds]"""
+"""GPU box: what a drop-in call (cudamat_solve on host arrays, the C4 matrix) costs, first call and same matrix again, after a
+throw-away call (clocks, page tables and the runtime's buffers are cold in a new process); CUDAMAT_VERBOSE=1 prints the stage
+stamps of the first calls.   usage: python scripts/upload_probe.py [rows] [rounds]"""
 import os
 import sys
 import time
@@ -25,18 +25,13 @@ os.environ["CUDAMAT_VALUE_DICT"] = "0"
 api._solve(n, A.nnz, A.val, A.rowptr, A.colidx, None, None, b, cm.PRECOND_NONE, cm.LOOP_PBICGSTAB, 200, 1e-8, False)
 print("---- warm", flush=True)
 for r in range(rounds):
-    for threads in (os.environ.get("PROBE_THREADS") or "0,4,8,12").split(","):
-        os.environ["CUDAMAT_UPLOAD_THREADS"] = threads.split(":")[0]
-        os.environ.pop("CUDAMAT_UPLOAD_PIECE_MB", None)
-        if ":" in threads:
-            os.environ["CUDAMAT_UPLOAD_PIECE_MB"] = threads.split(":")[1]
-        for again in (0, 1):
-            if not again:
-                cm.lib().cudamat_plan_cache_clear()
-            t0 = time.perf_counter()
-            x, st = api._solve(n, A.nnz, A.val, A.rowptr, A.colidx, None, None, b, cm.PRECOND_NONE, cm.LOOP_PBICGSTAB, 200, 1e-8, False)
-            dt = time.perf_counter() - t0
-            print("round %d threads %5s %s: end to end %.4f s  upload %.4f s (%.1f GB/s)  exposed set-up %.4f s  loop %.4f s  iters %d  err %.1e"
-                  % (r, threads, "same matrix again" if again else "first call       ", dt, st.t_upload, 6.12 * n / 1e7 / max(st.t_upload, 1e-9),
-                     st.t_setup, st.t_solve, st.iters, float(np.abs(x - xs).max())), flush=True)
+    for again in (0, 1):
+        if not again:
+            cm.lib().cudamat_plan_cache_clear()
+        t0 = time.perf_counter()
+        x, st = api._solve(n, A.nnz, A.val, A.rowptr, A.colidx, None, None, b, cm.PRECOND_NONE, cm.LOOP_PBICGSTAB, 200, 1e-8, False)
+        dt = time.perf_counter() - t0
+        print("round %d %s: end to end %.4f s  upload %.4f s (%.1f GB/s)  set-up not hidden %.4f s  loop %.4f s  iters %d  err %.1e"
+              % (r, "same matrix again" if again else "first call       ", dt, st.t_upload, 6.12 * n / 1e7 / max(st.t_upload, 1e-9),
+                 st.t_setup, st.t_solve, st.iters, float(np.abs(x - xs).max())), flush=True)
 cm.lib().cudamat_plan_cache_clear()
