@@ -701,18 +701,34 @@ def run_bench(args):
     vec_bytes = 144.0 * nloc
     blocked = solver.spmv_mode() == 1
     kernel = solver.spmv_kernel() + (" (one SpMV = the pair)" if blocked else "")
+    # small systems: the SpMV rides inside a fused kernel (cudamat_stats.loop_form: 1 = the vector updates folded into the two
+    # SpMV launches, 2 = the whole loop in ONE launch) -- name the kernel a trace of the timed region shows
+    if st.loop_form == 2:
+        kernel = "k_resident_loop<%d> (the whole loop in one launch, grid barriers between its phases; SpMV rows as %s)" % (
+            256, solver.spmv_kernel())
+    elif st.loop_form == 1:
+        kernel = "k_fspmv (vector updates folded into the two SpMV launches of an iteration; rows as %s)" % solver.spmv_kernel()
     if n_spmv == 0:
         kernel += " (L2-resident, launch-latency-bound: per-launch timing off, no roofline quoted)"
     # HBM bytes per SpMV launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     # FETCH_SIZE doubled per the gfx950 calibration); only for the exact workload they were taken on
     traffic, traffic_src, traffic_parts = None, None, None
-    if world == 1 and args.workload == "rand50" and args.rows == 10_000_000 and args.per_row == 50:
+    prof_dir = None
+    if world == 1 and args.rows == 10_000_000 and precond == cm.PRECOND_NONE:
+        if args.workload == "rand50" and args.per_row == 50:
+            prof_dir = "*rand50"
+        elif args.workload == "poisson5" and args.nx == 4000:
+            prof_dir = "*poisson5"
+    if prof_dir:
         import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_fetch_write.json")), reverse=True):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", prof_dir, "pmc_fetch_write.json")), reverse=True):
             pm = json.load(open(f))
             # (kernel names as the trace prints them, without argument lists; phase 1 has a dictionary form)
-            p1 = "cm::k_pb_phase1_dict" if solver.value_dict() > 0 else "cm::k_pb_phase1"
-            want = [p1, "cm::k_pb_phase2<"] if blocked else ["cm::k_spmv<"]
+            if blocked:
+                p1 = "cm::k_pb_phase1_dict" if solver.value_dict() > 0 else "cm::k_pb_phase1"
+                want = [p1, "cm::k_pb_phase2<"]
+            else:
+                want = ["cm::" + solver.spmv_kernel()]
             got = [next((v for k, v in pm.items() if (k == w or (w.endswith("<") and k.startswith(w))) and isinstance(v, dict)
                          and "hbm_bytes_per_launch_corrected" in v), None) for w in want]
             if all(g is not None for g in got):
@@ -747,7 +763,8 @@ def run_bench(args):
                          "launches_timed": n_spmv,
                          "iteration_bytes": 2 * b_spmv + vec_bytes,
                          "iteration_frac": (2 * b_spmv + vec_bytes) * (args.steps / dt) / 1e9 / HBM_PEAK_GBS},
-            "spmv_gbs": achieved, "spmv_form": "blocked two-phase" if blocked else "csr (lanes-per-row / stream tiles)",
+            "spmv_gbs": achieved, "spmv_form": {1: "blocked two-phase", 2: "SELL-C-sigma", 3: "row-pattern dictionary"}.get(
+                solver.spmv_mode(), "csr (lanes-per-row / stream tiles)"),
             # 0: the timed kernels read fp64 values (8 B per entry).  The bench switches the library's value dictionary off
             # (CUDAMAT_VALUE_DICT=0) unless CUDAMAT_BENCH_HEADLINE=dict: SURVEY 8d's generator draws from 39 distinct values,
             # which the 8-bit dictionary form would exploit -- that run is the side figure `with_value_dictionary`
