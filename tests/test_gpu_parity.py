@@ -1454,6 +1454,19 @@ def test_drop_in_call_reuses_the_plan_of_the_previous_call(cm, oracle, monkeypat
     okf, xf, dtf, stf = cm.bicgstab(S.n, S.nnz, S.val, S.rowptr, S.colidx, bs, 200, 1e-8)
     assert okf and stf.spmv_mode == 1 and stf.t_tune > 0
     np.testing.assert_array_equal(xf, xs_)
+    # The first call above built its blocked copy BESIDE the upload (csrc/dropin.hip) -- behind the value dictionary, in one
+    # fill pass after the last byte; the full timing built it the ordinary way: same bits.  With fp64 values the copy is
+    # filled PIECE BY PIECE behind the value milestones (36 M entries: three pieces): same bits again, and nearly all of the
+    # set-up hidden behind the upload.
+    monkeypatch.delenv("CUDAMAT_SPMV_TUNE")
+    monkeypatch.setenv("CUDAMAT_VALUE_DICT", "0")
+    okv, xv, dtv, stv = cm.bicgstab(S.n, S.nnz, S.val, S.rowptr, S.colidx, bs, 200, 1e-8)
+    assert okv and stv.spmv_mode == 1 and stv.t_tune == 0 and stv.plan_reused == 0
+    np.testing.assert_array_equal(xv, xs_)
+    # index base 1 through the same path (rebased in place once the pattern has landed)
+    okb, xb, dtb, stb = cm.bicgstab(S.n, S.nnz, S.val, S.rowptr + 1, S.colidx + 1, bs, 200, 1e-8)
+    assert okb and stb.spmv_mode == 1
+    np.testing.assert_array_equal(xb, xs_)
     cm.lib().cudamat_plan_cache_clear()
 
 
