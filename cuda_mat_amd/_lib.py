@@ -79,6 +79,7 @@ _SIGS = {
     "cudamat_ctx_set_option": (C.c_int, [_P, C.c_char_p, C.c_char_p]),
     "cudamat_ctx_reset_options": (C.c_int, [_P]),
     "cudamat_options_help": (C.c_char_p, []),
+    "cudamat_option_check": (C.c_int, [C.c_char_p, C.c_char_p]),
     "cudamat_ctx_sync": (C.c_int, [_P]),
     "cudamat_ctx_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "cudamat_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

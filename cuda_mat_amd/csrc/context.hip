@@ -173,6 +173,13 @@ extern "C" int cudamat_ctx_reset_options(cudamat_ctx *ctx)
 
 extern "C" const char *cudamat_options_help(void) { return config_help(); }
 
+// would cudamat_ctx_set_option accept this pair?  (no context, no device needed: a host program can validate its settings)
+extern "C" int cudamat_option_check(const char *name, const char *value)
+{
+    Config scratch;
+    return config_set(scratch, name, value) ? CUDAMAT_OK : CUDAMAT_ERR_ARG;
+}
+
 extern "C" int cudamat_ctx_sync(cudamat_ctx *ctx)
 {
     CM_ARG(ctx, "ctx is NULL");

@@ -218,6 +218,7 @@ int cudamat_ctx_destroy(cudamat_ctx *ctx);
 int cudamat_ctx_set_option(cudamat_ctx *ctx, const char *name, const char *value);
 int cudamat_ctx_reset_options(cudamat_ctx *ctx);   /* back to what a context created now would hold (defaults + environment) */
 const char *cudamat_options_help(void);
+int cudamat_option_check(const char *name, const char *value);   /* CUDAMAT_OK when cudamat_ctx_set_option would accept the pair (no device needed) */
 int cudamat_ctx_sync(cudamat_ctx *ctx);
 int cudamat_ctx_stream(cudamat_ctx *ctx, void **stream);
 

@@ -188,3 +188,21 @@ def test_switches_live_in_one_table_and_the_library_reads_the_environment_in_one
         calls += len(re.findall(r"\bgetenv\s*\(", src))
     assert calls == 1, calls
     assert L.cudamat_ctx_set_option(None, b"VERBOSE", b"1") != 0 and L.cudamat_ctx_reset_options(None) != 0
+
+
+def test_option_values_are_validated_without_a_device():
+    """the rules of the switch table (csrc/config.cpp): flags take 0 | 1, counts their range, lanes powers of two, enums
+    their words; names with or without the CUDAMAT_ prefix; anything else is refused, never silently ignored"""
+    import cuda_mat_amd as cm
+    L = cm.lib()
+    ok = [("SPMV_MODE", "pb"), ("CUDAMAT_SPMV_MODE", "pat"), ("SPMV_LANES", "64"), ("PB_DEPTH", "16"), ("FUSED", "0"), ("FUSED", "1000000"),
+          ("RESIDENT_SPIN_LIMIT", "0"), ("TRSV_SYNCFREE", "1"), ("TEST_COMM_FAIL", "1:7"), ("PIPE_RR", "0"), ("SPMV_TUNE", "full"),
+          ("OVERLAP_CHUNKS", "16"), ("VERBOSE", "1")]
+    bad = [("SPMV_MODE", "ell"), ("SPMV_LANES", "3"), ("SPMV_LANES", "128"), ("PB_DEPTH", "5"), ("VERBOSE", "yes"), ("VERBOSE", ""),
+           ("TEST_COMM_FAIL", "7"), ("TRSV_GROUPS", "1"), ("OVERLAP_CHUNKS", "17"), ("NO_SUCH_SWITCH", "1"), ("PB_PIPELINE", "1"),
+           ("DEFER_X", "0"), ("FUSED", "-1"), ("PIPE_RR", "x")]
+    for name, value in ok:
+        assert L.cudamat_option_check(name.encode(), value.encode()) == 0, (name, value)
+    for name, value in bad:
+        assert L.cudamat_option_check(name.encode(), value.encode()) != 0, (name, value)
+        assert name.replace("CUDAMAT_", "") in L.cudamat_last_error().decode() or "unknown option" in L.cudamat_last_error().decode()
