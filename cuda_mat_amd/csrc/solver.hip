@@ -635,7 +635,8 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
     // rows repeat at most 255 shapes; 25 % padding at most.  At C3 it moves 0.58 GB per launch where the compressed
     // stream kernel moves 0.77 GB -- timed like every other candidate.
     if (force_pat || (!force_pb && !scattered && s->plan.stream_rows > 0 && s->n > 300000 && s->nnz >= (1 << 20))) {
-        const int rc = pat_build(st, s->n, s->nnz, s->rp, s->ci, s->val, &s->pat, force_pat ? 0.0 : 1.25);
+        CM_TRY(ensure_valdict(s));
+        const int rc = pat_build(st, s->n, s->nnz, s->rp, s->ci, s->val, &s->pat, force_pat ? 0.0 : 1.25, &s->vd);
         if (rc != CUDAMAT_OK && (force_pat || rc != CUDAMAT_ERR_ARG) && rc != CUDAMAT_ERR_NOMEM) return rc;
         if (rc != CUDAMAT_OK && force_pat) return rc;
         have[3] = rc == CUDAMAT_OK;
@@ -868,6 +869,7 @@ extern "C" int cudamat_solver_value_dict(cudamat_solver *s, int *distinct)
     *distinct = 0;
     if (s->spmv_mode == 1 && s->pb.pvi) *distinct = s->pb.ndict;
     else if (s->spmv_mode == 0 && s->plan.d_pbase) *distinct = s->vd.n;
+    else if (s->spmv_mode == 3 && s->pat.vidx) *distinct = s->pat.ndict;
     return CUDAMAT_OK;
 }
 
@@ -880,6 +882,7 @@ extern "C" int cudamat_solver_spmv_kernel(cudamat_solver *s, char *name, int cap
     const SpmvPlan &p = s->plan;
     if (s->spmv_mode == 1) snprintf(name, (size_t)cap, "%s + k_pb_phase2", s->pb.pvi ? "k_pb_phase1_dict" : "k_pb_phase1");
     else if (s->spmv_mode == 2) snprintf(name, (size_t)cap, "k_spmv_sell");
+    else if (s->spmv_mode == 3 && s->pat.vidx) snprintf(name, (size_t)cap, "k_spmv_pat_d<%d>", s->pat.vword / 8);
     else if (s->spmv_mode == 3) snprintf(name, (size_t)cap, "k_spmv_pat<%d>", s->pat.W <= 8 ? 8 : 16);
     else if (p.tiles > 0) snprintf(name, (size_t)cap, "k_spmv_tiles");
     else if (p.stream_rows && p.c_off16) snprintf(name, (size_t)cap, "%s<%d>", p.d_pbase ? "k_spmv_stream_d" : "k_spmv_stream_c", p.stream_rows);

@@ -56,7 +56,7 @@ static int dalloc(T **p, size_t count)
 
 void pat_free(PatPlan *p)
 {
-    void *ptrs[] = {p->val, p->pid, p->tab};
+    void *ptrs[] = {p->val, p->vidx, p->pid, p->tab};
     for (void *q : ptrs)
         if (q) hipFree(q);
     *p = PatPlan();
@@ -166,7 +166,22 @@ __global__ __launch_bounds__(kBlock) void k_pat_fill(int n, int nchunks, int W, 
     for (int j = 0; j < W; j++) dst[(size_t)j * kPatChunk] = j < len ? val[s + j] : 0.0;
 }
 
-int pat_build(hipStream_t st, int n, int64_t nnz, const int *rp, const int *ci, const double *val, PatPlan *out, double max_fill)
+// dictionary indices into one word per row (bytes in column order, the rest 0); one lane per row
+__global__ __launch_bounds__(kBlock) void k_pat_fill_idx(int n, long long padded, int vword, const int *rp, const unsigned char *idx,
+                                                         unsigned char *vidx)
+{
+    const long long row = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= padded) return;
+    const int s = row < n ? rp[row] : 0, len = row < n ? rp[row + 1] - s : 0;
+    unsigned long long w[2] = {0ull, 0ull};
+    for (int j = 0; j < len; j++) w[j >> 3] |= (unsigned long long)idx[s + j] << (8 * (j & 7));
+    unsigned long long *dst = (unsigned long long *)(vidx + (size_t)row * vword);
+    dst[0] = w[0];
+    if (vword == 16) dst[1] = w[1];
+}
+
+int pat_build(hipStream_t st, int n, int64_t nnz, const int *rp, const int *ci, const double *val, PatPlan *out, double max_fill,
+              const ValDict *vd)
 {
     const double t0 = now_s();
     PatPlan p;
@@ -242,8 +257,16 @@ int pat_build(hipStream_t st, int n, int64_t nnz, const int *rp, const int *ci, 
             hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pattern assignment failed"); break; }
         if (h[0]) { rc = CUDAMAT_ERR_ARG; set_error("pat_build: two row patterns share a hash key; this matrix keeps its indices"); break; }
-        if ((rc = dalloc(&p.val, (size_t)padded * p.W))) break;
-        hipLaunchKernelGGL(k_pat_fill, dim3((unsigned)((padded + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, p.nchunks, p.W, rp, val, p.val);
+        if (vd && vd->n > 0) {
+            p.vword = p.W <= 8 ? 8 : 16;
+            p.dict = vd->dict;
+            p.ndict = vd->n;
+            if ((rc = dalloc(&p.vidx, (size_t)padded * p.vword))) break;
+            hipLaunchKernelGGL(k_pat_fill_idx, dim3((unsigned)((padded + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, padded, p.vword, rp, vd->idx, p.vidx);
+        } else {
+            if ((rc = dalloc(&p.val, (size_t)padded * p.W))) break;
+            hipLaunchKernelGGL(k_pat_fill, dim3((unsigned)((padded + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, p.nchunks, p.W, rp, val, p.val);
+        }
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pattern fill failed"); break; }
     } while (0);
     void *tmp[] = {table, rep, flags, keys_dev, reps_dev};
@@ -343,9 +366,96 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pat(SpmvArgs a, int nchunks, in
     }
 }
 
+// The same with a VALUE DICTIONARY: a row's values are 8-bit indices packed into one 8- or 16-byte word (one coalesced
+// load per wave and chunk), the dictionary sits beside the pattern table in LDS; dict[index] IS the stored double, so the
+// products and their order are those of k_spmv_pat: bit-identical.  A stencil row then costs 8 + 1 bytes of matrix data.
+template <int WORDS>
+__global__ __launch_bounds__(kBlock) void k_spmv_pat_d(SpmvArgs a, int nchunks, int tiles_per_block, const unsigned char *pid,
+                                                       const int *tab, int npat_rows, const unsigned char *vidx, const double *dict)
+{
+#pragma clang fp contract(off)
+    constexpr int WMAX = 8 * WORDS;
+    __shared__ int stab[kPatMax * kPatRow];
+    __shared__ double dv[kDictMax];
+    __shared__ double lds[8];
+    if (a.loop.st) {
+        if (a.check == CHECK_HALF) {
+            if (check_half(a.loop, a.half, lds)) return;
+        } else if (a.loop.st->state != 0) {
+            return;
+        }
+    }
+    for (int i = threadIdx.x; i < npat_rows * kPatRow; i += kBlock) stab[i] = tab[i];
+    dv[threadIdx.x] = dict[threadIdx.x];                 // (kBlock == kDictMax == 256)
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const bool xcd_split = (nb & 7) == 0;
+    const int wg_per_set = xcd_split ? nb >> 3 : nb;
+    const int set = xcd_split ? (b & 7) : 0;
+    const int w = xcd_split ? (b >> 3) : b;
+    const long long set_tile0 = (long long)set * wg_per_set * tiles_per_block;
+    double acc[2] = {0.0, 0.0};
+    for (int t = 0; t < tiles_per_block; t++) {
+        const long long tile = set_tile0 + (long long)t * wg_per_set + w;
+        const long long c = tile * 4 + wave;
+        if (c >= nchunks) continue;
+        const long long rowl = c * kPatChunk + lane;
+        const int *e = stab + (int)pid[rowl] * kPatRow;
+        const int len = e[0];
+        unsigned long long word[WORDS];
+#pragma unroll
+        for (int q = 0; q < WORDS; q++) word[q] = __builtin_nontemporal_load((const unsigned long long *)(vidx + (size_t)rowl * (8 * WORDS)) + q);
+        double xv[WMAX];
+#pragma unroll
+        for (int j = 0; j < WMAX; j++)
+            if (j < len) xv[j] = a.x[rowl + e[1 + j]];
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < WMAX; j++)
+            if (j < len) {
+                const double prod = dv[(word[j >> 3] >> (8 * (j & 7))) & 0xffull] * xv[j];
+                sum = sum + prod;
+            }
+        if (rowl < a.n) {
+            const int row = (int)rowl;
+            if (a.d) {
+                const double dx = a.d[row] * a.xd[row];
+                sum = sum + dx;
+            }
+            double out = a.alpha * sum;
+            if (a.beta != 0.0) {
+                const double by = a.beta * a.y[row];
+                out = out + by;
+            }
+            a.y[row] = out;
+            if (a.dot) {
+                acc[0] += out * a.w[row];
+                acc[1] += out * out;
+            }
+        }
+    }
+    if (a.dot) {
+        block_sum<2>(acc, lds);
+        if (threadIdx.x == 0) {
+            a.parts[2 * b] = acc[0];
+            a.parts[2 * b + 1] = acc[1];
+        }
+    }
+}
+
 int launch_spmv_pat(hipStream_t st, const PatPlan &p, const SpmvArgs &a)
 {
     const int rows = p.npat + 1 < kPatMax ? p.npat + 1 : kPatMax;      // (+ the empty pattern of the padding rows)
+    if (p.vidx) {
+        static_assert(kBlock == kDictMax, "one dictionary entry per thread");
+        if (p.vword == 8)
+            hipLaunchKernelGGL(k_spmv_pat_d<1>, dim3(p.grid), dim3(kBlock), 0, st, a, p.nchunks, p.tiles_per_block, p.pid, p.tab, rows, p.vidx, p.dict);
+        else
+            hipLaunchKernelGGL(k_spmv_pat_d<2>, dim3(p.grid), dim3(kBlock), 0, st, a, p.nchunks, p.tiles_per_block, p.pid, p.tab, rows, p.vidx, p.dict);
+        CM_HIP(hipGetLastError());
+        return CUDAMAT_OK;
+    }
     if (p.W <= 8)
         hipLaunchKernelGGL(k_spmv_pat<8>, dim3(p.grid), dim3(kBlock), 0, st, a, p.nchunks, p.W, p.tiles_per_block, p.pid, p.tab, rows, p.val);
     else

@@ -54,7 +54,7 @@ def _bits(a):
 # Poisson matrix the tuner TIMES the compressed stream kernel against the row-pattern form and keeps the faster: on fp64
 # values that is the row-pattern form (0.113 against 0.149 ms), with the dictionary the stream kernel (0.095 against 0.109).
 _KERNELS = {("rand50", "fp64"): ("k_pb_phase1 + k_pb_phase2",), ("rand50", "dict"): ("k_pb_phase1_dict + k_pb_phase2",),
-            ("poisson5", "fp64"): ("k_spmv_pat<", "k_spmv_stream_c<"), ("poisson5", "dict"): ("k_spmv_stream_d<", "k_spmv_pat<")}
+            ("poisson5", "fp64"): ("k_spmv_pat<", "k_spmv_stream_c<"), ("poisson5", "dict"): ("k_spmv_stream_d<", "k_spmv_pat_d<")}
 
 
 def _values_env(monkeypatch, values):
@@ -109,8 +109,8 @@ def test_full_size_spmv_vs_oracle(cm, kind, values, monkeypatch):
         if form == "csr":
             assert name.startswith("k_spmv_stream_c<" if values == "fp64" else "k_spmv_stream_d<")
         if form == "pat":
-            assert name.startswith("k_spmv_pat<")
-        assert (s.value_dict() > 0) == (values == "dict" and not name.startswith("k_spmv_pat<"))
+            assert name.startswith("k_spmv_pat<" if values == "fp64" else "k_spmv_pat_d<")
+        assert (s.value_dict() > 0) == (values == "dict")
         for x in (x_int, x_real):
             d_x.upload(x)
             s.spmv(d_x, d_y)

@@ -1751,15 +1751,21 @@ def _stencil9(oracle, nx, ny, rng):
     return oracle.Csr(S.shape[0], S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), S.shape[0])
 
 
-@pytest.mark.parametrize("case", ["poisson_real", "nine_point", "empty_rows_base1", "tiny"])
+@pytest.mark.parametrize("case", ["poisson_real", "nine_point", "empty_rows_base1", "tiny", "poisson_dict", "nine_point_dict"])
 def test_row_pattern_spmv_is_bit_exact(cm, ctx, oracle, case, sw):
     """the row-pattern dictionary form (csrc/spmv_pat.hip: one byte per row instead of column indices) adds a row's
     products in column order with one rounding each -- the rounding sequence of `b[i] += A.Value[j] * x[A.Col[j]]`
     (bicstab.cpp:72-77): bit for bit the oracle's result on real-valued data, with the diagonal term, with rows of
-    different lengths, empty rows, a row count that is no multiple of the 64-row chunks, index base 1"""
+    different lengths, empty rows, a row count that is no multiple of the 64-row chunks, index base 1; and with a value
+    dictionary (few distinct values: one byte per entry packed into an 8- or 16-byte word per row, k_spmv_pat_d)"""
     sw("SPMV_MODE", "pat")
     rng = np.random.default_rng(12)
-    if case == "poisson_real":
+    if case == "poisson_dict":
+        A = oracle.poisson5(733, 417)                    # values 4 / -1: two distinct, 1.5 M entries
+    elif case == "nine_point_dict":
+        A = _stencil9(oracle, 700, 401, rng)             # rows of up to 9 entries: 16-byte index words
+        A.val[:] = rng.choice(np.array([-2.5, -1.0, 0.125, 3.0, 7.75]), A.nnz)
+    elif case == "poisson_real":
         A = oracle.poisson5(733, 417)
         A.val[:] = rng.standard_normal(A.nnz)
     elif case == "nine_point":
@@ -1778,7 +1784,11 @@ def test_row_pattern_spmv_is_bit_exact(cm, ctx, oracle, case, sw):
         A = oracle.Csr(n, (S.indptr + 1).astype(np.int32), (S.indices + 1).astype(np.int32), S.data.astype(np.float64), n)
     x = rng.standard_normal(A.n)
     s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val, n_cols=A.m)
-    assert s.spmv_mode() == 3 and s.spmv_kernel().startswith("k_spmv_pat<") and s.value_dict() == 0
+    assert s.spmv_mode() == 3
+    if case.endswith("_dict"):
+        assert s.spmv_kernel() == ("k_spmv_pat_d<1>" if case == "poisson_dict" else "k_spmv_pat_d<2>") and s.value_dict() == (2 if case == "poisson_dict" else 5)
+    else:
+        assert s.spmv_kernel().startswith("k_spmv_pat<") and s.value_dict() == 0
     s.close()
     np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), oracle.spmv(A, x))
     d = rng.standard_normal(A.n)
