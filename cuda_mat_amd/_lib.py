@@ -99,6 +99,7 @@ _SIGS = {
     "cudamat_axpy": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P]),
     "cudamat_scal": (C.c_int, [_P, C.c_int64, C.c_double, _P]),
     "cudamat_solver_create": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, C.c_int, C.POINTER(_P)]),
+    "cudamat_solver_create_host": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, C.c_int, C.POINTER(_P)]),
     "cudamat_solver_destroy": (C.c_int, [_P]),
     "cudamat_solver_set_shift": (C.c_int, [_P, _P]),
     "cudamat_solver_ilu0": (C.c_int, [_P]),

@@ -276,15 +276,20 @@ class Solver:
 
     @classmethod
     def from_host_csr(cls, ctx, rowptr, colidx, val, n_cols=None):
+        """cudamat_solver_create_host: the solver's set-up runs beside the upload of the host arrays"""
         rowptr, colidx, val = _np(rowptr, np.int32), _np(colidx, np.int32), _np(val, np.float64)
         n = len(rowptr) - 1
         base = int(rowptr[0])
         nnz = int(rowptr[-1]) - base
-        d_rp, d_ci, d_v = ctx.array(rowptr), ctx.array(colidx[:nnz] if nnz else np.zeros(1, np.int32)), \
-            ctx.array(val[:nnz] if nnz else np.zeros(1))
-        s = cls(ctx, n, n if n_cols is None else n_cols, nnz, d_rp, d_ci, d_v, base)
-        for a in (d_rp, d_ci, d_v):
-            a.free()   # the solver keeps its own rebased copy
+        if nnz == 0:
+            colidx, val = np.zeros(1, np.int32), np.zeros(1)
+        s = cls.__new__(cls)
+        s.ctx = ctx
+        s.n, s.n_cols, s.nnz = n, int(n if n_cols is None else n_cols), nnz
+        h = C.c_void_p()
+        check(_lib.lib().cudamat_solver_create_host(ctx.h, s.n, s.n_cols, s.nnz, _vp(rowptr), _vp(colidx), _vp(val), base, C.byref(h)))
+        s.h = h
+        s._keep = []
         return s
 
     def close(self):

@@ -184,6 +184,7 @@ namespace {
 
 struct HostSystem {
     int n, nnz, base;
+    int64_t n_cols;       // == n for the drop-in entry point; a row block of a wider matrix for cudamat_solver_create_host
     const double *A;
     const int *iA, *jA;
     const double *d, *x0, *b;
@@ -256,6 +257,7 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
 {
     const double t0 = now_s();
     const int n = h.n, nnz = h.nnz, base = h.base;
+    const int64_t n_cols = h.n_cols;
     hipStream_t st = ctx->stream;
     cudamat_solver *s = nullptr;
     *s_out = nullptr;
@@ -263,15 +265,18 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
     auto stamp = [&](const char *what) {
         if (verbose) fprintf(stderr, "[cudamat] drop-in %-52s at %8.3f ms\n", what, (now_s() - t0) * 1e3);
     };
-    CM_TRY(solver_alloc(ctx, n, n, nnz, &s));
+    CM_TRY(solver_alloc(ctx, n, n_cols, nnz, &s));
     // the blocked copy is a candidate by size (pb_candidate looks at sizes only): allocate it now, decide when the
     // pattern is there; a matrix that ends up with another form frees it after the upload
     PbBuild pb;
     bool pb_open = false;
-    const bool want_pb = cfg.spmv_mode != 0 && cfg.spmv_mode != 2 && cfg.spmv_mode != 3 && (cfg.spmv_mode == 1 || !cfg.spmv_tune_full) &&
-                         pb_candidate(st, n, n, nnz, nullptr, nullptr) && (cfg.spmv_mode == 1 || (int64_t)nnz >= 8 * (int64_t)n);
+    // (a row block of a wider matrix will be sharded by cudamat_solver_set_comm, which cuts the column blocks at the ranks'
+    // slices: its copy is built then)
+    const bool want_pb = n_cols == (int64_t)n && cfg.spmv_mode != 0 && cfg.spmv_mode != 2 && cfg.spmv_mode != 3 &&
+                         (cfg.spmv_mode == 1 || !cfg.spmv_tune_full) && pb_candidate(st, n, n_cols, nnz, nullptr, nullptr) &&
+                         (cfg.spmv_mode == 1 || (int64_t)nnz >= 8 * (int64_t)n);
     if (want_pb) {
-        const int rcb = pb_build_alloc(st, cfg, n, n, nnz, nullptr, &pb);
+        const int rcb = pb_build_alloc(st, cfg, n, n_cols, nnz, nullptr, &pb);
         pb_open = rcb == CUDAMAT_OK;                     // (no room / outside the form's limits: ensure_spmv_mode decides later)
         if (pb_open && pb_build_values(st, &pb, nullptr) != CUDAMAT_OK) pb_open = false;      // fp64 value array (4 GB at C4); a matrix
     }                                                                                        // with a dictionary swaps it afterwards
@@ -286,7 +291,7 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
         const int m_pattern = nnz ? up.add(s->ci, h.jA, sizeof(int) * (size_t)nnz) : m_rp;
         // the values in pieces that end on row boundaries (~256 MB each): a piece's rows can be placed in the blocked
         // copy as soon as it has landed; the first piece is the value dictionary's sample
-        struct Piece { int row_end; int milestone; };
+        struct Piece { int row_end; int milestone; size_t entries_end; };
         std::vector<Piece> pieces;
         int m_first = m_pattern;
         {
@@ -300,15 +305,18 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
                     const int mid = lo + (hi - lo) / 2;
                     if ((size_t)(h.iA[mid] - base) >= want) hi = mid; else lo = mid + 1;
                 }
-                const int row_end = lo;                                    // rows [.., row_end) are complete after this piece
-                const size_t cut = (size_t)(h.iA[row_end] - base);         // (row_end == n: cut == nnz)
-                const int m = up.add(s->val + e0, h.A + e0, sizeof(double) * (cut - e0));
+                int row_end = lo;                                          // rows [.., row_end) are complete after this piece
+                long long cut = (long long)h.iA[row_end] - base;           // (row_end == n: cut == nnz)
+                // (row pointers that are not what they should be -- the device-side validation will refuse the matrix --
+                // must not send the uploader astray: everything that is left becomes one piece)
+                if (cut <= (long long)e0 || cut > (long long)nnz) { cut = nnz; row_end = n; }
+                const int m = up.add(s->val + e0, h.A + e0, sizeof(double) * ((size_t)cut - e0));
                 if (pieces.empty()) m_first = m;
-                pieces.push_back(Piece{row_end, m});
-                e0 = cut;
+                pieces.push_back(Piece{row_end, m, (size_t)cut});
+                e0 = (size_t)cut;
             }
         }
-        up.add(d_b, h.b, sizeof(double) * (size_t)n);
+        if (h.b) up.add(d_b, h.b, sizeof(double) * (size_t)n);
         if (h.x0) up.add(d_x, h.x0, sizeof(double) * (size_t)n);
         if (h.d) up.add(d_d, h.d, sizeof(double) * (size_t)n);
         const int m_all = up.mark();
@@ -334,7 +342,7 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
                 bool many = true;
                 if (cfg.value_dict && (int64_t)nnz >= (1 << 20)) {
                     if ((rc = up.wait_on(st, m_first))) break;
-                    if ((rc = valdict_sample_overflows(st, (int64_t)(h.iA[pieces[0].row_end] - base), s->val, ctx->scratch, &many))) break;
+                    if ((rc = valdict_sample_overflows(st, (int64_t)pieces[0].entries_end, s->val, ctx->scratch, &many))) break;
                 }
                 if (many) {
                     s->vd_tried = true;                  // (more than 256 distinct values, or the dictionary is switched off)
@@ -491,7 +499,7 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
     CM_ARG(iA[n] - base == nnz, "nnz != iA[n] - iA[0]");
     if (debug && loop == CUDAMAT_LOOP_PBICGSTAB) printf("N=%d, nnz=%d\n", n, nnz);   // :204
     const Config cfg = config_from_env();                          // no caller-made context: the switches of THIS call
-    const HostSystem h{n, nnz, base, A, iA, jA, d, x0, b};
+    const HostSystem h{n, nnz, base, (int64_t)n, A, iA, jA, d, x0, b};
     std::lock_guard<std::mutex> cache_lock(g_cache.mu);            // (the entry points are not re-entrant upstream either)
     int rc = solve_host_locked(cfg, h, precond, loop, maxit, tol, debug, x, out);
     if (rc == CUDAMAT_ERR_NOMEM) {
@@ -501,4 +509,21 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
         rc = solve_host_locked(cfg, h, precond, loop, maxit, tol, debug, x, out);
     }
     return rc;
+}
+
+// cudamat_solver_create from HOST arrays: the same staged creation, run beside the upload (what cudamat_solve does for its
+// matrix).  For a host program that keeps its system resident (cudamat_solver_*) but holds the matrix in host memory.
+extern "C" int cudamat_solver_create_host(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz, const int *rowptr,
+                                          const int *colidx, const double *val, int base, cudamat_solver **out)
+{
+    CM_ARG(ctx && out, "null pointer");
+    *out = nullptr;
+    CM_ARG(base == 0 || base == 1, "base in {0,1}");
+    CM_ARG(rowptr && (nnz == 0 || (colidx && val)), "null CSR array");
+    CM_ARG(n_local >= 0 && n_cols >= n_local && nnz >= 0 && nnz < (1LL << 31) && n_cols < (1LL << 31), "sizes");
+    CM_ARG(rowptr[0] == base && (int64_t)rowptr[n_local] - base == nnz, "row pointers must start at the base and end at base + nnz");
+    Range range_create("cudamat: solver create from host arrays (set-up beside the upload)");
+    const HostSystem h{n_local, (int)nnz, base, n_cols, val, rowptr, colidx, nullptr, nullptr, nullptr};
+    double t_up = 0.0;
+    return build_beside_upload(ctx, ctx->cfg, h, nullptr, nullptr, nullptr, out, &t_up);
 }

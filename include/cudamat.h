@@ -263,6 +263,12 @@ int cudamat_scal(cudamat_ctx *ctx, int64_t n, double alpha, double *x);
 int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz,
                           const int *rowptr, const int *colidx, const double *val,
                           int base, cudamat_solver **out);
+/* The same from HOST arrays (any pageable memory): creation runs beside the upload -- validation and the SpMV plan start
+ * when the row pointers and column indices have landed, a blocked copy is filled behind the values.
+ * rowptr[0] must equal base.                                                                                           */
+int cudamat_solver_create_host(cudamat_ctx *ctx, int n_local, int64_t n_cols, int64_t nnz,
+                               const int *rowptr_host, const int *colidx_host, const double *val_host,
+                               int base, cudamat_solver **out);
 int cudamat_solver_destroy(cudamat_solver *s);
 /* (A0 + diag(d)) variant, pbicgstab.h:116; d is a device vector of n_local doubles
  * that must stay alive; NULL removes it.                                             */
