@@ -170,6 +170,51 @@ for case in range(ncase):
         if not np.array_equal(outs[0], outs[1]): msgs.append("dependency-driven trsv differs from level trsv")
         lu = O.ilu0(A); ref = O.trsv_upper(A, lu, O.trsv_lower_unit(A, lu, rhs))
         if np.linalg.norm(outs[0] - ref) > 1e-9 * np.linalg.norm(ref) + 1e-300: msgs.append("trsv vs oracle")
+    # every fifth case also brings a STENCIL-like system of its own (own generator: the draws above stay what they were): a few
+    # diagonals at random offsets, clipped at the boundary, real or few-valued -- the row-pattern dictionary forms
+    # (csrc/spmv_pat.hip: k_spmv_pat / k_spmv_pat_d) forced, against the oracle bit for bit, and one solve through them
+    if case % 5 == 4:
+        r2 = np.random.default_rng(1000 * (int(sys.argv[1]) if len(sys.argv) > 1 else 0) + case)
+        n2 = int(r2.integers(70000, 400000))
+        offs = np.unique(np.concatenate([[0], r2.integers(-n2 // 3, n2 // 3, int(r2.integers(2, 9)))]))
+        few = bool(r2.integers(0, 2))
+        diags = []
+        for o in offs:
+            m = n2 - abs(int(o))
+            diags.append(r2.choice(np.array([-1.0, -0.25, 0.5]), m) if few else r2.uniform(-1, 1, m))
+        S2 = sp.diags(diags, [int(o) for o in offs], shape=(n2, n2), format="lil")
+        for r in r2.integers(0, n2, 4): S2[int(r), :] = 0                  # a few empty rows
+        S2 = S2.tocsr(); S2.setdiag(0); S2.eliminate_zeros()
+        rs2 = np.asarray(abs(S2).sum(axis=1)).ravel()
+        S2 = (S2 + sp.diags(8.0 * np.ceil((rs2 + 1.5) / 8.0) if few else 1.0 + rs2 + r2.random(n2))).tocsr(); S2.sort_indices()
+        b2 = int(r2.integers(0, 2))
+        A2 = O.Csr(n2, (S2.indptr + b2).astype(np.int32), (S2.indices + b2).astype(np.int32), S2.data.copy(), n2)
+        x2 = r2.standard_normal(n2); want2 = O.spmv(A2, x2)
+        for mode in ("pat", None):
+            ctx.reset_options()
+            if mode: ctx.set_option("SPMV_MODE", mode)
+            try:
+                s2 = cm.Solver.from_host_csr(ctx, A2.rowptr, A2.colidx, A2.val)
+                dx, dy = ctx.array(x2), ctx.empty(n2)
+                s2.spmv(dx, dy)
+                name = s2.spmv_kernel()
+                if mode == "pat" and not name.startswith("k_spmv_pat"): msgs.append("stencil: forced pat runs %s" % name)
+                if name.startswith("k_spmv_pat") and not np.array_equal(dy.download(), want2): msgs.append("stencil: %s not bit-exact" % name)
+                elif not np.allclose(dy.download(), want2, rtol=1e-12, atol=1e-12): msgs.append("stencil: %s differs" % name)
+                if mode == "pat":
+                    xs2 = 1.0 + r2.random(n2); bb = O.spmv(A2, xs2)
+                    db, dxx = ctx.array(bb), ctx.array(np.ones(n2))
+                    st2 = s2.solve(db, dxx, loop=0, maxit=300, tol=1e-9)
+                    xo2, so2 = O.pbicgstab(A2, bb, maxit=300, tol=1e-9)
+                    if bool(st2.converged) != bool(so2.converged) or (st2.converged and abs(st2.iters - so2.iters) > max(2, 0.1 * so2.iters)):
+                        msgs.append("stencil: solve through %s: %d iterations (converged %d) vs %d (%d)" % (name, st2.iters, st2.converged, so2.iters, so2.converged))
+                    elif st2.converged and np.linalg.norm(dxx.download() - xo2) > 1e-5 * np.linalg.norm(xo2): msgs.append("stencil: x differs")
+                    for a in (db, dxx): a.free()
+                for a in (dx, dy): a.free()
+                s2.close()
+            except cm.CudamatError as e:
+                msgs.append("stencil (%s): %s" % (mode, e))
+        ctx.reset_options()
     if msgs:
         bad += 1
         print("case %d n=%d per=%g base=%d: %s" % (case, n, per, base, "; ".join(msgs)), flush=True)
