@@ -12,6 +12,7 @@ ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = 0
 forms = {}
 dicts = 0
+stencils = {}
 
 
 def oracle_spread(A, b, loop, precond, first, nperm=8):
@@ -199,6 +200,7 @@ for case in range(ncase):
                 s2.spmv(dx, dy)
                 name = s2.spmv_kernel()
                 if mode == "pat" and not name.startswith("k_spmv_pat"): msgs.append("stencil: forced pat runs %s" % name)
+                if mode == "pat": stencils[name] = stencils.get(name, 0) + 1
                 if name.startswith("k_spmv_pat") and not np.array_equal(dy.download(), want2): msgs.append("stencil: %s not bit-exact" % name)
                 elif not np.allclose(dy.download(), want2, rtol=1e-12, atol=1e-12): msgs.append("stencil: %s differs" % name)
                 if mode == "pat":
@@ -218,4 +220,5 @@ for case in range(ncase):
     if msgs:
         bad += 1
         print("case %d n=%d per=%g base=%d: %s" % (case, n, per, base, "; ".join(msgs)), flush=True)
-print("soak: %d cases, %d with findings; solves by loop form (0 five launches, 1 three, 2 one): %s" % (ncase, bad, sorted(forms.items())) + "; SpMV runs on a value dictionary: %d" % dicts)
+print("soak: %d cases, %d with findings; solves by loop form (0 five launches, 1 three, 2 one): %s" % (ncase, bad, sorted(forms.items())) + "; SpMV runs on a value dictionary: %d" % dicts
+      + "; stencil systems through the row-pattern forms: %s" % sorted(stencils.items()))
