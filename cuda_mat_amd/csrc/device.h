@@ -113,4 +113,87 @@ __device__ __forceinline__ bool check_half(const LoopArgs &la, const ScalarSrc &
     return false;
 }
 
+// full-step test of iteration it-1, pbicgstab.cu:142-151 / :723-742.  sc = (rw.r, r.r)
+__device__ __forceinline__ bool check_full(const LoopArgs &la, const double (&sc)[2])
+{
+    LoopState *st = la.st;
+    const int it = st->it;
+    if (it == 0) return false;
+    const double nrm = sqrt(sc[1]);
+    const double omega = st->omega;
+    if (leader()) {
+        st->nrm = nrm;
+        if (la.hist) {
+            const int slot = (la.loop != CUDAMAT_LOOP_PBICGSTAB2) ? 2 * (it - 1) + 1 : it - 1;
+            if (slot < la.hist_cap) la.hist[slot] = nrm;
+        }
+    }
+    if (la.no_exit) return false;
+    if (nrm < st->tolabs) {
+        if (leader()) st->state = 2;
+        return true;
+    }
+    if (la.loop == CUDAMAT_LOOP_PBICGSTAB2 && (fabs(omega) < 1e-5 || isnan(omega))) {
+        if (leader()) st->state = 3;
+        return true;
+    }
+    if (isnan(nrm)) {                       // (see check_half)
+        if (leader()) st->state = 3;
+        return true;
+    }
+    return false;
+}
+
+// entries of one stream tile (kernels.h: SpmvPlan.stream_rows); LDS: kStreamNnz products + R+1 row pointers
+constexpr int kStreamNnz = 2048;
+
+// exclusive scan of one int per thread over the workgroup; *total = the sum
+__device__ __forceinline__ int block_scan_int(int v, int *lds_waves, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();                       // lds_waves may still be read from the previous round
+    if (lane == 63) lds_waves[wave] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) {
+        const int t = lds_waves[w];
+        if (w < wave) before += t;
+        all += t;
+    }
+    *total = all;
+    return before + inc - v;
+}
+
+// y = alpha*(sum + d.*xd) + beta*y for one row, and the row's share of the fused dots (w.y, y.y)
+__device__ __forceinline__ void spmv_finish_row(const SpmvArgs &a, int row, double sum, double (&acc)[2])
+{
+    if (a.d) sum += a.d[row] * a.xd[row];
+    double out = a.alpha * sum;
+    if (a.beta != 0.0) out += a.beta * a.y[row];
+    a.y[row] = out;
+    if (a.dot) {
+        acc[0] += out * a.w[row];
+        acc[1] += out * out;
+    }
+}
+
+// ---- streaming vector kernels: 16 bytes per lane (double2) whenever every operand is 16-byte aligned
+static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+#define COMMA ,
+#define CM_VEC_LOOP(N, BODY2, BODY1)                                                   \
+    {                                                                                  \
+        const int64_t n2__ = VEC ? (N) / 2 : 0;                                        \
+        const int64_t stride__ = (int64_t)gridDim.x * kBlock;                          \
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2__; i += stride__) { BODY2 } \
+        for (int64_t i = 2 * n2__ + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < (N); i += stride__) { BODY1 } \
+    }
+
 }  // namespace cm

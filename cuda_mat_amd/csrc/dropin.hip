@@ -208,7 +208,7 @@ int build_or_reuse_candidate(cudamat_ctx *ctx, const Config &cfg, const HostSyst
         if ((rc = cudamat_malloc(ctx, sizeof(double) * (size_t)nnz, (void **)&d_val))) break;
         {
             Uploader up;
-                        up.add(d_rp, h.iA, sizeof(int) * ((size_t)n + 1));            // pbicgstab.cu:313-315
+            up.add(d_rp, h.iA, sizeof(int) * ((size_t)n + 1));            // pbicgstab.cu:313-315
             up.add(d_ci, h.jA, sizeof(int) * (size_t)nnz);
             up.add(d_val, h.A, sizeof(double) * (size_t)nnz);
             up.add(d_b, h.b, sizeof(double) * (size_t)n);
@@ -287,7 +287,7 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
     bool piecewise = false, blocked = false;
     if (rc == CUDAMAT_OK) {
         Uploader up;
-                const int m_rp = up.add(s->rp, h.iA, sizeof(int) * ((size_t)n + 1));             // pbicgstab.cu:313-315
+        const int m_rp = up.add(s->rp, h.iA, sizeof(int) * ((size_t)n + 1));             // pbicgstab.cu:313-315
         const int m_pattern = nnz ? up.add(s->ci, h.jA, sizeof(int) * (size_t)nnz) : m_rp;
         // the values in pieces that end on row boundaries (~256 MB each): a piece's rows can be placed in the blocked
         // copy as soon as it has landed; the first piece is the value dictionary's sample

@@ -83,7 +83,7 @@ struct SpmvArgs {
 };
 int launch_spmv(hipStream_t s, const SpmvPlan &plan, const SpmvArgs &a);
 
-// fused loop of small systems: the SpMV computes its input vector on the fly (kernels.hip, "fused loop")
+// fused loop of small systems: the SpMV computes its input vector on the fly (small_loops.hip)
 struct FuseArgs {
     int mode;                              // 1: p' = r + beta (p - omega v);  2: s = r - alpha v
     const double *r;
@@ -95,7 +95,7 @@ struct FuseArgs {
     ScalarSrc src;                         // mode 1: (rw.r, ||r||^2) partials;  mode 2: rw.v partials
     double *parts_half;                    // mode 2: ||s||^2 partial of every workgroup
 };
-// the whole loop in one launch (small systems; kernels.hip "resident loop")
+// the whole loop in one launch (small systems; small_loops.hip)
 struct ResidentArgs {
     int iters;                 // iterations this launch may run (it stops early when a test fires)
     int first_count;           // partial sums behind parts_full at this launch's first iteration
@@ -137,7 +137,7 @@ int launch_half(hipStream_t s, LoopArgs la, ScalarSrc rv, int64_t n, double *r, 
 int launch_full(hipStream_t s, LoopArgs la, ScalarSrc tt, int64_t n, double *x, const double *sv,
                 double *r, const double *t, const double *rw, double *parts, int *nparts,
                 ScalarSrc half = ScalarSrc{nullptr, 0, 1}, const double *pw = nullptr);
-// pipelined BiCGStab (kernels.hip, "pipelined BiCGStab"): partials of k_pipe_a have stride 3, of k_pipe_b stride 5
+// pipelined BiCGStab (pipelined.hip): partials of k_pipe_a have stride 3, of k_pipe_b stride 5
 int launch_pipe_seed(hipStream_t s, ScalarSrc init, ScalarSrc rww, double *out5);
 // the hatted (M^-1-applied) vectors of the preconditioned form; all NULL without a preconditioner
 struct PipeHatA { const double *rh, *wh, *zh; double *sh, *qh; };

@@ -305,7 +305,7 @@ int Solve::iterate_pipelined(int k)
 
 // ============================================================================================ small systems
 // Vectors resident in L2: three launches per iteration instead of five -- the vector updates in front of the two SpMVs
-// are folded into them (kernels.hip, "fused loop"); p, v and r are double-buffered.
+// are folded into them (small_loops.hip); p, v and r are double-buffered.
 // Measured (bench.py, one MI355X): 5-point stencil rows 38.5 -> 46.3 k it/s at 1e4 rows, 37.7 -> 43.8 k at 4e4, 30.4 ->
 // 32.1 k at 1.6e5, even at 4.9e5, slower beyond; with 50 entries per row the three gathers per entry cost more than the
 // two launches save (29.9 -> 24.1 k it/s at 2e4 rows).  So: short rows (the stream-tile plan) up to 3e5 rows.  The option
@@ -319,7 +319,7 @@ bool Solve::wants_fused() const
 }
 
 // Very small systems (one stream tile per workgroup, at most one workgroup per two compute units): the whole loop in ONE
-// launch, grid barriers instead of launch boundaries (kernels.hip, "resident loop").  The option RESIDENT = 0 disables.
+// launch, grid barriers instead of launch boundaries (small_loops.hip).  The option RESIDENT = 0 disables.
 bool Solve::wants_resident()
 {
     if (loop_form != 1 || profile || s->resident_off || !cfg->resident || !resident_loop_supported(s->plan, n)) return false;

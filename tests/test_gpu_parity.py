@@ -1089,7 +1089,7 @@ def test_ilu0_very_long_rows(cm, ctx, oracle, n, longest):
 @pytest.mark.parametrize("name", ["mat900", "mat10000", "rand3000x40", "tiny5"])
 @pytest.mark.parametrize("loop", ["pbicgstab", "pbicgstab2_d"])
 def test_fused_small_system_loop_equals_five_launch_loop(cm, ctx, oracle, golden_dir, name, loop, sw):
-    """three launches per iteration (vector updates folded into the SpMVs, csrc/kernels.hip 'fused loop') against
+    """three launches per iteration (vector updates folded into the SpMVs, csrc/small_loops.hip) against
     the five-launch loop: same expressions element by element, only ||s||^2 is summed per SpMV workgroup instead of
     per vector chunk; both forms (stream tiles / lanes per row), both loops, with and without the diagonal shift"""
     if name == "rand3000x40":
