@@ -23,7 +23,7 @@ struct TriFactor {                 // one triangular factor in level-major stora
     int *row_of = nullptr;         // device: original row id of permuted row
     double *dinv = nullptr;        // device: 1/diag in permuted order (upper only)
     int64_t nnz = 0;
-    // index spaces of a solve (ilu.hip trsv_rows): permuted row pr reads rhs[rhs_of[pr]], writes out[out_of[pr]]
+    // index spaces of a solve (trsv.hip trsv_rows): permuted row pr reads rhs[rhs_of[pr]], writes out[out_of[pr]]
     // (nullptr = pr itself); `ci` holds indices into out.  Original space: both = row_of.  Level-major space (lm,
     // hybrid factors): out_of = nullptr; rhs_of = nullptr for L, the U-position -> L-position map (owned) for U.
     int *rhs_of = nullptr, *out_of = nullptr;
@@ -124,7 +124,7 @@ struct cudamat_solver {
     double *lu = nullptr;      // pm_nnz doubles on that matrix's pattern
     int *diag_pos = nullptr;   // position of the diagonal in each row
     cm::TriFactor L, U;
-    void *ilu_plans = nullptr;  // launch plans owned by ilu.hip
+    void *ilu_plans = nullptr;  // launch plans (ilu.h) owned by ilu.hip
     // the loop in level-major spaces (hybrid factors, one GPU): the matrix with rows in L's order and columns in U's
     // positions as a blocked copy, b in L's space, x in U's
     cm::PbPlan pb_perm{};
