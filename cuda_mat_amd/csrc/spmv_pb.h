@@ -61,6 +61,7 @@ struct PbBuild {
     PbCut cut{};
     size_t cap = 0;            // entries of the value / column / row / product arrays (with the blocks' alignment pads)
     double t0 = 0.0;
+    bool verbose = false;      // Config::verbose at the count pass: pb_build_end prints the plan and its segment lengths
 };
 int pb_build_begin(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
                    const PbCols *cols, PbBuild *b);

@@ -389,8 +389,7 @@ int pb_build_count(hipStream_t st, const Config &cfg, const int *rp, const int *
 {
     PbPlan &p = b->p;
     const int n = p.n;
-    const int64_t n_cols = p.n_cols, nnz = p.nnz;
-    const size_t nbins = (size_t)p.NCB * p.NSUB;
+    const int64_t nnz = p.nnz;
     int *bins = b->bins;
     constexpr int align = kPbAlign;
     int rc = CUDAMAT_OK;
@@ -412,23 +411,7 @@ int pb_build_count(hipStream_t st, const Config &cfg, const int *rp, const int *
         if ((int64_t)counted < nnz || (int64_t)counted > nnz + (int64_t)(align - 1) * p.NCB) {
             rc = CUDAMAT_ERR_ARG; set_error("pb_build: counted %d entries, expected %lld", counted, (long long)nnz); break;
         }
-        if (cfg.verbose) {
-            // the plan and how evenly the entries fall into its (sub-block, column block) segments: phase 2 is bound by fabric
-            // requests per segment, so a layout whose segments are much shorter or longer than the 48-entry target pays for it
-            std::vector<int> hl(nbins);
-            if (hipMemcpy(hl.data(), p.slen, sizeof(int) * nbins, hipMemcpyDeviceToHost) == hipSuccess) {
-                long long hist[7] = {0, 0, 0, 0, 0, 0, 0}, in_long = 0;
-                for (int v : hl) {
-                    hist[v == 0 ? 0 : v <= 8 ? 1 : v <= 24 ? 2 : v <= 48 ? 3 : v <= 64 ? 4 : v <= 128 ? 5 : 6]++;
-                    if (v > 64) in_long += v;
-                }
-                fprintf(stderr, "[cudamat] pb plan: %d x %lld, nnz %lld, NCB %d (CB %d), NSUB %d (NW %d, SR %d), LPS %d, depth %d; segments: "
-                                "empty %lld, 1-8 %lld, 9-24 %lld, 25-48 %lld, 49-64 %lld, 65-128 %lld, >128 %lld; %.1f %% of the entries in "
-                                "segments longer than a wave\n",
-                        n, (long long)n_cols, (long long)nnz, p.NCB, p.CB, p.NSUB, p.NW, p.SR, p.LPS, p.depth, hist[0], hist[1], hist[2], hist[3],
-                        hist[4], hist[5], hist[6], 100.0 * (double)in_long / (double)(nnz > 0 ? nnz : 1));
-            }
-        }
+        b->verbose = cfg.verbose != 0;
     } while (0);
     if (rc) pb_build_abort(b);
     return rc;
@@ -464,9 +447,31 @@ int pb_build_fill(hipStream_t st, PbBuild *b, const int *rp, const int *ci, cons
     return CUDAMAT_OK;
 }
 
+// CUDAMAT_VERBOSE: the plan and how evenly the entries fall into its (sub-block, column block) segments: phase 2 is bound by
+// fabric requests per segment, so a layout whose segments are much shorter or longer than the 48-entry target pays for it.
+// (Printed when the copy is complete, not from the count pass: the 38 MB read-back at C4 would sit in the way of an upload
+// that the drop-in call runs beside the build, and of the stage stamps that measure it.)
+static void pb_print_plan(const PbPlan &p)
+{
+    const size_t nbins = (size_t)p.NCB * p.NSUB;
+    std::vector<int> hl(nbins);
+    if (hipMemcpy(hl.data(), p.slen, sizeof(int) * nbins, hipMemcpyDeviceToHost) != hipSuccess) return;
+    long long hist[7] = {0, 0, 0, 0, 0, 0, 0}, in_long = 0;
+    for (int v : hl) {
+        hist[v == 0 ? 0 : v <= 8 ? 1 : v <= 24 ? 2 : v <= 48 ? 3 : v <= 64 ? 4 : v <= 128 ? 5 : 6]++;
+        if (v > 64) in_long += v;
+    }
+    fprintf(stderr, "[cudamat] pb plan: %d x %lld, nnz %lld, NCB %d (CB %d), NSUB %d (NW %d, SR %d), LPS %d, depth %d; segments: "
+                    "empty %lld, 1-8 %lld, 9-24 %lld, 25-48 %lld, 49-64 %lld, 65-128 %lld, >128 %lld; %.1f %% of the entries in "
+                    "segments longer than a wave\n",
+            p.n, (long long)p.n_cols, (long long)p.nnz, p.NCB, p.CB, p.NSUB, p.NW, p.SR, p.LPS, p.depth, hist[0], hist[1], hist[2], hist[3],
+            hist[4], hist[5], hist[6], 100.0 * (double)in_long / (double)(p.nnz > 0 ? p.nnz : 1));
+}
+
 int pb_build_end(hipStream_t st, PbBuild *b, PbPlan *out)
 {
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("pb fill failed"); pb_build_abort(b); return CUDAMAT_ERR_HIP; }
+    if (b->verbose) pb_print_plan(b->p);
     hipFree(b->bins);
     b->bins = nullptr;
     b->p.build_seconds = now_s() - b->t0;

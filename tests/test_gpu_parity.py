@@ -1467,6 +1467,21 @@ def test_drop_in_call_reuses_the_plan_of_the_previous_call(cm, oracle, monkeypat
     okb, xb, dtb, stb = cm.bicgstab(S.n, S.nnz, S.val, S.rowptr + 1, S.colidx + 1, bs, 200, 1e-8)
     assert okb and stb.spmv_mode == 1
     np.testing.assert_array_equal(xb, xs_)
+    # The count pass of the blocked copy walks the column indices piece by piece WHILE they arrive, before they have been
+    # validated (only the row pointers have): a column outside the matrix or row pointers that decrease must still end in
+    # the validation's error, never in a stray access.
+    bad_c = S.colidx.copy()
+    bad_c[20_000_000] = S.n + 7
+    bad_c[30_000_001] = -3
+    with pytest.raises(cm.CudamatError, match="column index"):
+        cm.bicgstab(S.n, S.nnz, S.val, S.rowptr, bad_c, bs, 200, 1e-8)
+    bad_r = S.rowptr.copy()
+    bad_r[1000] = bad_r[1001] + 5
+    with pytest.raises(cm.CudamatError, match="row pointers"):
+        cm.bicgstab(S.n, S.nnz, S.val, bad_r, S.colidx, bs, 200, 1e-8)
+    oka, xa, dta, sta = cm.bicgstab(S.n, S.nnz, S.val, S.rowptr, S.colidx, bs, 200, 1e-8)       # and the library is fine afterwards
+    assert oka and sta.spmv_mode == 1
+    np.testing.assert_array_equal(xa, xs_)
     cm.lib().cudamat_plan_cache_clear()
 
 
