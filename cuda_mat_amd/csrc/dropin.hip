@@ -12,7 +12,7 @@
 //               then the fill pass piece by piece behind the value milestones (or in one pass after the value dictionary
 //               is known, when the first values suggest the matrix has one).  No hipMalloc / hipFree while bytes travel.
 // so that when the last byte lands only the tail of the fill, the loop and the download remain: at C4 a first call takes
-// 0.171 s (upload 0.115 s at 53 GB/s, 17 ms of set-up not hidden, loop 0.031 s) where round 3 took 0.237 s.
+// 0.154-0.161 s (upload 0.113-0.120 s at 51-54 GB/s, 1.4-4 ms of set-up not hidden, loop 0.030 s) where round 3 took 0.237 s.
 #include <atomic>
 #include <chrono>
 #include <mutex>
