@@ -57,7 +57,6 @@ const Option kOptions[] = {
     OPT_FLAG("TRSV_PERM", trsv_perm, "0: permute around every M^-1 application instead of running the loop in the level-major spaces"),
     OPT_FLAG("LEVELS_SWEEP", levels_sweep, "1: level analysis by relaxation sweeps"),
     OPT_FLAG("ILU0_SIMPLE", ilu0_simple, "1: numeric ILU(0) without LDS staging / prefetch"),
-    OPT_INT("HOST_THREADS", host_threads, 1, 256, "threads of the host-side level sort of the ILU(0) analysis"),
     OPT_FLAG("FORCE_SHARDED", force_sharded, "1: keep the collective path at world size 1"),
     OPT_FLAG("OVERLAP", overlap, "0: plain all-gather instead of pieces behind phase 1 of the blocked SpMV"),
     OPT_INT("OVERLAP_CHUNKS", overlap_chunks, 1, 16, "pieces per slice of an overlapped gather"),

@@ -44,7 +44,6 @@ struct Config {
     int trsv_perm = 1;            // TRSV_PERM          0: permute around every M^-1 instead of running the loop in the level-major spaces
     int levels_sweep = 0;         // LEVELS_SWEEP       1: level analysis by relaxation sweeps
     int ilu0_simple = 0;          // ILU0_SIMPLE        1: numeric ILU(0) without LDS staging / prefetch
-    int host_threads = 0;         // HOST_THREADS       threads of the host-side level sort (0: up to 16)
     // ---- row sharding
     int force_sharded = 0;        // FORCE_SHARDED      1: keep the collective path at world size 1
     int overlap = 1;              // OVERLAP            0: plain all-gather instead of pieces behind phase 1

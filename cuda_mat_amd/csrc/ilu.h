@@ -35,7 +35,7 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
     std::vector<int> grp_level;            // K+1 level boundaries of the groups
     std::vector<PbPlan> far;               // far[g]: rows of group g x columns of groups < g
     double *far_buf = nullptr;             // n doubles in level-major row order: far_g . out
-    std::vector<int> lev_host;             // level of every original row (kept until the split)
+    int *lev_dev = nullptr;                // device: level of every original row (kept until the split)
     bool want_hybrid = false;              // this factor alone would take the hybrid solve (the two factors decide together)
     bool syncfree = false;                 // one dependency-driven launch per group instead of one launch per level
     int spin_limit = kSpinLimit;

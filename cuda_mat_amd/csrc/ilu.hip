@@ -23,7 +23,6 @@
 // Algorithmic bytes per preconditioner application: 12 nnz + 8 (n+1) + 32 n.
 #include <algorithm>
 #include <chrono>
-#include <thread>
 #include <vector>
 
 #include "ilu.h"
@@ -347,6 +346,12 @@ static void free_factor(TriFactor &F)
     F = TriFactor();
 }
 
+static void free_levels(TriHost &H)
+{
+    if (H.lev_dev) hipFree(H.lev_dev);
+    H.lev_dev = nullptr;
+}
+
 int ilu0_release(cudamat_solver *s)
 {
     free_factor(s->L);
@@ -379,6 +384,7 @@ int ilu0_release(cudamat_solver *s)
             for (PbPlan &fp : h->far) pb_free(&fp);
             if (h->far_buf) hipFree(h->far_buf);
             if (h->tickets) hipFree(h->tickets);
+            free_levels(*h);
         }
         if (pl->err_host) hipHostFree(pl->err_host);
         if (pl->posU) hipFree(pl->posU);
@@ -388,221 +394,6 @@ int ilu0_release(cudamat_solver *s)
         s->ilu_plans = nullptr;
     }
     return CUDAMAT_OK;
-}
-
-// host-side loops over 1e7 rows (level sort, row pointers): a few threads over contiguous ranges
-static int host_threads(const Config &cfg, long long n)
-{
-    if (n < (1 << 20)) return 1;
-    unsigned hw = std::thread::hardware_concurrency();
-    if (cfg.host_threads) hw = (unsigned)cfg.host_threads;
-    return hw < 1 ? 1 : hw > 16 ? 16 : (int)hw;
-}
-
-template <class Fn>
-static void parallel_ranges(int n, int T, Fn fn)
-{
-    if (T <= 1) { fn(0, 0, n); return; }
-    std::vector<std::thread> th;
-    th.reserve((size_t)T - 1);
-    const long long per = ((long long)n + T - 1) / T;
-    auto range = [&](int t, int &lo, int &hi) {
-        const long long a = per * t, b = per * (t + 1);
-        lo = (int)(a < n ? a : n);
-        hi = (int)(b < n ? b : n);
-    };
-    for (int t = 1; t < T; t++) {
-        int lo, hi;
-        range(t, lo, hi);
-        try {
-            th.emplace_back([=] { fn(t, lo, hi); });
-        } catch (...) {                    // no thread to be had: this range runs here
-            fn(t, lo, hi);
-        }
-    }
-    int lo, hi;
-    range(0, lo, hi);
-    fn(0, lo, hi);
-    for (std::thread &q : th) q.join();
-}
-
-// levels -> level-major permutation (stable: rows of a level stay in increasing order)
-static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags, TriFactor &F, TriHost &H,
-                        std::vector<int> &h_rp, std::vector<int> &h_diag, int *err_host, int *err_dev)
-{
-    hipStream_t st = s->ctx->stream;
-    const Config &cfg = s->ctx->cfg;
-    const int n = s->n;
-    double t_stamp = now_s();
-    const long long threads = (long long)n * 8;
-    const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
-    // one dependency-driven pass; the relaxation sweeps below remain as the fallback (option LEVELS_SWEEP = 1
-    // or a timed-out wait)
-    bool have_levels = false;
-    if (n > 0 && err_host && !s->ctx->cfg.levels_sweep) {
-        CM_HIP(hipMemsetAsync(d_lev, 0xFF, sizeof(int) * (size_t)n, st));
-        // lanes per row from the mean number of dependencies: with 2 per row (stencils) one lane per row keeps 8x
-        // more rows in flight, and rows in flight are what a chain-like dependency graph needs (unlike the
-        // triangular solves, fewer resident workgroups only slow this pass down: Poisson 0.9 / 2.2 / 4.1 s at 8 / 2 / 1)
-        const double mean_dep = (double)(s->pm_nnz - n) / 2.0 / n;
-        const int L = mean_dep <= 3.0 ? 1 : mean_dep <= 6.0 ? 2 : 8;
-        const long long nsub = ((long long)n * L + kBlock - 1) / kBlock;
-        int steps = 4;                                           // a ticket = 4 x 256 threads' worth of rows
-        while (steps > 1 && nsub / steps < 1024) steps >>= 1;
-        const long long ntick = (nsub + steps - 1) / steps;
-        const unsigned gridL = (unsigned)(ntick < 2048 ? ntick : 2048);       // 8 resident workgroups per CU
-        unsigned *d_ticket = (unsigned *)(d_flags + 2);
-        CM_HIP(hipMemsetAsync(d_ticket, 0, sizeof(unsigned), st));
-        if (L == 1)
-            hipLaunchKernelGGL(k_levels_dep<1>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev, d_ticket, steps);
-        else if (L == 2)
-            hipLaunchKernelGGL(k_levels_dep<2>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev, d_ticket, steps);
-        else
-            hipLaunchKernelGGL(k_levels_dep<8>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev, d_ticket, steps);
-        CM_HIP(hipGetLastError());
-        CM_HIP(hipStreamSynchronize(st));
-        have_levels = *err_host == 0;
-        *err_host = 0;
-    }
-    if (!have_levels) CM_HIP(hipMemsetAsync(d_lev, 0, sizeof(int) * (size_t)(n ? n : 1), st));
-    int sweeps = 0;
-    while (n > 0 && !have_levels) {
-        CM_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_level_sweep, dim3(grid ? grid : 1), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci,
-                           s->diag_pos, upper ? 1 : 0, d_lev, d_flags);
-        CM_HIP(hipGetLastError());
-        int changed = 0;
-        CM_HIP(hipMemcpyAsync(&changed, d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
-        CM_HIP(hipStreamSynchronize(st));
-        sweeps++;
-        if (!changed) break;
-        if (sweeps > n + 1) { set_error("level analysis did not converge"); return CUDAMAT_ERR_HIP; }
-    }
-    CM_STAMP(upper ? "U levels (device)" : "L levels (device)");
-    std::vector<int> lev((size_t)n);
-    if (n) CM_HIP(hipMemcpy(lev.data(), d_lev, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
-    // stable counting sort of the rows by level + the factor's row pointers.  Big systems: T host threads over
-    // contiguous row ranges (per-thread level counts give every thread its own stable write cursors; same result as
-    // the serial loops) -- at 1e7 rows 44 ms per factor serial
-    const int T = host_threads(s->ctx->cfg, n);
-    std::vector<int> tmax((size_t)T, 0);
-    parallel_ranges(n, T, [&](int t, int lo, int hi) {
-        int m = 0;
-        for (int i = lo; i < hi; i++) m = std::max(m, lev[(size_t)i] + 1);
-        tmax[(size_t)t] = m;
-    });
-    int nlev = 0;
-    for (int t = 0; t < T; t++) nlev = std::max(nlev, tmax[(size_t)t]);
-    F.nlevels = nlev;
-    F.level_ptr.assign((size_t)nlev + 1, 0);
-    std::vector<int> row_of((size_t)n);
-    const int Tc = (long long)nlev * T <= 4LL * n + 4096 ? T : 1;      // (chain-like graphs: as many levels as rows)
-    {
-        std::vector<int> cnt((size_t)Tc * (size_t)nlev, 0);             // cnt[t][l]: rows of level l in thread t's range
-        parallel_ranges(n, Tc, [&](int t, int lo, int hi) {
-            int *c = cnt.data() + (size_t)t * (size_t)nlev;
-            for (int i = lo; i < hi; i++) c[lev[(size_t)i]]++;
-        });
-        int run = 0;
-        for (int l = 0; l < nlev; l++) {                                // level-major, thread-minor: exclusive offsets
-            F.level_ptr[(size_t)l] = run;
-            for (int t = 0; t < Tc; t++) {
-                const int c = cnt[(size_t)t * (size_t)nlev + (size_t)l];
-                cnt[(size_t)t * (size_t)nlev + (size_t)l] = run;
-                run += c;
-            }
-        }
-        F.level_ptr[(size_t)nlev] = run;
-        parallel_ranges(n, Tc, [&](int t, int lo, int hi) {
-            int *c = cnt.data() + (size_t)t * (size_t)nlev;
-            for (int i = lo; i < hi; i++) row_of[(size_t)c[lev[(size_t)i]]++] = i;
-        });
-    }
-    // factor row pointers in permuted order: lengths, per-range sums, offsets
-    std::vector<int> frp((size_t)n + 1, 0);
-    std::vector<long long> tsum((size_t)T + 1, 0);
-    parallel_ranges(n, T, [&](int t, int lo, int hi) {
-        long long sum = 0;
-        for (int pr = lo; pr < hi; pr++) {
-            const int r = row_of[(size_t)pr];
-            const int cnt = upper ? h_rp[(size_t)r + 1] - h_diag[(size_t)r] - 1 : h_diag[(size_t)r] - h_rp[(size_t)r];
-            frp[(size_t)pr + 1] = cnt;
-            sum += cnt;
-        }
-        tsum[(size_t)t + 1] = sum;
-    });
-    for (int t = 0; t < T; t++) tsum[(size_t)t + 1] += tsum[(size_t)t];
-    parallel_ranges(n, T, [&](int t, int lo, int hi) {
-        int run = (int)tsum[(size_t)t];
-        for (int pr = lo; pr < hi; pr++) {
-            run += frp[(size_t)pr + 1];
-            frp[(size_t)pr + 1] = run;
-        }
-    });
-    F.nnz = n ? frp[(size_t)n] : 0;
-    CM_STAMP("level sort (host)");
-    CM_TRY(dalloc(&F.rp, (size_t)n + 1));
-    CM_TRY(dalloc(&F.ci, (size_t)F.nnz));
-    CM_TRY(dalloc(&F.val, (size_t)F.nnz));
-    CM_TRY(dalloc(&F.row_of, (size_t)n));
-    if (upper) CM_TRY(dalloc(&F.dinv, (size_t)n));
-    CM_HIP(hipMemcpy(F.rp, frp.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
-    if (n) CM_HIP(hipMemcpy(F.row_of, row_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-    F.rhs_of = F.out_of = F.row_of;            // original index space (until both factors go level-major, ilu0_setup)
-    F.lm = false;
-    CM_TRY(dalloc(&H.level_ptr_dev, (size_t)nlev + 1));
-    CM_HIP(hipMemcpy(H.level_ptr_dev, F.level_ptr.data(), sizeof(int) * ((size_t)nlev + 1), hipMemcpyHostToDevice));
-    CM_STAMP("factor arrays alloc + upload");
-    H.lanes = pick_lanes(n ? (double)F.nnz / n : 1.0);
-    if (cfg.trsv_lanes) H.lanes = cfg.trsv_lanes;
-    // the hybrid solve is for big factors with many wide levels whose columns are scattered (the gather-bound case);
-    // the two factors decide together (ilu0_setup): they share the level-major index spaces
-    H.lev_host.swap(lev);
-    H.want_hybrid = nlev >= 4 && (cfg.trsv_hybrid >= 0 ? cfg.trsv_hybrid == 1 : (n >= 500000 && F.nnz >= (8 << 20) && nlev >= 16 && n / nlev >= 16384));
-    return CUDAMAT_OK;
-}
-
-// groups of consecutive levels (hybrid: ~17 levels per group leaves ~15 % of the entries near; measured at C5, round 3:
-// 5 / 8 / 12 / 16 / 24 groups -> 4.85 / 4.79 / 5.03 / 5.54 / 6.57 ms per L^-1 U^-1 -- the near launches shrink with more
-// groups, the far SpMVs lose more on their shorter segments) and the launch plan
-static void plan_groups(const Config &cfg, const TriFactor &F, TriHost &H, bool hybrid)
-{
-    const int nlev = F.nlevels;
-    int K = 1;
-    if (hybrid) {
-        K = nlev / 17;
-        if (K < 2) K = 2;
-        if (K > 16) K = 16;
-        if (cfg.trsv_groups >= 2 && cfg.trsv_groups <= nlev) K = cfg.trsv_groups;
-    }
-    H.hybrid = K > 1;
-    H.grp_level.assign((size_t)K + 1, 0);
-    for (int g = 0; g <= K; g++) H.grp_level[(size_t)g] = (int)((long long)nlev * g / K);
-    if (cfg.verbose && K > 1) {
-        fprintf(stderr, "cudamat: trsv groups (levels:rows)");
-        for (int g = 0; g < K; g++)
-            fprintf(stderr, " %d:%d", H.grp_level[(size_t)g + 1] - H.grp_level[(size_t)g],
-                    F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]] - F.level_ptr[(size_t)H.grp_level[(size_t)g]]);
-        fprintf(stderr, "\n");
-    }
-    // launch plan: a big level is its own segment; consecutive small levels are merged (inside a group)
-    H.seg_begin.clear();
-    H.seg_end.clear();
-    H.seg_group.clear();
-    for (int g = 0; g < K; g++) {
-        int l = H.grp_level[(size_t)g];
-        const int lend = H.grp_level[(size_t)g + 1];
-        while (l < lend) {
-            const int rows = F.level_ptr[(size_t)l + 1] - F.level_ptr[(size_t)l];
-            int e = l + 1;
-            if (rows <= kSmallLevel)
-                while (e < lend && F.level_ptr[(size_t)e + 1] - F.level_ptr[(size_t)e] <= kSmallLevel) e++;
-            H.seg_begin.push_back(l);
-            H.seg_end.push_back(e);
-            H.seg_group.push_back(g);
-            l = e;
-        }
-    }
 }
 
 // ---- exclusive prefix sums of n ints on the device (out has n + 1 entries, out[n] = total): tiles of 4096 elements
@@ -686,7 +477,353 @@ static int device_exclusive_scan(hipStream_t st, int n, const int *in, int *out)
     return CUDAMAT_OK;
 }
 
+// ---- stable sort of the rows by level, on the device (round 4; the host's counting sort over 1e7 levels took 44 ms per
+// factor on 16 threads, plus the read-back of the levels and of the pattern's row pointers and the upload of the result).
+// LSD radix passes of 8 bits (one pass up to 256 levels: C5 has 137; two up to 65 536), each a stable counting sort:
+// a wavefront takes kLsChunk consecutive positions -- histogram of its digits (k_lsort_hist), exclusive offsets in
+// (digit, chunk) order (k_lsort_scan_digit / k_lsort_scan_tot), then it walks its positions IN ORDER and places every
+// element behind the earlier ones of its digit (k_lsort_scatter: the lanes of one step that share a digit are ranked by
+// lane number) -- so rows of one level stay in increasing order, as the level kernels and the bit-identity of the
+// triangular-solve forms require.
+constexpr int kLsChunk = 2048;
+constexpr int kLsWaves = kBlock / 64;
+
+__global__ __launch_bounds__(kBlock) void k_lsort_hist(int n, const int *key, int shift, int nchunks, int *cnt)
+{
+    __shared__ int h[kLsWaves][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * kLsWaves + wave;
+    for (int d = lane; d < 256; d += 64) h[wave][d] = 0;
+    __syncthreads();
+    if (chunk < nchunks) {
+        const long long i0 = (long long)chunk * kLsChunk;
+        for (int c = 0; c < kLsChunk; c += 64) {
+            const long long i = i0 + c + lane;
+            if (i < n) atomicAdd(&h[wave][(key[i] >> shift) & 255], 1);
+        }
+    }
+    __syncthreads();
+    if (chunk < nchunks)
+        for (int d = lane; d < 256; d += 64) cnt[(size_t)d * nchunks + chunk] = h[wave][d];
+}
+
+// one workgroup per digit: cnt[d][.] -> exclusive offsets inside the digit, tot[d] = elements with that digit
+__global__ __launch_bounds__(kBlock) void k_lsort_scan_digit(int nchunks, int *cnt, int *tot)
+{
+    __shared__ int lds_waves[kBlock / 64];
+    int *c = cnt + (size_t)blockIdx.x * nchunks;
+    int run = 0;
+    for (int c0 = 0; c0 < nchunks; c0 += kBlock) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < nchunks ? c[i] : 0;
+        int total;
+        const int ex = wg_exclusive_scan(v, lds_waves, &total);
+        if (i < nchunks) c[i] = run + ex;
+        run += total;
+    }
+    if (threadIdx.x == 0) tot[blockIdx.x] = run;
+}
+
+__global__ __launch_bounds__(kBlock) void k_lsort_scan_tot(const int *tot, int *base)
+{
+    static_assert(kBlock == 256, "one digit per thread");
+    __shared__ int lds_waves[kBlock / 64];
+    int total;
+    base[threadIdx.x] = wg_exclusive_scan(tot[threadIdx.x], lds_waves, &total);
+}
+
+__global__ __launch_bounds__(kBlock) void k_lsort_scatter(int n, const int *key_in, const int *row_in, int shift, int nchunks,
+                                                          const int *cnt, const int *base, int *key_out, int *row_out)
+{
+    __shared__ int cur[kLsWaves][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * kLsWaves + wave;
+    if (chunk < nchunks)
+        for (int d = lane; d < 256; d += 64) cur[wave][d] = base[d] + cnt[(size_t)d * nchunks + chunk];
+    __syncthreads();
+    if (chunk >= nchunks) return;
+    const long long i0 = (long long)chunk * kLsChunk;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int c = 0; c < kLsChunk; c += 64) {
+        const long long i = i0 + c + lane;
+        const bool active = i < n;
+        const int k = active ? key_in[i] : 0;
+        const int d = (k >> shift) & 255;
+        const int r = active ? (row_in ? row_in[i] : (int)i) : 0;
+        unsigned long long todo = __ballot(active);              // (wave-uniform: the loop below is, too)
+        int dest = 0;
+        while (todo) {
+            const int leader = __ffsll(todo) - 1;
+            const int dl = __shfl(d, leader, 64);
+            const bool mine = active && d == dl;
+            const unsigned long long m = __ballot(mine);
+            // (one wavefront's LDS accesses execute in program order: every lane of the digit reads the cursor, then the
+            // leader moves it on)
+            if (mine) dest = cur[wave][dl] + __popcll(m & below);
+            if (lane == leader) cur[wave][dl] += __popcll(m);
+            todo &= ~m;
+        }
+        if (active) {
+            key_out[dest] = k;
+            row_out[dest] = r;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_max_int(int n, const int *v, int *out)
+{
+    __shared__ int red[kBlock / 64];
+    int m = 0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) m = max(m, v[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) m = max(m, red[w]);
+        atomicMax(out, m);
+    }
+}
+
+// longest row of a CSR pattern (same reduction over rp[i + 1] - rp[i])
+__global__ __launch_bounds__(kBlock) void k_max_row_len(int n, const int *rp, int *out)
+{
+    __shared__ int red[kBlock / 64];
+    int m = 0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) m = max(m, rp[i + 1] - rp[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) m = max(m, red[w]);
+        atomicMax(out, m);
+    }
+}
+
+// level_ptr[l] = first position of level l in the sorted keys, level_ptr[last level + 1] = n
+__global__ __launch_bounds__(kBlock) void k_level_ptr(int n, const int *skey, int *level_ptr)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int k = skey[i], kp = i ? skey[i - 1] : -1;
+    for (int l = kp + 1; l <= k; l++) level_ptr[l] = (int)i;
+    if (i == n - 1) level_ptr[k + 1] = n;
+}
+
+// entries of the factor's row pr = the strict lower / strict upper part of pattern row row_of[pr]
+__global__ __launch_bounds__(kBlock) void k_factor_len(int n, const int *row_of, const int *rp, const int *diag, int upper, int *len)
+{
+    const long long pr = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (pr >= n) return;
+    const int r = row_of[pr];
+    len[pr] = upper ? rp[r + 1] - diag[r] - 1 : diag[r] - rp[r];
+}
+
+// rows sorted by (level, row): *row_of_out (n ints) and *level_ptr_dev_out (levels + 1 ints) are the caller's afterwards;
+// level_ptr: the same table on the host.  n > 0.
+static int sort_rows_by_level(hipStream_t st, int n, const int *d_lev, int **row_of_out, std::vector<int> &level_ptr, int **level_ptr_dev_out)
+{
+    *row_of_out = nullptr;
+    *level_ptr_dev_out = nullptr;
+    int *kb[2] = {nullptr, nullptr}, *rb[2] = {nullptr, nullptr}, *cnt = nullptr, *tot = nullptr, *maxv = nullptr, *lp = nullptr;
+    int rc = CUDAMAT_OK;
+    do {
+        if ((rc = dalloc(&maxv, 1))) break;
+        if (hipMemsetAsync(maxv, 0, sizeof(int), st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        const unsigned gmax = (unsigned)std::min<long long>(((long long)n + kBlock - 1) / kBlock, 4096);
+        hipLaunchKernelGGL(k_max_int, dim3(gmax), dim3(kBlock), 0, st, n, d_lev, maxv);
+        int maxlev = 0;
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&maxlev, maxv, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("level maximum failed"); break; }
+        const int nlev = maxlev + 1;
+        const int passes = nlev <= (1 << 8) ? 1 : nlev <= (1 << 16) ? 2 : nlev <= (1 << 24) ? 3 : 4;
+        const int nchunks = (int)(((long long)n + kLsChunk - 1) / kLsChunk);
+        const unsigned grid = (unsigned)((nchunks + kLsWaves - 1) / kLsWaves);
+        if ((rc = dalloc(&cnt, (size_t)256 * nchunks))) break;
+        if ((rc = dalloc(&tot, 512))) break;                    // totals, then bases
+        for (int q = 0; q < (passes > 1 ? 2 : 1) && !rc; q++) {
+            rc = dalloc(&kb[q], (size_t)n);
+            if (!rc) rc = dalloc(&rb[q], (size_t)n);
+        }
+        if (rc) break;
+        const int *key_in = d_lev, *row_in = nullptr;
+        int last = 0;
+        for (int p = 0; p < passes; p++) {
+            const int o = p & 1;
+            hipLaunchKernelGGL(k_lsort_hist, dim3(grid), dim3(kBlock), 0, st, n, key_in, 8 * p, nchunks, cnt);
+            hipLaunchKernelGGL(k_lsort_scan_digit, dim3(256), dim3(kBlock), 0, st, nchunks, cnt, tot);
+            hipLaunchKernelGGL(k_lsort_scan_tot, dim3(1), dim3(kBlock), 0, st, tot, tot + 256);
+            hipLaunchKernelGGL(k_lsort_scatter, dim3(grid), dim3(kBlock), 0, st, n, key_in, row_in, 8 * p, nchunks, cnt, tot + 256, kb[o], rb[o]);
+            key_in = kb[o];
+            row_in = rb[o];
+            last = o;
+        }
+        if (hipGetLastError() != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("level sort launch failed"); break; }
+        if ((rc = dalloc(&lp, (size_t)nlev + 1))) break;
+        hipLaunchKernelGGL(k_level_ptr, dim3((unsigned)(((long long)n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, kb[last], lp);
+        level_ptr.assign((size_t)nlev + 1, 0);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(level_ptr.data(), lp, sizeof(int) * ((size_t)nlev + 1), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("level sort failed"); break; }
+        if (level_ptr[0] != 0 || level_ptr[(size_t)nlev] != n) { rc = CUDAMAT_ERR_HIP; set_error("level sort: inconsistent level table"); break; }
+        *row_of_out = rb[last];
+        rb[last] = nullptr;
+        *level_ptr_dev_out = lp;
+        lp = nullptr;
+    } while (0);
+    void *tmp[] = {kb[0], kb[1], rb[0], rb[1], cnt, tot, maxv, lp};
+    for (void *q : tmp)
+        if (q) hipFree(q);
+    return rc;
+}
+
+// levels -> level-major permutation (stable: rows of a level stay in increasing order)
+static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags, TriFactor &F, TriHost &H, int *err_host, int *err_dev)
+{
+    hipStream_t st = s->ctx->stream;
+    const Config &cfg = s->ctx->cfg;
+    const int n = s->n;
+    double t_stamp = now_s();
+    const long long threads = (long long)n * 8;
+    const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
+    // one dependency-driven pass; the relaxation sweeps below remain as the fallback (option LEVELS_SWEEP = 1
+    // or a timed-out wait)
+    bool have_levels = false;
+    if (n > 0 && err_host && !s->ctx->cfg.levels_sweep) {
+        CM_HIP(hipMemsetAsync(d_lev, 0xFF, sizeof(int) * (size_t)n, st));
+        // lanes per row from the mean number of dependencies: with 2 per row (stencils) one lane per row keeps 8x
+        // more rows in flight, and rows in flight are what a chain-like dependency graph needs (unlike the
+        // triangular solves, fewer resident workgroups only slow this pass down: Poisson 0.9 / 2.2 / 4.1 s at 8 / 2 / 1)
+        const double mean_dep = (double)(s->pm_nnz - n) / 2.0 / n;
+        const int L = mean_dep <= 3.0 ? 1 : mean_dep <= 6.0 ? 2 : 8;
+        const long long nsub = ((long long)n * L + kBlock - 1) / kBlock;
+        int steps = 4;                                           // a ticket = 4 x 256 threads' worth of rows
+        while (steps > 1 && nsub / steps < 1024) steps >>= 1;
+        const long long ntick = (nsub + steps - 1) / steps;
+        const unsigned gridL = (unsigned)(ntick < 2048 ? ntick : 2048);       // 8 resident workgroups per CU
+        unsigned *d_ticket = (unsigned *)(d_flags + 2);
+        CM_HIP(hipMemsetAsync(d_ticket, 0, sizeof(unsigned), st));
+        if (L == 1)
+            hipLaunchKernelGGL(k_levels_dep<1>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev, d_ticket, steps);
+        else if (L == 2)
+            hipLaunchKernelGGL(k_levels_dep<2>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev, d_ticket, steps);
+        else
+            hipLaunchKernelGGL(k_levels_dep<8>, dim3(gridL), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci, s->diag_pos, upper ? 1 : 0, d_lev, err_dev, d_ticket, steps);
+        CM_HIP(hipGetLastError());
+        CM_HIP(hipStreamSynchronize(st));
+        have_levels = *err_host == 0;
+        *err_host = 0;
+    }
+    if (!have_levels) CM_HIP(hipMemsetAsync(d_lev, 0, sizeof(int) * (size_t)(n ? n : 1), st));
+    int sweeps = 0;
+    while (n > 0 && !have_levels) {
+        CM_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_level_sweep, dim3(grid ? grid : 1), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci,
+                           s->diag_pos, upper ? 1 : 0, d_lev, d_flags);
+        CM_HIP(hipGetLastError());
+        int changed = 0;
+        CM_HIP(hipMemcpyAsync(&changed, d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
+        CM_HIP(hipStreamSynchronize(st));
+        sweeps++;
+        if (!changed) break;
+        if (sweeps > n + 1) { set_error("level analysis did not converge"); return CUDAMAT_ERR_HIP; }
+    }
+    CM_STAMP(upper ? "U levels (device)" : "L levels (device)");
+    // the level of every original row stays on the device until the far / near split (split_factor); d_lev is the
+    // caller's scratch and serves the other factor next
+    CM_TRY(dalloc(&H.lev_dev, (size_t)n));
+    if (n) CM_HIP(hipMemcpyAsync(H.lev_dev, d_lev, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    // stable sort of the rows by level, the level table, the factor's row pointers in that order: all on the device
+    if (n > 0) {
+        CM_TRY(sort_rows_by_level(st, n, H.lev_dev, &F.row_of, F.level_ptr, &H.level_ptr_dev));
+        F.nlevels = (int)F.level_ptr.size() - 1;
+    } else {
+        F.nlevels = 0;
+        F.level_ptr.assign(1, 0);
+        CM_TRY(dalloc(&F.row_of, 0));
+        CM_TRY(dalloc(&H.level_ptr_dev, 1));
+        CM_HIP(hipMemsetAsync(H.level_ptr_dev, 0, sizeof(int), st));
+    }
+    const int nlev = F.nlevels;
+    CM_STAMP("level sort (device)");
+    CM_TRY(dalloc(&F.rp, (size_t)n + 1));
+    {
+        int *d_len = nullptr;
+        CM_TRY(dalloc(&d_len, (size_t)n));
+        if (n) hipLaunchKernelGGL(k_factor_len, dim3((unsigned)(((long long)n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, F.row_of, s->pm_rp,
+                                  s->diag_pos, upper ? 1 : 0, d_len);
+        int rcs = hipGetLastError() == hipSuccess ? device_exclusive_scan(st, n, d_len, F.rp) : CUDAMAT_ERR_HIP;
+        int total = 0;
+        if (!rcs && hipMemcpy(&total, F.rp + n, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rcs = CUDAMAT_ERR_HIP;
+        hipFree(d_len);
+        if (rcs) { set_error("factor row pointers failed"); return rcs; }
+        F.nnz = total;
+    }
+    CM_TRY(dalloc(&F.ci, (size_t)F.nnz));
+    CM_TRY(dalloc(&F.val, (size_t)F.nnz));
+    if (upper) CM_TRY(dalloc(&F.dinv, (size_t)n));
+    F.rhs_of = F.out_of = F.row_of;            // original index space (until both factors go level-major, ilu0_setup)
+    F.lm = false;
+    CM_STAMP("factor row pointers + arrays");
+    H.lanes = pick_lanes(n ? (double)F.nnz / n : 1.0);
+    if (cfg.trsv_lanes) H.lanes = cfg.trsv_lanes;
+    // the hybrid solve is for big factors with many wide levels whose columns are scattered (the gather-bound case);
+    // the two factors decide together (ilu0_setup): they share the level-major index spaces
+    H.want_hybrid = nlev >= 4 && (cfg.trsv_hybrid >= 0 ? cfg.trsv_hybrid == 1 : (n >= 500000 && F.nnz >= (8 << 20) && nlev >= 16 && n / nlev >= 16384));
+    return CUDAMAT_OK;
+}
+
+// groups of consecutive levels (hybrid: ~17 levels per group leaves ~15 % of the entries near; measured at C5, round 3:
+// 5 / 8 / 12 / 16 / 24 groups -> 4.85 / 4.79 / 5.03 / 5.54 / 6.57 ms per L^-1 U^-1 -- the near launches shrink with more
+// groups, the far SpMVs lose more on their shorter segments) and the launch plan
+static void plan_groups(const Config &cfg, const TriFactor &F, TriHost &H, bool hybrid)
+{
+    const int nlev = F.nlevels;
+    int K = 1;
+    if (hybrid) {
+        K = nlev / 17;
+        if (K < 2) K = 2;
+        if (K > 16) K = 16;
+        if (cfg.trsv_groups >= 2 && cfg.trsv_groups <= nlev) K = cfg.trsv_groups;
+    }
+    H.hybrid = K > 1;
+    H.grp_level.assign((size_t)K + 1, 0);
+    for (int g = 0; g <= K; g++) H.grp_level[(size_t)g] = (int)((long long)nlev * g / K);
+    if (cfg.verbose && K > 1) {
+        fprintf(stderr, "cudamat: trsv groups (levels:rows)");
+        for (int g = 0; g < K; g++)
+            fprintf(stderr, " %d:%d", H.grp_level[(size_t)g + 1] - H.grp_level[(size_t)g],
+                    F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]] - F.level_ptr[(size_t)H.grp_level[(size_t)g]]);
+        fprintf(stderr, "\n");
+    }
+    // launch plan: a big level is its own segment; consecutive small levels are merged (inside a group)
+    H.seg_begin.clear();
+    H.seg_end.clear();
+    H.seg_group.clear();
+    for (int g = 0; g < K; g++) {
+        int l = H.grp_level[(size_t)g];
+        const int lend = H.grp_level[(size_t)g + 1];
+        while (l < lend) {
+            const int rows = F.level_ptr[(size_t)l + 1] - F.level_ptr[(size_t)l];
+            int e = l + 1;
+            if (rows <= kSmallLevel)
+                while (e < lend && F.level_ptr[(size_t)e + 1] - F.level_ptr[(size_t)e] <= kSmallLevel) e++;
+            H.seg_begin.push_back(l);
+            H.seg_end.push_back(e);
+            H.seg_group.push_back(g);
+            l = e;
+        }
+    }
+}
+
 // ---- hybrid split of a level-major factor into near (same group) and far (earlier groups) entries
+__global__ __launch_bounds__(kBlock) void k_group_of_row(int n, const int *lev, const unsigned char *group_of_level, unsigned char *grp)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) grp[i] = group_of_level[lev[i]];
+}
+
 __global__ __launch_bounds__(kBlock) void k_split_count(int n, const int *frp, const int *fci, const int *row_of,
                                                         const unsigned char *grp, int *cnt_near, int *cnt_far)
 {
@@ -782,16 +919,11 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
     const int n = s->n;
     const int K = (int)H.grp_level.size() - 1;
     double t_stamp = now_s();
-    // group of every original row
-    std::vector<unsigned char> hg((size_t)n);
-    {
-        std::vector<unsigned char> g_of_level((size_t)F.nlevels);
-        for (int g = 0; g < K; g++)
-            for (int l = H.grp_level[(size_t)g]; l < H.grp_level[(size_t)g + 1]; l++) g_of_level[(size_t)l] = (unsigned char)g;
-        parallel_ranges(n, host_threads(s->ctx->cfg, n), [&](int, int lo, int hi) {
-            for (int i = lo; i < hi; i++) hg[(size_t)i] = g_of_level[(size_t)H.lev_host[(size_t)i]];
-        });
-    }
+    // group of every level (the group of a row = that of its level: on the device, from the levels kept there)
+    std::vector<unsigned char> g_of_level((size_t)(F.nlevels > 0 ? F.nlevels : 1));
+    for (int g = 0; g < K; g++)
+        for (int l = H.grp_level[(size_t)g]; l < H.grp_level[(size_t)g + 1]; l++) g_of_level[(size_t)l] = (unsigned char)g;
+    unsigned char *d_gtab = nullptr;
     unsigned char *d_grp = nullptr;
     int *d_cn = nullptr, *d_cf = nullptr, *nrp = nullptr, *qrp = nullptr, *nci = nullptr, *qci = nullptr, *qci2 = nullptr;
     double *nval = nullptr, *qval = nullptr, *qval2 = nullptr;
@@ -800,8 +932,11 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
         if ((rc = dalloc(&d_grp, (size_t)n))) break;
         if ((rc = dalloc(&d_cn, (size_t)n))) break;
         if ((rc = dalloc(&d_cf, (size_t)n))) break;
-        if (hipMemcpy(d_grp, hg.data(), (size_t)n, hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        if (!H.lev_dev) { rc = CUDAMAT_ERR_ARG; set_error("factor split: the levels of the rows are gone"); break; }
+        if ((rc = dalloc(&d_gtab, g_of_level.size()))) break;
+        if (hipMemcpy(d_gtab, g_of_level.data(), g_of_level.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
         const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_group_of_row, dim3(grid), dim3(kBlock), 0, st, n, H.lev_dev, d_gtab, d_grp);
         hipLaunchKernelGGL(k_split_count, dim3(grid), dim3(kBlock), 0, st, n, F.rp, F.ci, F.row_of, d_grp, d_cn, d_cf);
         // row pointers of the near and the far part: prefix sums on the device; the host needs the two totals and the far
         // pointer at the group boundaries only
@@ -852,11 +987,10 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
         nrp = nullptr; nci = nullptr; nval = nullptr;
         H.lanes = pick_lanes(n ? (double)F.nnz / n : 1.0);
     } while (0);
-    void *tmp[] = {d_grp, d_cn, d_cf, nrp, qrp, nci, qci, nval, qval, qci2, qval2};
+    void *tmp[] = {d_grp, d_gtab, d_cn, d_cf, nrp, qrp, nci, qci, nval, qval, qci2, qval2};
     for (void *q : tmp)
         if (q) hipFree(q);
-    H.lev_host.clear();
-    H.lev_host.shrink_to_fit();
+    free_levels(H);
     if (rc) {   // e.g. not enough memory for the blocked copies: keep the pure level solve (F is intact)
         for (PbPlan &pl : H.far) pb_free(&pl);
         H.far.clear();
@@ -981,7 +1115,7 @@ int ilu0_setup(cudamat_solver *s, bool block)
     const double t0 = now_s();
     double t_stamp = t0;
     do {
-        if ((rc = dalloc(&d_flags, 4))) break;     // [0..1] flags, [2] ticket counter of k_levels_dep
+        if ((rc = dalloc(&d_flags, 5))) break;     // [0..1] flags, [2] ticket counter of k_levels_dep, [3] longest row
         if ((rc = dalloc(&d_lev, (size_t)n))) break;
         if (hipHostMalloc((void **)&pl->err_host, sizeof(int), hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void **)&pl->err_dev, pl->err_host, 0) != hipSuccess) {
@@ -1003,27 +1137,19 @@ int ilu0_setup(cudamat_solver *s, bool block)
             rc = CUDAMAT_ERR_ZERO_PIVOT;
             break;
         }
-        std::vector<int> h_rp((size_t)n + 1), h_diag((size_t)n);
-        if (hipMemcpy(h_rp.data(), s->pm_rp, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost) != hipSuccess ||
-            (n && hipMemcpy(h_diag.data(), s->diag_pos, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)) {
-            rc = CUDAMAT_ERR_HIP; set_error("D2H of the pattern failed"); break;
-        }
-        CM_STAMP("find diag + pattern D2H");
+        CM_STAMP("find diag");
         // ---- analysis (pbicgstab.cu:336-347)
-        if ((rc = build_levels(s, false, d_lev, d_flags, s->L, pl->L, h_rp, h_diag, pl->err_host, pl->err_dev))) break;
+        if ((rc = build_levels(s, false, d_lev, d_flags, s->L, pl->L, pl->err_host, pl->err_dev))) break;
         s->t_analysis_l = now_s() - t0;
         const double tu = now_s();
-        if ((rc = build_levels(s, true, d_lev, d_flags, s->U, pl->U, h_rp, h_diag, pl->err_host, pl->err_dev))) break;
+        if ((rc = build_levels(s, true, d_lev, d_flags, s->U, pl->U, pl->err_host, pl->err_dev))) break;
         int maxrow_all = 0;
-        {
-            const int T = host_threads(s->ctx->cfg, n);
-            std::vector<int> tm((size_t)T, 0);
-            parallel_ranges(n, T, [&](int t, int lo, int hi) {
-                int m = 0;
-                for (int i = lo; i < hi; i++) m = std::max(m, h_rp[(size_t)i + 1] - h_rp[(size_t)i]);
-                tm[(size_t)t] = m;
-            });
-            for (int t = 0; t < T; t++) maxrow_all = std::max(maxrow_all, tm[(size_t)t]);
+        if (n) {           // the longest row of the pattern (LDS staging of the factorisation, sortable far rows)
+            if (hipMemsetAsync(d_flags + 3, 0, sizeof(int), st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+            hipLaunchKernelGGL(k_max_row_len, dim3((unsigned)std::min<long long>(((long long)n + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, st,
+                               n, s->pm_rp, d_flags + 3);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&maxrow_all, d_flags + 3, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("row length maximum failed"); break; }
         }
         {
             // the two factors take the hybrid solve TOGETHER: they then share the level-major index spaces (L's output
@@ -1112,9 +1238,9 @@ int ilu0_setup(cudamat_solver *s, bool block)
             if ((rc = dalloc(&pl->perm_a, (size_t)n))) break;
             if ((rc = dalloc(&pl->perm_b, (size_t)n))) break;
         } else {
-            pl->L.lev_host.clear(); pl->L.lev_host.shrink_to_fit();
+            free_levels(pl->L);
         }
-        pl->U.lev_host.clear(); pl->U.lev_host.shrink_to_fit();
+        free_levels(pl->U);
         s->t_factor = now_s() - t1;
         // solve form: one dependency-driven launch per group (default whenever there is more than one level
         // to chain), or one launch per level / run of small levels (option TRSV_SYNCFREE = 0)
