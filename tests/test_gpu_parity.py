@@ -383,7 +383,7 @@ def _real_sparse(oracle, n, density, seed, base=0):
                       S.data.copy(), n)
 
 
-@pytest.mark.parametrize("name", ["mat900", "mat10000", "rand20000x50", "real3000", "longrows"])
+@pytest.mark.parametrize("name", ["mat900", "mat10000", "rand20000x50", "real3000", "longrows", "grid300", "chain70000"])
 def test_ilu0_factors_and_trsv_vs_oracle(cm, ctx, oracle, golden_dir, name):
     """cusparseDcsrilu0 + csrsv_solve replacements (pbicgstab.cu:359, :92-98) against the oracle's
     sequential IKJ ILU(0) and substitutions.  Tolerance: rtol 1e-12 on the factors (same operations,
@@ -394,6 +394,14 @@ def test_ilu0_factors_and_trsv_vs_oracle(cm, ctx, oracle, golden_dir, name):
         A = _real_sparse(oracle, 3000, 0.004, 11, base=1)
     elif name == "longrows":
         A = _real_sparse(oracle, 400, 0.6, 5)          # ~240 entries per row, deep dependency chains
+    elif name == "grid300":
+        A = oracle.poisson5(300, 300)                   # 599 levels: two 8-bit passes of the device's level sort
+    elif name == "chain70000":                          # a tridiagonal chain: as many levels as rows (three passes)
+        n = 70000
+        rp = np.concatenate([[0], np.cumsum(np.r_[2, np.full(n - 2, 3), 2])]).astype(np.int32)
+        ci = np.concatenate([[0, 1]] + [[i - 1, i, i + 1] for i in range(1, n - 1)] + [[n - 2, n - 1]]).astype(np.int32)
+        va = np.concatenate([[4.0, -1.0]] + [[-1.0, 4.0, -1.5]] * (n - 2) + [[-1.0, 4.0]])
+        A = oracle.Csr(n, rp, ci, va, n)
     else:
         A = _load(oracle, golden_dir, name)
     s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
