@@ -264,8 +264,8 @@ extern "C" int cudamat_rccl_comm_create(cudamat_ctx *ctx, const void *id, int ra
         if (c->coll) g_api.CommDestroy(c->coll);
         if (c->p2p) g_api.CommDestroy(c->p2p);
         if (c->red) g_api.CommDestroy(c->red);
-        if (c->side) hipStreamDestroy(c->side);
-        if (c->rstream) hipStreamDestroy(c->rstream);
+        if (c->side) CM_DROP(hipStreamDestroy(c->side));
+        if (c->rstream) CM_DROP(hipStreamDestroy(c->rstream));
         delete c;
         return rc;
     }
@@ -342,8 +342,8 @@ extern "C" int cudamat_rccl_comm_destroy(cudamat_comm *comm)
     if (c->coll) g_api.CommDestroy(c->coll);
     if (c->p2p) g_api.CommDestroy(c->p2p);
     if (c->red) g_api.CommDestroy(c->red);
-    if (c->side) hipStreamDestroy(c->side);
-    if (c->rstream) hipStreamDestroy(c->rstream);
+    if (c->side) CM_DROP(hipStreamDestroy(c->side));
+    if (c->rstream) CM_DROP(hipStreamDestroy(c->rstream));
     delete c;
     memset(comm, 0, sizeof(*comm));
     return CUDAMAT_OK;

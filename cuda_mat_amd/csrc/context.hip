@@ -130,8 +130,8 @@ extern "C" int cudamat_ctx_create(int device, void *stream, cudamat_ctx **out)
     hipError_t e = hipMalloc((void **)&c->parts, sizeof(double) * 2 * kMaxParts);
     if (e == hipSuccess) e = hipMalloc(&c->scratch, kCtxScratchBytes);
     if (e != hipSuccess) {
-        if (c->parts) hipFree(c->parts);
-        if (c->own_stream) hipStreamDestroy(c->stream);
+        if (c->parts) CM_DROP(hipFree(c->parts));
+        if (c->own_stream) CM_DROP(hipStreamDestroy(c->stream));
         delete c;
         return fail_hip(e, "hipMalloc(parts)", __FILE__, __LINE__);
     }
@@ -144,9 +144,9 @@ extern "C" int cudamat_ctx_destroy(cudamat_ctx *ctx)
     if (!ctx) return CUDAMAT_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    hipFree(ctx->parts);
-    hipFree(ctx->scratch);
-    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    CM_DROP(hipFree(ctx->parts));
+    CM_DROP(hipFree(ctx->scratch));
+    if (ctx->own_stream) CM_DROP(hipStreamDestroy(ctx->stream));
     delete ctx;
     return CUDAMAT_OK;
 }
@@ -290,8 +290,8 @@ extern "C" int cudamat_timer_destroy(cudamat_ctx *ctx, void *timer)
     (void)ctx;
     if (!timer) return CUDAMAT_OK;
     cm_timer *t = (cm_timer *)timer;
-    hipEventDestroy(t->a);
-    hipEventDestroy(t->b);
+    CM_DROP(hipEventDestroy(t->a));
+    CM_DROP(hipEventDestroy(t->b));
     free(t);
     return CUDAMAT_OK;
 }

@@ -115,9 +115,9 @@ struct Uploader {
     {
         if (thread.joinable()) thread.join();
         for (hipEvent_t e : ms_event)
-            if (e) hipEventDestroy(e);
+            if (e) CM_DROP(hipEventDestroy(e));
         ms_event.clear();
-        if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); stream = nullptr; }
+        if (stream) { hipStreamSynchronize(stream); CM_DROP(hipStreamDestroy(stream)); stream = nullptr; }
     }
     int finish()
     {
@@ -376,7 +376,7 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
         if (pb_open && !piecewise) {
             if ((rc = ensure_valdict(s))) break;
             if (s->vd.n > 0) {                           // 8-bit indices instead of the fp64 values
-                hipFree(pb.p.pv);
+                CM_DROP(hipFree(pb.p.pv));
                 pb.p.pv = nullptr;
                 if ((rc = pb_build_values(st, &pb, &s->vd))) { pb_open = false; break; }
             }

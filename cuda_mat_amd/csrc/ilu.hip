@@ -341,14 +341,14 @@ static void free_factor(TriFactor &F)
 {
     void *ptrs[] = {F.rp, F.ci, F.val, F.row_of, F.dinv};
     for (void *p : ptrs)
-        if (p) hipFree(p);
-    if (F.lm && F.rhs_of) hipFree(F.rhs_of);       // (in original space the maps alias row_of)
+        if (p) CM_DROP(hipFree(p));
+    if (F.lm && F.rhs_of) CM_DROP(hipFree(F.rhs_of));       // (in original space the maps alias row_of)
     F = TriFactor();
 }
 
 static void free_levels(TriHost &H)
 {
-    if (H.lev_dev) hipFree(H.lev_dev);
+    if (H.lev_dev) CM_DROP(hipFree(H.lev_dev));
     H.lev_dev = nullptr;
 }
 
@@ -358,16 +358,16 @@ int ilu0_release(cudamat_solver *s)
     free_factor(s->U);
     pb_free(&s->pb_perm);
     valdict_free(&s->vd_perm);
-    if (s->x_perm) { hipFree(s->x_perm); s->x_perm = nullptr; }
-    if (s->b_perm) { hipFree(s->b_perm); s->b_perm = nullptr; }
+    if (s->x_perm) { CM_DROP(hipFree(s->x_perm)); s->x_perm = nullptr; }
+    if (s->b_perm) { CM_DROP(hipFree(s->b_perm)); s->b_perm = nullptr; }
     s->perm_ready = false;
     s->perm_failed = false;
-    if (s->lu) hipFree(s->lu);
-    if (s->diag_pos) hipFree(s->diag_pos);
+    if (s->lu) CM_DROP(hipFree(s->lu));
+    if (s->diag_pos) CM_DROP(hipFree(s->diag_pos));
     if (s->pm_owned) {
-        if (s->pm_rp) hipFree(s->pm_rp);
-        if (s->pm_ci) hipFree(s->pm_ci);
-        if (s->pm_val) hipFree(s->pm_val);
+        if (s->pm_rp) CM_DROP(hipFree(s->pm_rp));
+        if (s->pm_ci) CM_DROP(hipFree(s->pm_ci));
+        if (s->pm_val) CM_DROP(hipFree(s->pm_val));
     }
     s->pm_rp = s->pm_ci = nullptr;
     s->pm_val = nullptr;
@@ -378,18 +378,18 @@ int ilu0_release(cudamat_solver *s)
     s->diag_pos = nullptr;
     s->has_ilu = false;
     if (IluPlans *pl = (IluPlans *)s->ilu_plans) {
-        if (pl->L.level_ptr_dev) hipFree(pl->L.level_ptr_dev);
-        if (pl->U.level_ptr_dev) hipFree(pl->U.level_ptr_dev);
+        if (pl->L.level_ptr_dev) CM_DROP(hipFree(pl->L.level_ptr_dev));
+        if (pl->U.level_ptr_dev) CM_DROP(hipFree(pl->U.level_ptr_dev));
         for (TriHost *h : {&pl->L, &pl->U}) {
             for (PbPlan &fp : h->far) pb_free(&fp);
-            if (h->far_buf) hipFree(h->far_buf);
-            if (h->tickets) hipFree(h->tickets);
+            if (h->far_buf) CM_DROP(hipFree(h->far_buf));
+            if (h->tickets) CM_DROP(hipFree(h->tickets));
             free_levels(*h);
         }
-        if (pl->err_host) hipHostFree(pl->err_host);
-        if (pl->posU) hipFree(pl->posU);
-        if (pl->perm_a) hipFree(pl->perm_a);
-        if (pl->perm_b) hipFree(pl->perm_b);
+        if (pl->err_host) CM_DROP(hipHostFree(pl->err_host));
+        if (pl->posU) CM_DROP(hipFree(pl->posU));
+        if (pl->perm_a) CM_DROP(hipFree(pl->perm_a));
+        if (pl->perm_b) CM_DROP(hipFree(pl->perm_b));
         delete pl;
         s->ilu_plans = nullptr;
     }
@@ -472,7 +472,7 @@ static int device_exclusive_scan(hipStream_t st, int n, const int *in, int *out)
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)(((long long)n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, tile_sum, out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(tile_sum);
+    CM_DROP(hipFree(tile_sum));
     CM_HIP(e);
     return CUDAMAT_OK;
 }
@@ -674,7 +674,7 @@ static int sort_rows_by_level(hipStream_t st, int n, const int *d_lev, int **row
     } while (0);
     void *tmp[] = {kb[0], kb[1], rb[0], rb[1], cnt, tot, maxv, lp};
     for (void *q : tmp)
-        if (q) hipFree(q);
+        if (q) CM_DROP(hipFree(q));
     return rc;
 }
 
@@ -756,7 +756,7 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
         int rcs = hipGetLastError() == hipSuccess ? device_exclusive_scan(st, n, d_len, F.rp) : CUDAMAT_ERR_HIP;
         int total = 0;
         if (!rcs && hipMemcpy(&total, F.rp + n, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rcs = CUDAMAT_ERR_HIP;
-        hipFree(d_len);
+        CM_DROP(hipFree(d_len));
         if (rcs) { set_error("factor row pointers failed"); return rcs; }
         F.nnz = total;
     }
@@ -981,7 +981,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
         if ((rc = dalloc(&H.far_buf, (size_t)n))) break;
         if (hipMemsetAsync(H.far_buf, 0, sizeof(double) * (size_t)n, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
         // the level kernels keep only the near entries
-        hipFree(F.rp); hipFree(F.ci); hipFree(F.val);
+        CM_DROP(hipFree(F.rp)); CM_DROP(hipFree(F.ci)); CM_DROP(hipFree(F.val));
         F.rp = nrp; F.ci = nci; F.val = nval;
         F.nnz = nnz_near;
         nrp = nullptr; nci = nullptr; nval = nullptr;
@@ -989,12 +989,12 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
     } while (0);
     void *tmp[] = {d_grp, d_gtab, d_cn, d_cf, nrp, qrp, nci, qci, nval, qval, qci2, qval2};
     for (void *q : tmp)
-        if (q) hipFree(q);
+        if (q) CM_DROP(hipFree(q));
     free_levels(H);
     if (rc) {   // e.g. not enough memory for the blocked copies: keep the pure level solve (F is intact)
         for (PbPlan &pl : H.far) pb_free(&pl);
         H.far.clear();
-        if (H.far_buf) { hipFree(H.far_buf); H.far_buf = nullptr; }
+        if (H.far_buf) { CM_DROP(hipFree(H.far_buf)); H.far_buf = nullptr; }
         H.hybrid = false;
         return rc == CUDAMAT_ERR_NOMEM ? CUDAMAT_OK : rc;
     }
@@ -1087,8 +1087,8 @@ static int select_precond_matrix(cudamat_solver *s)
             rc = CUDAMAT_ERR_HIP; set_error("block extraction failed"); break;
         }
     } while (0);
-    if (first) hipFree(first);
-    if (cnt) hipFree(cnt);
+    if (first) CM_DROP(hipFree(first));
+    if (cnt) CM_DROP(hipFree(cnt));
     return rc;       // on failure ilu0_setup's error path releases the partial copy
 }
 
@@ -1211,7 +1211,7 @@ int ilu0_setup(cudamat_solver *s, bool block)
             int *posL = nullptr;
             const unsigned gp = (unsigned)((n + kBlock - 1) / kBlock);
             if ((rc = dalloc(&posL, (size_t)n))) break;
-            if ((rc = dalloc(&pl->posU, (size_t)n))) { hipFree(posL); break; }
+            if ((rc = dalloc(&pl->posU, (size_t)n))) { CM_DROP(hipFree(posL)); break; }
             hipLaunchKernelGGL(k_invert_perm, dim3(gp), dim3(kBlock), 0, st, n, s->L.row_of, posL);
             hipLaunchKernelGGL(k_invert_perm, dim3(gp), dim3(kBlock), 0, st, n, s->U.row_of, pl->posU);
             rc = split_factor(s, s->L, pl->L, posL);
@@ -1222,8 +1222,8 @@ int ilu0_setup(cudamat_solver *s, bool block)
                 hipLaunchKernelGGL(k_compose_perm, dim3(gp), dim3(kBlock), 0, st, n, s->U.row_of, posL, mapUL);
                 if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("permutation maps failed"); }
             }
-            hipFree(posL);
-            if (rc) { if (mapUL) hipFree(mapUL); break; }
+            CM_DROP(hipFree(posL));
+            if (rc) { if (mapUL) CM_DROP(hipFree(mapUL)); break; }
             if (!(pl->L.hybrid && pl->U.hybrid)) {
                 // (split_factor fell back on one side: out of memory for the blocked copies) -- a half-split pair has no
                 // consistent index space
@@ -1286,8 +1286,8 @@ int ilu0_setup(cudamat_solver *s, bool block)
         }
         s->has_ilu = true;
     } while (0);
-    if (d_flags) hipFree(d_flags);
-    if (d_lev) hipFree(d_lev);
+    if (d_flags) CM_DROP(hipFree(d_flags));
+    if (d_lev) CM_DROP(hipFree(d_lev));
     if (rc) {
         char saved[512];
         snprintf(saved, sizeof(saved), "%s", cudamat_last_error());
@@ -1340,14 +1340,14 @@ int ilu_perm_matrix(cudamat_solver *s)
     } while (0);
     void *tmp[] = {d_rp, d_ci, d_val, d_len};
     for (void *q : tmp)
-        if (q) hipFree(q);
+        if (q) CM_DROP(hipFree(q));
     if (rc) {
         pb_free(&s->pb_perm);
         valdict_free(&s->vd_perm);
         return rc;
     }
     s->perm_ready = true;
-    hipFree(pl->posU);
+    CM_DROP(hipFree(pl->posU));
     pl->posU = nullptr;
     s->t_perm_matrix = now_s() - t0;
     if (s->ctx->cfg.verbose) fprintf(stderr, "[cudamat] ilu0 permuted matrix (rows in L order, columns in U positions) %8.3f ms\n", s->t_perm_matrix * 1e3);

@@ -135,7 +135,7 @@ int Solve::setup()
     // a restart segment (abs_tol > 0) appends to the history of the segments before it (the kernels check the capacity)
     hist_base = abs_tol > 0.0 ? (s->hist_count < s->hist_cap ? s->hist_count : s->hist_cap) : 0;
     if (hist_base == 0 && need_hist > s->hist_cap) {
-        if (s->hist) { CM_HIP(hipStreamSynchronize(st)); hipFree(s->hist); s->hist = nullptr; }
+        if (s->hist) { CM_HIP(hipStreamSynchronize(st)); CM_DROP(hipFree(s->hist)); s->hist = nullptr; }
         CM_TRY(dev_alloc((void **)&s->hist, sizeof(double) * (size_t)need_hist));
         s->hist_cap = need_hist;
     }

@@ -356,8 +356,8 @@ extern "C" int cudamat_comm_dry_destroy(cudamat_comm *comm)
     DryComm *c = (DryComm *)comm->user;
     hipStreamSynchronize(c->side);
     hipStreamSynchronize(c->red);
-    hipStreamDestroy(c->side);
-    hipStreamDestroy(c->red);
+    CM_DROP(hipStreamDestroy(c->side));
+    CM_DROP(hipStreamDestroy(c->red));
     delete c;
     memset(comm, 0, sizeof(*comm));
     return CUDAMAT_OK;

@@ -55,7 +55,7 @@ static void free_work(cudamat_solver *s)
                      &s->pz, &s->pww, &s->pq, &s->py, &s->pxh, &s->pipeA, &s->pipeB, &s->red_pipe,
                      &s->prh, &s->pwh, &s->psh, &s->pzh, &s->pqh, &s->ptmp};
     for (double **q : vs) {
-        if (*q) hipFree(*q);
+        if (*q) CM_DROP(hipFree(*q));
         *q = nullptr;
     }
 }
@@ -266,27 +266,27 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     void *ptrs[] = {s->rp, s->ci, s->val, s->parts_full, s->parts_rv, s->parts_half, s->parts_tt,
                     s->red, s->st, s->hist};
     for (void *p : ptrs)
-        if (p) hipFree(p);
-    if (s->st_ring) hipHostFree(s->st_ring);
-    if (s->snap_host) hipHostFree(s->snap_host);
+        if (p) CM_DROP(hipFree(p));
+    if (s->st_ring) CM_DROP(hipHostFree(s->st_ring));
+    if (s->snap_host) CM_DROP(hipHostFree(s->snap_host));
     for (int i = 0; i < kRing; i++)
-        if (s->ev[i]) hipEventDestroy(s->ev[i]);
-    for (hipEvent_t e : s->prof_ev) hipEventDestroy(e);
-    for (hipEvent_t e : s->comm_ev) hipEventDestroy(e);
-    if (s->need_dev) hipFree(s->need_dev);
-    if (s->bar) hipFree(s->bar);
+        if (s->ev[i]) CM_DROP(hipEventDestroy(s->ev[i]));
+    for (hipEvent_t e : s->prof_ev) CM_DROP(hipEventDestroy(e));
+    for (hipEvent_t e : s->comm_ev) CM_DROP(hipEventDestroy(e));
+    if (s->need_dev) CM_DROP(hipFree(s->need_dev));
+    if (s->bar) CM_DROP(hipFree(s->bar));
     valdict_free(&s->vd);
     for (int e = 0; e < 2; e++) {
-        if (s->ev_red[e]) hipEventDestroy(s->ev_red[e]);
-        if (s->ev_red_done[e]) hipEventDestroy(s->ev_red_done[e]);
+        if (s->ev_red[e]) CM_DROP(hipEventDestroy(s->ev_red[e]));
+        if (s->ev_red_done[e]) CM_DROP(hipEventDestroy(s->ev_red_done[e]));
     }
-    if (s->ev_x) hipEventDestroy(s->ev_x);
+    if (s->ev_x) CM_DROP(hipEventDestroy(s->ev_x));
     for (hipEvent_t e : s->ev_part)
-        if (e) hipEventDestroy(e);
+        if (e) CM_DROP(hipEventDestroy(e));
     for (hipEvent_t e : s->ev_p1)
-        if (e) hipEventDestroy(e);
+        if (e) CM_DROP(hipEventDestroy(e));
     for (hipStream_t q : s->part_stream)
-        if (q) { hipStreamSynchronize(q); hipStreamDestroy(q); }
+        if (q) { hipStreamSynchronize(q); CM_DROP(hipStreamDestroy(q)); }
     delete s;
     return CUDAMAT_OK;
 }
@@ -312,7 +312,7 @@ extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *co
     s->agreed = false;
     s->windowed = false;
     s->windows_known = false;
-    if (s->need_dev) { hipFree(s->need_dev); s->need_dev = nullptr; }
+    if (s->need_dev) { CM_DROP(hipFree(s->need_dev)); s->need_dev = nullptr; }
     const bool forced = comm && comm->world == 1 && s->ctx->cfg.force_sharded;
     if (!comm || (comm->world <= 1 && !forced)) {
         s->sharded = false;
@@ -669,8 +669,8 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms[mode], e0, e1);
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    CM_DROP(hipEventDestroy(e0));
+    CM_DROP(hipEventDestroy(e1));
     s->t_spmv_timing = now_s() - t_timing0;
     CM_HIP(hipMemsetAsync(s->v, 0, sizeof(double) * (size_t)(s->n_pad > 0 ? s->n_pad : 1), st));
     s->ms_csr = ms[0] / 2;
@@ -770,7 +770,7 @@ static int compute_windows(cudamat_solver *s)
         }
         if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_lohi, sizeof(int) * h.size(), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        hipFree(d_lohi);
+        CM_DROP(hipFree(d_lohi));
         CM_HIP(e);
         for (int q = 0; q < W; q++)
             if (q != me && h[(size_t)W + q] > h[(size_t)q]) { mine[(size_t)2 * q] = h[(size_t)q]; mine[(size_t)2 * q + 1] = h[(size_t)W + q]; }

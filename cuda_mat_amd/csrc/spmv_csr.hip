@@ -406,11 +406,11 @@ int plan_spmv_compress(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz
         if (hipMemcpyAsync(&h, flags, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
     } while (0);
-    if (flags) hipFree(flags);
+    if (flags) CM_DROP(hipFree(flags));
     if (rc || h) {                                    // does not fit (or no memory): the plain stream kernel stays
         void *ptrs[] = {plan->c_off16, plan->c_len8, plan->c_tile_base};
         for (void *q : ptrs)
-            if (q) hipFree(q);
+            if (q) CM_DROP(hipFree(q));
         plan->c_off16 = nullptr;
         plan->c_len8 = nullptr;
         plan->c_tile_base = nullptr;
@@ -505,7 +505,7 @@ int plan_spmv_align(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, c
     if (rc) {                                         // no memory / failure: the packed arrays stay
         void *ptrs[] = {plan->a_base, plan->a_off16, plan->a_val};
         for (void *q : ptrs)
-            if (q) hipFree(q);
+            if (q) CM_DROP(hipFree(q));
         plan->a_base = nullptr;
         plan->a_off16 = nullptr;
         plan->a_val = nullptr;
@@ -540,7 +540,7 @@ int plan_spmv_dict(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const 
     if (rc) {                                         // no memory / failure: the plain compressed kernel stays
         void *ptrs[] = {plan->d_pbase, plan->d_off16, plan->d_val8};
         for (void *q : ptrs)
-            if (q) hipFree(q);
+            if (q) CM_DROP(hipFree(q));
         plan->d_pbase = nullptr;
         plan->d_off16 = nullptr;
         plan->d_val8 = nullptr;
@@ -770,7 +770,7 @@ void plan_spmv_free(SpmvPlan *plan)
     plan->d_off16 = nullptr;
     plan->d_val8 = nullptr;
     for (void *q : ptrs)
-        if (q) hipFree(q);
+        if (q) CM_DROP(hipFree(q));
     plan->c_off16 = nullptr;
     plan->c_len8 = nullptr;
     plan->c_tile_base = nullptr;
@@ -819,7 +819,7 @@ static int plan_spmv_tiles(hipStream_t s, int n_rows, int64_t nnz, const int *rp
         plan->grid = grid;
         plan->tile_fix_grid = fix_grid;
     } while (0);
-    if (flag) hipFree(flag);
+    if (flag) CM_DROP(hipFree(flag));
     if (rc) {
         plan_spmv_free(plan);
         if (rc == CUDAMAT_ERR_NOMEM) return CUDAMAT_OK;                  // no room for the tables: lanes-per-row plan stays
@@ -857,7 +857,7 @@ static int plan_spmv_balance(hipStream_t s, const Config &cfg, int n_rows, int64
                            plan->lanes, d);
         hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s);
         const hipError_t e = hipStreamSynchronize(s);
-        if (!scratch) hipFree(d);
+        if (!scratch) CM_DROP(hipFree(d));
         if (e != hipSuccess) return fail_hip(e, "lane cost", __FILE__, __LINE__);
         plan->lane_cost = (double)h * 64.0 / (double)nnz;
         // measured (scripts/skew_probe.py): at 2.0 (rows of 2 and 62 alternating) the lanes kernel is still memory-bound
@@ -882,7 +882,7 @@ int plan_spmv_refine(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, 
     hipLaunchKernelGGL(k_tile_nnz_max, dim3((unsigned)((tiles + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp, d);
     hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
-    if (!scratch) hipFree(d);
+    if (!scratch) CM_DROP(hipFree(d));
     if (e != hipSuccess) return fail_hip(e, "tile scan", __FILE__, __LINE__);
     int R = 0;
     if (h[2] <= kStreamNnz) R = 256;

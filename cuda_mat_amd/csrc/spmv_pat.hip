@@ -58,7 +58,7 @@ void pat_free(PatPlan *p)
 {
     void *ptrs[] = {p->val, p->vidx, p->pid, p->tab};
     for (void *q : ptrs)
-        if (q) hipFree(q);
+        if (q) CM_DROP(hipFree(q));
     *p = PatPlan();
 }
 
@@ -271,7 +271,7 @@ int pat_build(hipStream_t st, int n, int64_t nnz, const int *rp, const int *ci, 
     } while (0);
     void *tmp[] = {table, rep, flags, keys_dev, reps_dev};
     for (void *q : tmp)
-        if (q) hipFree(q);
+        if (q) CM_DROP(hipFree(q));
     if (rc) {
         pat_free(&p);
         return rc;

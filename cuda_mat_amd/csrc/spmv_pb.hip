@@ -59,7 +59,7 @@ void pb_free(PbPlan *p)
 {
     void *ptrs[] = {p->pv, p->pvi, p->pc, p->pr, p->P, p->cstart, p->col0, p->sstart, p->slen, p->order};
     for (void *q : ptrs)
-        if (q) hipFree(q);
+        if (q) CM_DROP(hipFree(q));
     *p = PbPlan();
 }
 
@@ -238,7 +238,7 @@ static int round_blocks(int64_t n, int tile_max)
 // pb_build_end.  pb_build is the four in a row; the drop-in entry point runs them while the matrix is still being uploaded.
 void pb_build_abort(PbBuild *b)
 {
-    if (b->bins) hipFree(b->bins);
+    if (b->bins) CM_DROP(hipFree(b->bins));
     b->bins = nullptr;
     pb_free(&b->p);
 }
@@ -472,7 +472,7 @@ int pb_build_end(hipStream_t st, PbBuild *b, PbPlan *out)
 {
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("pb fill failed"); pb_build_abort(b); return CUDAMAT_ERR_HIP; }
     if (b->verbose) pb_print_plan(b->p);
-    hipFree(b->bins);
+    CM_DROP(hipFree(b->bins));
     b->bins = nullptr;
     b->p.build_seconds = now_s() - b->t0;
     *out = b->p;

@@ -43,7 +43,7 @@ void sell_free(SellPlan *p)
 {
     void *ptrs[] = {p->val, p->col, p->perm, p->len, p->chunk_off};
     for (void *q : ptrs)
-        if (q) hipFree(q);
+        if (q) CM_DROP(hipFree(q));
     *p = SellPlan();
 }
 
@@ -138,7 +138,7 @@ int sell_build(hipStream_t st, int n, int64_t nnz, const int *rp, const int *ci,
                            p.perm, p.len, p.chunk_off, p.val, p.col);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("sell fill failed"); break; }
     } while (0);
-    if (width) hipFree(width);
+    if (width) CM_DROP(hipFree(width));
     if (rc) {
         sell_free(&p);
         return rc;

@@ -109,8 +109,8 @@ int valdict_sample_overflows(hipStream_t st, int64_t count, const double *val, v
 
 void valdict_free(ValDict *v)
 {
-    if (v->dict) hipFree(v->dict);
-    if (v->idx) hipFree(v->idx);
+    if (v->dict) CM_DROP(hipFree(v->dict));
+    if (v->idx) CM_DROP(hipFree(v->idx));
     *v = ValDict();
 }
 
@@ -163,8 +163,8 @@ int valdict_build(hipStream_t st, const Config &cfg, int64_t nnz, const double *
         if (h[1]) { rc = CUDAMAT_ERR_HIP; set_error("value dictionary: a value is missing from its own dictionary"); break; }
         v.n = (int)keys.size();
     } while (0);
-    if (table) hipFree(table);
-    if (flags) hipFree(flags);
+    if (table) CM_DROP(hipFree(table));
+    if (flags) CM_DROP(hipFree(flags));
     if (rc != CUDAMAT_OK || v.n == 0) valdict_free(&v);
     else *out = v;
     return rc;

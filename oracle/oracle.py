@@ -58,6 +58,8 @@ def lib():
                                      C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, C.POINTER(C.c_double), f64p]
         L.orc_pbicgstab.argtypes = [C.c_int, i32p, i32p, f64p, C.c_void_p, f64p, f64p, C.c_int,
                                     C.c_double, C.c_void_p, C.c_int, C.POINTER(Stats)]
+        L.orc_pbicgstab_ex.argtypes = [C.c_int, i32p, i32p, f64p, C.c_void_p, f64p, f64p, C.c_int,
+                                       C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_pipelined_bicgstab.argtypes = [C.c_int, i32p, i32p, f64p, f64p, f64p, C.c_int, C.c_double,
                                              C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_ppipelined_bicgstab.argtypes = [C.c_int, i32p, i32p, f64p, C.c_void_p, f64p, f64p, C.c_int, C.c_double,
@@ -77,6 +79,10 @@ def lib():
         L.orc_rand_rows.argtypes = [C.c_int64, C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int,
                                     i32p, i32p, f64p]
         L.orc_xstar.argtypes = [C.c_int64, C.c_int64, C.c_uint64, f64p]
+        L.orc_example_count.argtypes = [C.c_int, C.c_double, C.c_uint]
+        L.orc_example_count.restype = C.c_int64
+        L.orc_example_system.argtypes = [C.c_int, C.c_double, C.c_double, C.c_uint, i32p, i32p, f64p, f64p]
+        L.orc_example_system.restype = C.c_int64
         L.orc_mtx_load.argtypes = [C.c_char_p, C.c_int] + [C.POINTER(C.c_int)] * 3 + [
             C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_int)),
             C.POINTER(C.POINTER(C.c_int))]
@@ -204,19 +210,37 @@ def levels(A, upper=False):
     return nlev, lev
 
 
-def pbicgstab(A, f, x0=None, vm=None, maxit=2000, tol=1e-6, want_hist=False):
-    """pbicgstab.cu:45-154 (x0 defaults to ones, :306-308)."""
+def pbicgstab(A, f, x0=None, vm=None, maxit=2000, tol=1e-6, want_hist=False, want_trace=False):
+    """pbicgstab.cu:45-154 (x0 defaults to ones, :306-308).
+    want_trace: also return the loop's scalars, one row per iteration started:
+    (rho, sum|rw_j r_j|, rw.v, sum|rw_j v_j|, alpha, t.r, t.t, omega) -- see noise_breakdown()."""
     x = np.ones(A.n) if x0 is None else _f(x0).copy()
     st = Stats()
-    hist = np.full(2 * maxit, np.nan) if want_hist else None
-    vmp = None if vm is None else _f(vm).ctypes.data_as(C.c_void_p)
+    hist = np.full(2 * maxit, np.nan) if (want_hist or want_trace) else None
     vm_keep = None if vm is None else _f(vm)
-    if vm_keep is not None:
-        vmp = vm_keep.ctypes.data_as(C.c_void_p)
-    lib().orc_pbicgstab(A.n, A.rowptr, A.colidx, A.val, vmp, _f(f), x, maxit, tol,
-                        None if hist is None else hist.ctypes.data_as(C.c_void_p),
-                        0 if hist is None else len(hist), C.byref(st))
+    vmp = None if vm_keep is None else vm_keep.ctypes.data_as(C.c_void_p)
+    trace = np.full((maxit, 8), np.nan) if want_trace else None
+    lib().orc_pbicgstab_ex(A.n, A.rowptr, A.colidx, A.val, vmp, _f(f), x, maxit, tol,
+                           None if hist is None else hist.ctypes.data_as(C.c_void_p),
+                           0 if hist is None else len(hist),
+                           None if trace is None else trace.ctypes.data_as(C.c_void_p), maxit if want_trace else 0, C.byref(st))
+    if want_trace:
+        started = min(maxit, st.iters + (1 if st.half_exit else 0))
+        return x, st, hist, trace[:started]
     return (x, st, hist) if want_hist else (x, st)
+
+
+def noise_breakdown(trace, n):
+    """first iteration of a pbicgstab() trace whose rho (pbicgstab.cu:81) or rw.v (:106) is no larger than the worst-case
+    rounding error of its own summation, n eps sum|a_j b_j| -- from there on the reference's unguarded loop (:84,107)
+    divides rounding noise by rounding noise; also counts a rho / rw.v / t.t that is exactly 0 or not finite.  None: never."""
+    eps = np.finfo(np.float64).eps
+    with np.errstate(invalid="ignore"):
+        bad = ((np.abs(trace[:, 0]) <= n * eps * trace[:, 1]) | ~np.isfinite(trace[:, 0])
+               | (np.abs(trace[:, 2]) <= n * eps * trace[:, 3]) | (~np.isfinite(trace[:, 2]) & np.isfinite(trace[:, 1]))
+               | (trace[:, 6] == 0.0))
+    w = np.nonzero(bad)[0]
+    return int(w[0]) if w.size else None
 
 
 PIPE_RR = 32        # residual replacement period of the pipelined loop (csrc/solver.hip kPipeRR)
@@ -299,6 +323,19 @@ def xstar(n, seed, i0=0, i1=None):
     x = np.empty(i1 - i0)
     lib().orc_xstar(i0, i1, seed, x)
     return x
+
+
+def example_system(dim=10000, p_zero=0.99, p_zero_vec=0.2, seed=1):
+    """the system the reference CLI solves when no -M is given (example.cpp:274-288,339): returns (A 1-based, b).
+    seed 1 = the reference's own rand() stream (it never calls srand)."""
+    nnz = lib().orc_example_count(dim, p_zero, seed)
+    rp = np.empty(dim + 1, np.int32)
+    ci = np.empty(max(nnz, 1), np.int32)
+    v = np.empty(max(nnz, 1))
+    b = np.empty(dim)
+    got = lib().orc_example_system(dim, p_zero, p_zero_vec, seed, rp, ci, v, b)
+    assert got == nnz
+    return Csr(dim, rp, ci[:nnz].copy(), v[:nnz].copy(), dim), b
 
 
 def _take(ptr, count, dtype):

@@ -119,3 +119,53 @@ void orc_xstar(int64_t i0, int64_t i1, uint64_t seed, double *x)
     for (int64_t i = i0; i < i1; i++)
         x[i - i0] = 1.0 + (double)(orc_mix64(seed + (uint64_t)i) & 7) * 0.125;
 }
+
+/* ---- the reference CLI's own random system (example.cpp:173-180,274-288,339) ----------------
+ * What `example` solves when no -M is given: fill_csr_matrix<Base1>(dim, dim, f, 1e-3)
+ * (pbicgstab.h:57-76: dense scan, row-major, positions with |f(i,j)| > eps kept, 1-based) with
+ *   f(i,i) = rand_float(1,10);  f(i,j) = rand_float_0_1() >= p_zero ? rand_float(1,10) : 0.0
+ * (example.cpp:274-285), rand_float_0_1 = rand() / RAND_MAX, rand_float = that * (max-min) + min
+ * (pbicgstab.cu:413-423); the right-hand side afterwards from the same rand() stream:
+ * b_i = rand_float_0_1() <= p_zero_vec ? 0 : rand_float(1,5)  (gen_rand_vector, pbicgstab.cu:1093-1097;
+ * example.cpp:339 with P(0) = 0.2).  The reference never calls srand(): its draws are those of
+ * srand(1).  `seed` is passed to srand() here (1 = the reference's stream).
+ * The matrix is neither diagonally dominant nor symmetric: entries in [1,10] everywhere.
+ * Two passes over the same stream: orc_example_count sizes the arrays. */
+static double ex_rand01(void) { return (double)rand() / (double)RAND_MAX; }
+static double ex_rand(double lo, double hi) { return ex_rand01() * (hi - lo) + lo; }
+
+static int64_t example_scan(int dim, double p_zero, unsigned seed, int *rp, int *ci, double *v)
+{
+    int64_t k = 0;
+    srand(seed);
+    if (rp) rp[0] = 1;
+    for (int i = 0; i < dim; i++) {
+        for (int j = 0; j < dim; j++) {
+            double el;
+            if (i == j) el = ex_rand(1, 10);                                 /* example.cpp:275 */
+            else if (ex_rand01() >= p_zero) el = ex_rand(1, 10);             /* :277-278 */
+            else el = 0.0;                                                   /* :280 */
+            if ((el < 0 ? -el : el) > 1e-3) {                                /* pbicgstab.h:65 */
+                if (ci) { ci[k] = j + 1; v[k] = el; }
+                k++;
+            }
+        }
+        if (rp) rp[i + 1] = (int)k + 1;
+    }
+    return k;
+}
+
+int64_t orc_example_count(int dim, double p_zero, unsigned seed)
+{
+    return example_scan(dim, p_zero, seed, NULL, NULL, NULL);
+}
+
+/* fills rp[dim+1], ci[nnz], v[nnz] (1-based, as fill_csr_matrix<Base1>) and b[dim]; returns nnz */
+int64_t orc_example_system(int dim, double p_zero, double p_zero_vec, unsigned seed,
+                           int *rp, int *ci, double *v, double *b)
+{
+    const int64_t nnz = example_scan(dim, p_zero, seed, rp, ci, v);
+    for (int i = 0; i < dim; i++)                                            /* pbicgstab.cu:1093-1097 */
+        b[i] = ex_rand01() <= p_zero_vec ? 0.0 : ex_rand(1, 5.0);
+    return nnz;
+}

@@ -210,10 +210,31 @@ static void precond_apply(int n, const int *rp, const int *ci, const double *vm,
     }
 }
 
+/* sum |a_i b_i|: the scale the rounding error of orc_dot(a, b) is relative to */
+static double abs_dot(int n, const double *a, const double *b)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += fabs(a[i] * b[i]);
+    return s;
+}
+
 int orc_pbicgstab(int n, const int *rp, const int *ci, const double *a,
                   const double *vm, const double *f, double *x,
                   int maxit, double tol, double *hist, int hist_cap,
                   orc_stats *st)
+{
+    return orc_pbicgstab_ex(n, rp, ci, a, vm, f, x, maxit, tol, hist, hist_cap, NULL, 0, st);
+}
+
+/* the same loop, also recording its scalars: trace[8 i + ...] = rho (:81), sum |rw_j r_j|, rw.v (:106), sum |rw_j v_j|,
+ * alpha (:107), t.r (:135), t.t (:136), omega (:137) of iteration i (NaN where the iteration ended at the half step).
+ * The reference has no breakdown guard in this loop (:81,107,137 divide whatever they get): a caller can tell from the
+ * trace when rho or rw.v fell below the rounding error of its own summation (|rho| <= n eps sum|rw_j r_j|), i.e. when the
+ * loop began to divide noise by noise -- tests/test_gpu_nondominant.py classifies outcomes with it. */
+int orc_pbicgstab_ex(int n, const int *rp, const int *ci, const double *a,
+                     const double *vm, const double *f, double *x,
+                     int maxit, double tol, double *hist, int hist_cap,
+                     double *trace, int trace_iters, orc_stats *st)
 {
     double *r = dalloc(n), *rw = dalloc(n), *p = dalloc(n), *pw = dalloc(n);
     double *s = dalloc(n), *t = dalloc(n), *v = dalloc(n);
@@ -233,6 +254,11 @@ int orc_pbicgstab(int n, const int *rp, const int *ci, const double *a,
     for (i = 0; i < maxit;) {                                 /* :79               */
         rhop = rho;                                           /* :80               */
         rho = orc_dot(n, rw, r);                              /* :81               */
+        double *tr = (trace && i < trace_iters) ? trace + 8 * (size_t)i : NULL;
+        if (tr) {
+            for (int q = 0; q < 8; q++) tr[q] = NAN;
+            tr[0] = rho; tr[1] = abs_dot(n, rw, r);
+        }
         if (i > 0) {                                          /* :83               */
             beta = (rho / rhop) * (alpha / omega);            /* :84               */
             negomega = -omega;
@@ -244,6 +270,7 @@ int orc_pbicgstab(int n, const int *rp, const int *ci, const double *a,
         orc_csrmv(n, rp, ci, a, 1.0, pw, 0.0, v);             /* :104 v = A pw     */
         temp = orc_dot(n, rw, v);                             /* :106              */
         alpha = rho / temp;                                   /* :107              */
+        if (tr) { tr[2] = temp; tr[3] = abs_dot(n, rw, v); tr[4] = alpha; }
         negalpha = -alpha;
         orc_axpy(n, negalpha, v, r);                          /* :109              */
         orc_axpy(n, alpha, pw, x);                            /* :110              */
@@ -258,6 +285,7 @@ int orc_pbicgstab(int n, const int *rp, const int *ci, const double *a,
         temp = orc_dot(n, t, r);                              /* :135              */
         temp2 = orc_dot(n, t, t);                             /* :136              */
         omega = temp / temp2;                                 /* :137              */
+        if (tr) { tr[5] = temp; tr[6] = temp2; tr[7] = omega; }
         negomega = -omega;
         orc_axpy(n, omega, s, x);                             /* :139              */
         orc_axpy(n, negomega, t, r);                          /* :140              */
