@@ -316,7 +316,7 @@ extern "C" int cudamat_rccl_comm_abort(cudamat_comm *comm)
         h[0] = c->coll; h[1] = c->p2p; h[2] = c->red;
         c->coll = c->p2p = c->red = nullptr;
     }
-    hipSetDevice(device);
+    CM_DROP(hipSetDevice(device));
     for (ncclComm_t q : h)
         if (q) g_api.CommAbort(q);
     return CUDAMAT_OK;
@@ -327,7 +327,7 @@ extern "C" int cudamat_rccl_comm_destroy(cudamat_comm *comm)
     if (!comm || !comm->user) return CUDAMAT_OK;
     CM_ARG(comm->allgather == rccl_allgather, "not a communicator made by cudamat_rccl_comm_create");
     RcclComm *c = (RcclComm *)comm->user;
-    hipSetDevice(c->device);
+    CM_DROP(hipSetDevice(c->device));
     bool was_aborted;
     { std::lock_guard<std::mutex> lock(c->mu); was_aborted = c->aborted; }
     if (was_aborted) {              // (the communicators are gone; their kernels were told to leave)
@@ -335,9 +335,9 @@ extern "C" int cudamat_rccl_comm_destroy(cudamat_comm *comm)
         bounded_sync(c->side, 5.0);
         bounded_sync(c->rstream, 5.0);
     } else {
-        hipStreamSynchronize(c->main);
-        hipStreamSynchronize(c->side);
-        hipStreamSynchronize(c->rstream);
+        CM_DROP(hipStreamSynchronize(c->main));
+        CM_DROP(hipStreamSynchronize(c->side));
+        CM_DROP(hipStreamSynchronize(c->rstream));
     }
     if (c->coll) g_api.CommDestroy(c->coll);
     if (c->p2p) g_api.CommDestroy(c->p2p);

@@ -14,6 +14,10 @@ namespace cm {
 
 void set_error(const char *fmt, ...);
 int fail_hip(hipError_t e, const char *what, const char *file, int line);
+inline int rc_of(hipError_t e, const char *what, const char *file, int line)
+{
+    return e == hipSuccess ? CUDAMAT_OK : fail_hip(e, what, file, line);
+}
 // raise hipFuncAttributeMaxDynamicSharedMemorySize of kernel `fn` to 160 KB on the CURRENT device; remembered per
 // (device, kernel), so a second device driven by the same process gets its own call; the return code is checked
 int set_max_lds(const void *fn);
@@ -23,6 +27,12 @@ int set_max_lds(const void *fn);
         hipError_t e__ = (expr);                                            \
         if (e__ != hipSuccess) return cm::fail_hip(e__, #expr, __FILE__, __LINE__); \
     } while (0)
+
+// a release or teardown call whose failure has no remedy (hipFree, hip*Destroy, the device selection and the last sync
+// of a destructor): the result is dropped on purpose
+#define CM_DROP(expr) ((void)(expr))
+// a HIP call inside code that keeps its own `rc`: records the failure (message included) and yields the error code
+#define CM_RC(expr) cm::rc_of((expr), #expr, __FILE__, __LINE__)
 
 #define CM_TRY(expr)                          \
     do {                                      \

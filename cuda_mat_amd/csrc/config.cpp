@@ -5,7 +5,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <unistd.h>
+
+#include <mutex>
+#include <set>
 #include <string>
+
+extern char **environ;
 
 #include "common.h"
 
@@ -137,6 +143,16 @@ bool config_set(Config &cfg, const char *name, const char *value)
     return false;
 }
 
+// one stderr line per distinct complaint and process: an A/B script that passes its switches through the environment must
+// not measure the default configuration unnoticed because a value was mistyped or a switch no longer exists
+static void warn_once(const std::string &text)
+{
+    static std::mutex mu;
+    static std::set<std::string> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    if (seen.insert(text).second) fprintf(stderr, "cudamat: %s\n", text.c_str());
+}
+
 Config config_from_env()
 {
     Config cfg;
@@ -144,8 +160,18 @@ Config config_from_env()
         const std::string var = std::string("CUDAMAT_") + o.name;
         const char *v = getenv(var.c_str());          // the library's only getenv
         if (!v || !*v) continue;
-        if (!apply(cfg, o, v) && cfg.verbose)
-            fprintf(stderr, "cudamat: %s=\"%s\" is not an accepted value and was ignored (%s)\n", var.c_str(), v, o.help);
+        if (!apply(cfg, o, v))
+            warn_once(var + "=\"" + v + "\" is not an accepted value and was IGNORED (" + o.help + ")");
+    }
+    // CUDAMAT_* variables that name no switch of this library (bench.py's own CUDAMAT_BENCH_* aside)
+    for (char **e = environ; e && *e; e++) {
+        if (strncmp(*e, "CUDAMAT_", 8) || !strncmp(*e, "CUDAMAT_BENCH_", 14)) continue;
+        const char *eq = strchr(*e, '=');
+        if (!eq || !eq[1]) continue;
+        const std::string name(*e + 8, (size_t)(eq - (*e + 8)));
+        bool known = false;
+        for (const Option &o : kOptions) known = known || name == o.name;
+        if (!known) warn_once("CUDAMAT_" + name + " names no switch of this library and was IGNORED (cudamat_options_help lists them)");
     }
     return cfg;
 }

@@ -142,8 +142,8 @@ extern "C" int cudamat_ctx_create(int device, void *stream, cudamat_ctx **out)
 extern "C" int cudamat_ctx_destroy(cudamat_ctx *ctx)
 {
     if (!ctx) return CUDAMAT_OK;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    CM_DROP(hipSetDevice(ctx->device));
+    CM_DROP(hipStreamSynchronize(ctx->stream));
     CM_DROP(hipFree(ctx->parts));
     CM_DROP(hipFree(ctx->scratch));
     if (ctx->own_stream) CM_DROP(hipStreamDestroy(ctx->stream));
@@ -324,9 +324,10 @@ extern "C" int cudamat_spmv(cudamat_ctx *ctx, int n, const int *rowptr, const in
     a.dot = 0;
     a.loop = LoopArgs{nullptr, nullptr, 0, 0, 0};
     a.check = CHECK_NONE;
-    const int rc = launch_spmv(ctx->stream, plan, a);
+    int rc = launch_spmv(ctx->stream, plan, a);
     if (plan.tiles) {                      // the tile tables live only for this call
-        hipStreamSynchronize(ctx->stream);
+        const int rc_sync = CM_RC(hipStreamSynchronize(ctx->stream));
+        if (!rc) rc = rc_sync;
         plan_spmv_free(&plan);
     }
     return rc;

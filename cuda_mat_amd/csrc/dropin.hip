@@ -47,6 +47,8 @@ struct Uploader {
     std::vector<hipEvent_t> ms_event;
     std::vector<std::atomic<int>> ms_recorded;
     std::atomic<int> failed{0};
+    hipError_t err = hipSuccess;          // the uploader thread's failing call (read after join(): HIP's last error is per thread)
+    const char *err_what = "";
     hipStream_t stream = nullptr;
     int device = 0;
     std::thread thread;
@@ -85,17 +87,23 @@ struct Uploader {
 
     void issue()
     {
-        hipSetDevice(device);
+        auto bad = [this](hipError_t e, const char *what) {
+            if (e == hipSuccess) return false;
+            err = e; err_what = what;
+            failed = 1;
+            return true;
+        };
+        if (bad(hipSetDevice(device), "hipSetDevice")) return;
         for (size_t c = 0; c < chunks.size(); c++) {
             if (failed) return;
-            if (hipMemcpyAsync(chunks[c].dst, chunks[c].src, chunks[c].bytes, hipMemcpyHostToDevice, stream) != hipSuccess) { failed = 1; return; }
+            if (bad(hipMemcpyAsync(chunks[c].dst, chunks[c].src, chunks[c].bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync")) return;
             const int m = chunks[c].milestone;
             if (m >= 0) {
-                if (hipEventRecord(ms_event[(size_t)m], stream) != hipSuccess) { failed = 1; return; }
+                if (bad(hipEventRecord(ms_event[(size_t)m], stream), "hipEventRecord")) return;
                 ms_recorded[(size_t)m].store(1, std::memory_order_release);
             }
         }
-        if (hipStreamSynchronize(stream) != hipSuccess) failed = 1;
+        bad(hipStreamSynchronize(stream), "hipStreamSynchronize");
         t_done = now_s();
     }
 
@@ -117,12 +125,15 @@ struct Uploader {
         for (hipEvent_t e : ms_event)
             if (e) CM_DROP(hipEventDestroy(e));
         ms_event.clear();
-        if (stream) { hipStreamSynchronize(stream); CM_DROP(hipStreamDestroy(stream)); stream = nullptr; }
+        if (stream) { CM_DROP(hipStreamSynchronize(stream)); CM_DROP(hipStreamDestroy(stream)); stream = nullptr; }
     }
     int finish()
     {
         join();
-        if (failed) { set_error("host-to-device upload failed (%s)", hipGetErrorString(hipGetLastError())); return CUDAMAT_ERR_HIP; }
+        if (failed) {
+            set_error("host-to-device upload failed (%s: %s)", err_what, err == hipSuccess ? "stopped early" : hipGetErrorString(err));
+            return CUDAMAT_ERR_HIP;
+        }
         return CUDAMAT_OK;
     }
     ~Uploader() { if (thread.joinable()) failed = 1; join(); }      // (an early exit: tell the thread to stop; never touches the error string)
@@ -222,7 +233,8 @@ int build_or_reuse_candidate(cudamat_ctx *ctx, const Config &cfg, const HostSyst
         int hflag = 1;
         cudamat_solver *c = g_cache.s;
         if ((rc = cudamat_malloc(ctx, sizeof(int), (void **)&flag))) break;
-        hipMemsetAsync(flag, 0, sizeof(int), ctx->stream);
+        // (a flag word that could not be cleared would make any matrix look "different": fail the call instead)
+        if ((rc = CM_RC(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream)))) break;
         rc = cudamat_malloc(ctx, sizeof(int) * ((size_t)nnz > (size_t)n + 1 ? (size_t)nnz : (size_t)n + 1), (void **)&tmp);
         if (!rc) rc = launch_rebase(ctx->stream, (int64_t)n + 1, d_rp, -base, tmp);
         if (!rc) rc = device_equal(ctx->stream, tmp, c->rp, sizeof(int) * ((size_t)n + 1), flag);
@@ -252,8 +264,10 @@ int build_or_reuse_candidate(cudamat_ctx *ctx, const Config &cfg, const HostSyst
 // Everything is ALLOCATED before the first byte travels (the blocked copy's geometry depends on the sizes only) and
 // nothing is freed until the last byte has landed: hipMalloc / hipFree take process-wide locks (hipFree waits for every
 // stream of the device), and an upload that shares the process with them was measured at a sixth of its speed.
+// speculative = false (the retry after an out-of-memory call): nothing is allocated ahead of the pattern; the SpMV form is
+// then chosen, and its copy built, after the upload by ensure_spmv_mode like in the staged cudamat_solver_create path.
 int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h, double *d_b, double *d_x, double *d_d,
-                        cudamat_solver **s_out, double *t_up)
+                        cudamat_solver **s_out, double *t_up, bool speculative = true)
 {
     const double t0 = now_s();
     const int n = h.n, nnz = h.nnz, base = h.base;
@@ -272,9 +286,16 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
     bool pb_open = false;
     // (a row block of a wider matrix will be sharded by cudamat_solver_set_comm, which cuts the column blocks at the ranks'
     // slices: its copy is built then)
-    const bool want_pb = n_cols == (int64_t)n && cfg.spmv_mode != 0 && cfg.spmv_mode != 2 && cfg.spmv_mode != 3 &&
-                         (cfg.spmv_mode == 1 || !cfg.spmv_tune_full) && pb_candidate(st, n, n_cols, nnz, nullptr, nullptr) &&
-                         (cfg.spmv_mode == 1 || (int64_t)nnz >= 8 * (int64_t)n);
+    bool want_pb = speculative && n_cols == (int64_t)n && cfg.spmv_mode != 0 && cfg.spmv_mode != 2 && cfg.spmv_mode != 3 &&
+                   (cfg.spmv_mode == 1 || !cfg.spmv_tune_full) && pb_candidate(st, n, n_cols, nnz, nullptr, nullptr) &&
+                   (cfg.spmv_mode == 1 || (int64_t)nnz >= 8 * (int64_t)n);
+    if (want_pb) {
+        // the copy is 20 B per entry and the pattern may still turn it down (banded, not scattered): take it ahead of the
+        // pattern only while it leaves as much again free -- otherwise a later stage (value dictionary, ILU(0), a cached
+        // system) could run out of memory where the staged path would have fitted
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (size_t)20 * (size_t)nnz) want_pb = false;
+    }
     if (want_pb) {
         const int rcb = pb_build_alloc(st, cfg, n, n_cols, nnz, nullptr, &pb);
         pb_open = rcb == CUDAMAT_OK;                     // (no room / outside the form's limits: ensure_spmv_mode decides later)
@@ -407,7 +428,7 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
 }
 
 // one attempt (the caller holds g_cache.mu)
-int solve_host_locked(const Config &cfg, const HostSystem &h, int precond, int loop, int maxit, double tol, int debug,
+int solve_host_locked(const Config &cfg, const HostSystem &h, bool speculative, int precond, int loop, int maxit, double tol, int debug,
                       double *x, cudamat_stats *out)
 {
     const int n = h.n, nnz = h.nnz, base = h.base;
@@ -434,7 +455,7 @@ int solve_host_locked(const Config &cfg, const HostSystem &h, int precond, int l
         if (candidate) {
             if ((rc = build_or_reuse_candidate(ctx, cfg, h, d_b, d_x, d_d, &s, &reused, &t_up))) break;
         } else {
-            if ((rc = build_beside_upload(ctx, cfg, h, d_b, d_x, d_d, &s, &t_up))) break;
+            if ((rc = build_beside_upload(ctx, cfg, h, d_b, d_x, d_d, &s, &t_up, speculative))) break;
         }
         if (g_cache.d_d && !reused) { cudamat_free(ctx, g_cache.d_d); g_cache.d_d = nullptr; }
         if ((rc = cudamat_solver_set_shift(s, d_d))) break;
@@ -501,12 +522,12 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
     const Config cfg = config_from_env();                          // no caller-made context: the switches of THIS call
     const HostSystem h{n, nnz, base, (int64_t)n, A, iA, jA, d, x0, b};
     std::lock_guard<std::mutex> cache_lock(g_cache.mu);            // (the entry points are not re-entrant upstream either)
-    int rc = solve_host_locked(cfg, h, precond, loop, maxit, tol, debug, x, out);
+    int rc = solve_host_locked(cfg, h, true, precond, loop, maxit, tol, debug, x, out);
     if (rc == CUDAMAT_ERR_NOMEM) {
         // the solver kept from the previous call (several GB at the BASELINE sizes) may be what is in the way: the
         // reference frees everything per call (pbicgstab.cu:392-405), so release it and try once more
         cache_drop_locked();
-        rc = solve_host_locked(cfg, h, precond, loop, maxit, tol, debug, x, out);
+        rc = solve_host_locked(cfg, h, false, precond, loop, maxit, tol, debug, x, out);
     }
     return rc;
 }

@@ -39,7 +39,7 @@ static double now_s()
 #define CM_STAMP(label)                                                                       \
     do {                                                                                      \
         if (s->ctx->cfg.verbose) {                                                            \
-            hipStreamSynchronize(st);                                                         \
+            CM_DROP(hipStreamSynchronize(st));   /* (diagnostic timing only) */                       \
             const double t_now = now_s();                                                     \
             fprintf(stderr, "[cudamat] ilu0 %-28s %8.3f ms\n", label, (t_now - t_stamp) * 1e3); \
             t_stamp = t_now;                                                                  \

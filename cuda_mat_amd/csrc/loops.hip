@@ -65,7 +65,7 @@ struct Solve {
     ScalarSrc pipeB_src{nullptr, 0, 1};
     hipStream_t rst = nullptr;         // the communicator's reduce stream (sharded runs)
 
-    void prof_mark() { if (profile) hipEventRecord(prof_event(s, pe++), st); }
+    void prof_mark() { if (profile && hipEventRecord(prof_event(s, pe++), st) != hipSuccess) s->prof_failed = true; }
 
     int setup();
     int pipelined_prologue();
@@ -152,6 +152,7 @@ int Solve::setup()
     s->comm_used = 0;
     s->comm_kind.clear();
     s->profiling = profile && sharded;
+    s->prof_failed = false;
     t_loop0 = now_s();
     if (flags & CUDAMAT_FLAG_X0_ONES) CM_TRY(launch_fill(st, n, 1.0, x));
     // r = A x0 (pbicgstab.cu:67 / :645-646); x may be a caller buffer without pad
@@ -585,7 +586,7 @@ int Solve::finish(bool *precond_gave_up, cudamat_stats *out)
         // construction -- the solver's stream idles there for nothing else
         for (size_t i = 0; i < s->comm_kind.size() && 2 * i + 1 < s->comm_used; i++) {
             float ms = 0.f;
-            hipEventElapsedTime(&ms, s->comm_ev[2 * i], s->comm_ev[2 * i + 1]);
+            if (hipEventElapsedTime(&ms, s->comm_ev[2 * i], s->comm_ev[2 * i + 1]) != hipSuccess) s->prof_failed = true;
             switch (s->comm_kind[i]) {
             case 0: stt.ms_gather += ms; stt.n_gather++; break;
             case 2: stt.ms_gather += ms; stt.ms_gather_exposed += ms; stt.n_gather++; break;
@@ -598,7 +599,7 @@ int Solve::finish(bool *precond_gave_up, cudamat_stats *out)
         const int per_it_pairs = precond ? 4 : 2;
         for (size_t i = 0; i + 1 < pe; i += 2) {
             float ms = 0.f;
-            hipEventElapsedTime(&ms, s->prof_ev[i], s->prof_ev[i + 1]);
+            if (hipEventElapsedTime(&ms, s->prof_ev[i], s->prof_ev[i + 1]) != hipSuccess) s->prof_failed = true;
             const size_t pair = (i / 2) % per_it_pairs;
             const bool is_trsv = precond && (pair == 0 || pair == 2);
             if (is_trsv) { stt.ms_trsv += ms; stt.n_trsv += 2; }
@@ -612,10 +613,16 @@ int Solve::finish(bool *precond_gave_up, cudamat_stats *out)
         }
     }
 
+    if (s->prof_failed) {          // an event call failed: no timing is better than a wrong one
+        stt.ms_spmv = stt.ms_trsv = stt.ms_gather = stt.ms_gather_exposed = stt.ms_allreduce = 0.0;
+        stt.n_spmv = stt.n_trsv = stt.n_gather = stt.n_allreduce = 0;
+        if (s->ctx->cfg.verbose) fprintf(stderr, "[cudamat] per-launch timing dropped: a hipEvent call failed\n");
+    }
+
     if (flags & CUDAMAT_FLAG_DEBUG) {
         std::vector<double> h((size_t)(s->hist_count > 0 ? s->hist_count : 1));
         if (s->hist_count > 0)
-            hipMemcpy(h.data(), s->hist, sizeof(double) * (size_t)s->hist_count, hipMemcpyDeviceToHost);
+            CM_HIP(hipMemcpy(h.data(), s->hist, sizeof(double) * (size_t)s->hist_count, hipMemcpyDeviceToHost));
         if (loop != CUDAMAT_LOOP_PBICGSTAB2) {
             printf("gpu, init residual:norm %20.16f\n", fin.nrm0);            // :77
             for (int i = hist_base; i < s->hist_count; i++) {                  // (a restart segment prints its own part)

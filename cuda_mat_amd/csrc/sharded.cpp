@@ -354,8 +354,8 @@ extern "C" int cudamat_comm_dry_destroy(cudamat_comm *comm)
     if (!comm || !comm->user) return CUDAMAT_OK;
     CM_ARG(comm->allgather == dry_allgather, "not a dry communicator");
     DryComm *c = (DryComm *)comm->user;
-    hipStreamSynchronize(c->side);
-    hipStreamSynchronize(c->red);
+    CM_DROP(hipStreamSynchronize(c->side));
+    CM_DROP(hipStreamSynchronize(c->red));
     CM_DROP(hipStreamDestroy(c->side));
     CM_DROP(hipStreamDestroy(c->red));
     delete c;

@@ -89,6 +89,7 @@ struct cudamat_solver {
     std::vector<int> comm_kind;
     size_t comm_used = 0;
     bool profiling = false;
+    bool prof_failed = false;          // an event call of the (optional) per-launch timing failed: the timings of this solve are void
 
     // row sharding
     bool sharded = false;

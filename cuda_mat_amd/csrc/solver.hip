@@ -115,16 +115,18 @@ static int validate_csr(cudamat_solver *s)
 {
     hipStream_t st = s->ctx->stream;
     int *d = (int *)s->ctx->scratch, h[3] = {0, 0, 0};
-    hipMemsetAsync(d, 0, sizeof(h), st);
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(h), st);
     hipLaunchKernelGGL(k_check_rowptr, dim3((unsigned)(((long long)s->n + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, s->n,
                        (long long)s->nnz, s->rp, d);
-    hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
-    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess && !h[0] && s->n > 0 && s->nnz > 0) {
         hipLaunchKernelGGL(k_check_columns, dim3((unsigned)(((long long)s->n * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                            s->n, (long long)s->n_cols, s->rp, s->ci, d);
-        hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
-        e = hipStreamSynchronize(st);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     if (e != hipSuccess) return fail_hip(e, "CSR validation", __FILE__, __LINE__);
     if (h[0]) { set_error("row pointers must start at the index base, never decrease and end at nnz"); return CUDAMAT_ERR_ARG; }
@@ -255,8 +257,8 @@ extern "C" int cudamat_solver_create(cudamat_ctx *ctx, int n_local, int64_t n_co
 extern "C" int cudamat_solver_destroy(cudamat_solver *s)
 {
     if (!s) return CUDAMAT_OK;
-    hipSetDevice(s->ctx->device);
-    hipStreamSynchronize(s->ctx->stream);
+    CM_DROP(hipSetDevice(s->ctx->device));
+    CM_DROP(hipStreamSynchronize(s->ctx->stream));
     ilu0_release(s);
     pb_free(&s->pb);
     sell_free(&s->sell);
@@ -286,7 +288,7 @@ extern "C" int cudamat_solver_destroy(cudamat_solver *s)
     for (hipEvent_t e : s->ev_p1)
         if (e) CM_DROP(hipEventDestroy(e));
     for (hipStream_t q : s->part_stream)
-        if (q) { hipStreamSynchronize(q); CM_DROP(hipStreamDestroy(q)); }
+        if (q) { CM_DROP(hipStreamSynchronize(q)); CM_DROP(hipStreamDestroy(q)); }
     delete s;
     return CUDAMAT_OK;
 }
@@ -301,7 +303,7 @@ extern "C" int cudamat_solver_set_shift(cudamat_solver *s, const double *d)
 extern "C" int cudamat_solver_set_comm(cudamat_solver *s, const cudamat_comm *comm)
 {
     CM_ARG(s, "solver is NULL");
-    hipStreamSynchronize(s->ctx->stream);
+    CM_HIP(hipStreamSynchronize(s->ctx->stream));
     free_work(s);
     pb_free(&s->pb);
     sell_free(&s->sell);
@@ -353,8 +355,8 @@ namespace cm {
 static hipEvent_t comm_event(cudamat_solver *s)
 {
     if (s->comm_used == s->comm_ev.size()) {
-        hipEvent_t e;
-        hipEventCreate(&e);
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) s->prof_failed = true;
         s->comm_ev.push_back(e);
     }
     return s->comm_ev[s->comm_used++];
@@ -363,11 +365,11 @@ void comm_mark_begin(cudamat_solver *s, int kind, hipStream_t st)
 {
     if (!s->profiling) return;
     s->comm_kind.push_back(kind);
-    hipEventRecord(comm_event(s), st);
+    if (hipEventRecord(comm_event(s), st) != hipSuccess) s->prof_failed = true;
 }
 void comm_mark_end(cudamat_solver *s, hipStream_t st)
 {
-    if (s->profiling) hipEventRecord(comm_event(s), st);
+    if (s->profiling && hipEventRecord(comm_event(s), st) != hipSuccess) s->prof_failed = true;
 }
 
 // y = (A + diag d) x with x a LOCAL n_pad-long work vector (pad zero); gathers first
@@ -502,7 +504,7 @@ static int col_span_bytes(cudamat_solver *s, double *out)
     *out = 0.0;
     hipStream_t st = s->ctx->stream;
     unsigned long long *d = (unsigned long long *)s->ctx->scratch, h[2] = {0ULL, 0ULL};
-    hipMemsetAsync(d, 0, sizeof(h), st);
+    CM_HIP(hipMemsetAsync(d, 0, sizeof(h), st));
     const int samples = s->n < 4096 ? s->n : 4096;
     hipLaunchKernelGGL(k_col_span, dim3((samples + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s->n, s->rp, s->ci, samples, d, (int *)(d + 1));
     hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
@@ -561,8 +563,9 @@ int ensure_spmv_mode(cudamat_solver *s)
     if (s->spmv_mode >= 0) return CUDAMAT_OK;
     Range range_mode("cudamat: SpMV form (matrix copies, tuning)");
     const double t0 = now_s();
-    const int rc = ensure_spmv_mode_inner(s);
-    hipStreamSynchronize(s->ctx->stream);
+    int rc = ensure_spmv_mode_inner(s);
+    const int rc_sync = CM_RC(hipStreamSynchronize(s->ctx->stream));
+    if (!rc) rc = rc_sync;
     s->t_spmv_setup = now_s() - t0;
     if (s->ctx->cfg.verbose)
         fprintf(stderr, "[cudamat] SpMV form %d chosen in %.3f ms (blocked copy %.3f ms, timing %.3f ms)\n", s->spmv_mode,
@@ -648,9 +651,9 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
     const LoopArgs la_none{nullptr, nullptr, 0, 0, 0};
     const ScalarSrc nosrc{nullptr, 0, 1};
     const double *xin = s->sharded ? s->gather : s->p;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    CM_HIP(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { CM_DROP(hipEventDestroy(e0)); return fail_hip(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__); }
     float ms[4] = {0.f, 0.f, 0.f, 0.f};
     int rc = CUDAMAT_OK;
     const double t_timing0 = now_s();
@@ -661,16 +664,19 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
         a.alpha = 1.0; a.beta = 0.0; a.y = s->v; a.dot = 0; a.loop = la_none; a.check = CHECK_NONE; a.half = nosrc;
         a.pb_strict = cfg.pb_strict;
         for (int rep = 0; rep < 3 && rc == CUDAMAT_OK; rep++) {
-            if (rep == 1) hipEventRecord(e0, st);
+            if (rep == 1) rc = CM_RC(hipEventRecord(e0, st));
+            if (rc) break;
             rc = mode == 1 ? launch_spmv_pb(st, s->pb, a) : mode == 2 ? launch_spmv_sell(st, s->sell, a) :
                  mode == 3 ? launch_spmv_pat(st, s->pat, a) : launch_spmv(st, s->plan, a);
         }
-        hipEventRecord(e1, st);
-        hipEventSynchronize(e1);
-        hipEventElapsedTime(&ms[mode], e0, e1);
+        // (a candidate that cannot be timed must not win by its 0 ms: the error ends the selection)
+        if (!rc) rc = CM_RC(hipEventRecord(e1, st));
+        if (!rc) rc = CM_RC(hipEventSynchronize(e1));
+        if (!rc) rc = CM_RC(hipEventElapsedTime(&ms[mode], e0, e1));
     }
     CM_DROP(hipEventDestroy(e0));
     CM_DROP(hipEventDestroy(e1));
+    CM_TRY(rc);
     s->t_spmv_timing = now_s() - t_timing0;
     CM_HIP(hipMemsetAsync(s->v, 0, sizeof(double) * (size_t)(s->n_pad > 0 ? s->n_pad : 1), st));
     s->ms_csr = ms[0] / 2;
@@ -916,8 +922,8 @@ namespace cm {
 hipEvent_t prof_event(cudamat_solver *s, size_t i)
 {
     while (s->prof_ev.size() <= i) {
-        hipEvent_t e;
-        hipEventCreate(&e);
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) s->prof_failed = true;
         s->prof_ev.push_back(e);
     }
     return s->prof_ev[i];

@@ -399,7 +399,7 @@ int plan_spmv_compress(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz
             hipMalloc((void **)&plan->c_len8, (size_t)n_rows) != hipSuccess ||
             hipMalloc((void **)&plan->c_tile_base, sizeof(int) * (ntiles + 1)) != hipSuccess ||
             hipMalloc((void **)&flags, sizeof(int)) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
-        hipMemsetAsync(flags, 0, sizeof(int), s);
+        if ((rc = CM_RC(hipMemsetAsync(flags, 0, sizeof(int), s)))) break;
         const long long threads = ((long long)n_rows + 1) * 8;
         hipLaunchKernelGGL(k_stream_compress, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, R,
                            rp, ci, plan->c_off16, plan->c_len8, plan->c_tile_base, flags);
@@ -495,8 +495,8 @@ int plan_spmv_align(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, c
         if (total < nnz || (int64_t)total > nnz + 64LL * ntiles) { rc = CUDAMAT_ERR_HIP; break; }
         if (hipMalloc((void **)&plan->a_off16, sizeof(short) * (size_t)total + 256) != hipSuccess ||
             hipMalloc((void **)&plan->a_val, sizeof(double) * (size_t)total + 256) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
-        hipMemsetAsync(plan->a_off16, 0, sizeof(short) * (size_t)total + 256, s);      // idle slots: offset 0, value 0
-        hipMemsetAsync(plan->a_val, 0, sizeof(double) * (size_t)total + 256, s);
+        if ((rc = CM_RC(hipMemsetAsync(plan->a_off16, 0, sizeof(short) * (size_t)total + 256, s)))) break;      // idle slots: offset 0, value 0
+        if ((rc = CM_RC(hipMemsetAsync(plan->a_val, 0, sizeof(double) * (size_t)total + 256, s)))) break;
         const long long threads = (long long)n_rows * 8;
         hipLaunchKernelGGL(k_tile_align_fill, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, R, rp,
                            plan->c_off16, val, plan->a_base, plan->a_off16, plan->a_val);
@@ -529,8 +529,8 @@ int plan_spmv_dict(hipStream_t s, int n_rows, int64_t nnz, const int *rp, const 
         if (total < nnz || (int64_t)total > nnz + 8LL * ntiles) { rc = CUDAMAT_ERR_HIP; break; }
         if (hipMalloc((void **)&plan->d_off16, sizeof(short) * (size_t)total + 16) != hipSuccess ||
             hipMalloc((void **)&plan->d_val8, (size_t)total + 16) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
-        hipMemsetAsync(plan->d_off16, 0, sizeof(short) * (size_t)total + 16, s);      // padding: offset 0, value index 0
-        hipMemsetAsync(plan->d_val8, 0, (size_t)total + 16, s);
+        if ((rc = CM_RC(hipMemsetAsync(plan->d_off16, 0, sizeof(short) * (size_t)total + 16, s)))) break;      // padding: offset 0, value index 0
+        if ((rc = CM_RC(hipMemsetAsync(plan->d_val8, 0, (size_t)total + 16, s)))) break;
         const long long threads = (long long)n_rows * 8;
         hipLaunchKernelGGL(k_tile_pad_fill, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, R, rp,
                            plan->c_off16, vidx, plan->d_pbase, plan->d_off16, plan->d_val8);
@@ -791,8 +791,8 @@ static int plan_spmv_tiles(hipStream_t s, int n_rows, int64_t nnz, const int *rp
             hipMalloc((void **)&plan->tile_heads, sizeof(double) * (size_t)ntiles) != hipSuccess ||
             hipMalloc((void **)&plan->tile_tails, sizeof(double) * (size_t)ntiles) != hipSuccess ||
             hipMalloc((void **)&flag, sizeof(int) * (size_t)ntiles) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; break; }
-        hipMemsetAsync(plan->tile_heads, 0, sizeof(double) * (size_t)ntiles, s);
-        hipMemsetAsync(plan->tile_tails, 0, sizeof(double) * (size_t)ntiles, s);
+        if ((rc = CM_RC(hipMemsetAsync(plan->tile_heads, 0, sizeof(double) * (size_t)ntiles, s)))) break;
+        if ((rc = CM_RC(hipMemsetAsync(plan->tile_tails, 0, sizeof(double) * (size_t)ntiles, s)))) break;
         hipLaunchKernelGGL(k_tiles_rows, dim3((unsigned)((ntiles + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp,
                            ntiles, plan->tile_S);
         hipLaunchKernelGGL(k_tiles_span, dim3((unsigned)((ntiles + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp,
@@ -851,12 +851,13 @@ static int plan_spmv_balance(hipStream_t s, const Config &cfg, int n_rows, int64
         if (nnz < 65536) return CUDAMAT_OK;
         unsigned long long *d = (unsigned long long *)scratch, h = 0;
         if (!scratch) CM_HIP(hipMalloc((void **)&d, sizeof(h)));
-        hipMemsetAsync(d, 0, sizeof(h), s);
+        hipError_t e = hipMemsetAsync(d, 0, sizeof(h), s);
         const long long groups = ((long long)n_rows + (64 / plan->lanes) - 1) / (64 / plan->lanes);
         hipLaunchKernelGGL(k_lane_cost, dim3((unsigned)((groups + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp,
                            plan->lanes, d);
-        hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s);
-        const hipError_t e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (!scratch) CM_DROP(hipFree(d));
         if (e != hipSuccess) return fail_hip(e, "lane cost", __FILE__, __LINE__);
         plan->lane_cost = (double)h * 64.0 / (double)nnz;
@@ -877,11 +878,12 @@ int plan_spmv_refine(hipStream_t s, const Config &cfg, int n_rows, int64_t nnz, 
     if (mean > 12.0) return plan_spmv_balance(s, cfg, n_rows, nnz, rp, plan, scratch);
     int *d = (int *)scratch, h[3] = {0, 0, 0};
     if (!scratch) CM_HIP(hipMalloc((void **)&d, 3 * sizeof(int)));
-    hipMemsetAsync(d, 0, 3 * sizeof(int), s);
+    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(int), s);
     const long long tiles = ((long long)n_rows + 63) / 64;
     hipLaunchKernelGGL(k_tile_nnz_max, dim3((unsigned)((tiles + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n_rows, rp, d);
-    hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s);
-    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (!scratch) CM_DROP(hipFree(d));
     if (e != hipSuccess) return fail_hip(e, "tile scan", __FILE__, __LINE__);
     int R = 0;

@@ -197,9 +197,9 @@ int pat_build(hipStream_t st, int n, int64_t nnz, const int *rp, const int *ci, 
         if ((rc = dalloc(&table, (size_t)kPatSlots))) break;
         if ((rc = dalloc(&rep, (size_t)kPatSlots))) break;
         if ((rc = dalloc(&flags, 2))) break;
-        hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) * kPatSlots, st);
-        hipMemsetAsync(rep, 0x7F, sizeof(int) * kPatSlots, st);
-        hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+        if ((rc = CM_RC(hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) * kPatSlots, st)))) break;
+        if ((rc = CM_RC(hipMemsetAsync(rep, 0x7F, sizeof(int) * kPatSlots, st)))) break;
+        if ((rc = CM_RC(hipMemsetAsync(flags, 0, 2 * sizeof(int), st)))) break;
         int grid = (int)(((long long)n + kBlock - 1) / kBlock);
         if (grid > 8192) grid = 8192;
         hipLaunchKernelGGL(k_pat_probe, dim3(grid), dim3(kBlock), 0, st, n, rp, ci, table, rep, flags);
@@ -251,7 +251,7 @@ int pat_build(hipStream_t st, int n, int64_t nnz, const int *rp, const int *ci, 
             break;
         }
         if ((rc = dalloc(&p.pid, (size_t)padded))) break;
-        hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+        if ((rc = CM_RC(hipMemsetAsync(flags, 0, 2 * sizeof(int), st)))) break;
         hipLaunchKernelGGL(k_pat_assign, dim3(grid), dim3(kBlock), 0, st, n, (int)padded, p.npat, empty_id, rp, ci, keys_dev, p.tab, p.pid, flags);
         if (hipGetLastError() != hipSuccess ||
             hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -94,8 +94,8 @@ int valdict_sample_overflows(hipStream_t st, int64_t count, const double *val, v
     unsigned long long *table = (unsigned long long *)scratch;
     int *flags = (int *)((char *)scratch + sizeof(unsigned long long) * kTableSlots);
     int h[2] = {0, 0};
-    hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) * kTableSlots, st);
-    hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+    CM_HIP(hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) * kTableSlots, st));
+    CM_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int), st));
     int64_t g = (count + kBlock - 1) / kBlock;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(k_dict_probe, dim3((unsigned)g), dim3(kBlock), 0, st, (int64_t)0, count, val, table, flags);
@@ -126,8 +126,8 @@ int valdict_build(hipStream_t st, const Config &cfg, int64_t nnz, const double *
     do {
         if (hipMalloc((void **)&table, sizeof(unsigned long long) * kTableSlots) != hipSuccess ||
             hipMalloc((void **)&flags, 2 * sizeof(int)) != hipSuccess) { rc = CUDAMAT_ERR_NOMEM; set_error("value dictionary: out of memory"); break; }
-        hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) * kTableSlots, st);
-        hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+        if ((rc = CM_RC(hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) * kTableSlots, st)))) break;
+        if ((rc = CM_RC(hipMemsetAsync(flags, 0, 2 * sizeof(int), st)))) break;
         // a sample first: arbitrary values overflow the table within the first few thousand entries
         const int64_t sample = nnz < (1 << 20) ? nnz : (1 << 20);
         const int64_t pieces[2][2] = {{0, sample}, {sample, nnz - sample}};
@@ -153,7 +153,7 @@ int valdict_build(hipStream_t st, const Config &cfg, int64_t nnz, const double *
         if (hipMalloc((void **)&v.dict, sizeof(double) * kDictMax) != hipSuccess ||
             hipMalloc((void **)&v.idx, (size_t)nnz + 16) != hipSuccess) { valdict_free(&v); break; }      // no memory: no dictionary
         if (hipMemcpy(v.dict, dict.data(), sizeof(double) * kDictMax, hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
-        hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+        if ((rc = CM_RC(hipMemsetAsync(flags, 0, 2 * sizeof(int), st)))) break;
         int64_t g = (nnz + kBlock - 1) / kBlock;
         if (g > 16384) g = 16384;
         hipLaunchKernelGGL(k_dict_index, dim3((unsigned)g), dim3(kBlock), 0, st, nnz, val, v.dict, (int)keys.size(), v.idx, flags);

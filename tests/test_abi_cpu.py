@@ -206,3 +206,27 @@ def test_option_values_are_validated_without_a_device():
     for name, value in bad:
         assert L.cudamat_option_check(name.encode(), value.encode()) != 0, (name, value)
         assert name.replace("CUDAMAT_", "") in L.cudamat_last_error().decode() or "unknown option" in L.cudamat_last_error().decode()
+
+
+def test_rejected_and_unknown_environment_switches_are_reported_once_on_stderr():
+    """csrc/config.cpp config_from_env: an A/B script that passes switches through the environment must not measure the
+    default configuration unnoticed -- a value that fails validation, or a CUDAMAT_* name that is no switch (removed ones
+    included), gets one stderr line per process, VERBOSE or not; bench.py's own CUDAMAT_BENCH_* are left alone.
+    cudamat_solve reads the environment before it looks for a device, so this runs without a GPU."""
+    import subprocess
+    import sys
+    code = ("import numpy as np, cuda_mat_amd as cm\n"
+            "from cuda_mat_amd import api\n"
+            "for _ in range(2):\n"
+            "    try:\n"
+            "        api.bicgstab(2, 2, np.ones(2), np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32), np.ones(2), 5, 1e-8)\n"
+            "    except cm.CudamatError as e:\n"
+            "        print('rc', e.code)\n")
+    env = dict(os.environ, CUDAMAT_TRSV_GROUPS="99999", CUDAMAT_PB_DEPTH="12", CUDAMAT_HOST_THREADS="4", CUDAMAT_SPMV_MODE="pb",
+               CUDAMAT_BENCH_FORMS="rccl:1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    err = r.stderr
+    assert err.count('CUDAMAT_TRSV_GROUPS="99999" is not an accepted value and was IGNORED') == 1, err
+    assert err.count('CUDAMAT_PB_DEPTH="12" is not an accepted value and was IGNORED') == 1, err
+    assert err.count("CUDAMAT_HOST_THREADS names no switch of this library and was IGNORED") == 1, err
+    assert "CUDAMAT_SPMV_MODE" not in err and "CUDAMAT_BENCH_FORMS" not in err, err
