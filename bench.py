@@ -74,6 +74,10 @@ def parse():
                          "twice (one GPU only; the second call reuses the first one's plan)")
     ap.add_argument("--cpu-iters-full", type=int, default=2, help="iterations of the CPU baseline on the full matrix, per OpenMP team size")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "off"],
+                    help="auto: after the judged region of the default (headline) invocation on one GPU, also run BASELINE.json's "
+                         "other single-GPU configurations -- C3 poisson5, C5 rand50 + ILU(0), C2 mat10000 -- as side sections "
+                         "of the same JSON line (`other_configs`)")
     return ap.parse_args()
 
 
@@ -314,7 +318,8 @@ def cpu_baseline(args):
     del A, b, xs
     i_best = teams.index(t_best)
     return {
-        "value": rate[t_best], "unit": "iter/s", "cores": t_best, "kind": "port",
+        "value": rate[t_best], "unit": "iter/s", "cores": t_best, "cores_are": "OpenMP threads used (not physical cores)",
+        "cpus_granted": cpu_quota() or HOST_CPUS, "kind": "port",
         "sample": "oracle BiCG restatement of bicstab_omp (2 SpMV/iter; SpMV+dot OpenMP, vector loops serial as in the "
                   "reference): %d iterations of its loop (bicstab.cpp:146-182) on the FULL %d-row x %d nnz/row matrix, "
                   "built in host memory by the same generator; %d threads = the team that runs THIS LOOP fastest (sweep below)"
@@ -395,12 +400,49 @@ def main():
     os.dup2(2, 1)
     try:
         out = run_bench(args)
+        headline = (args.workload == "rand50" and args.rows == 10_000_000 and args.per_row == 50 and args.precond == "none"
+                    and args.loop == "pbicgstab")
+        if out is not None and out.get("n_gpus") == 1 and headline and args.other_configs != "off":
+            out["other_configs"] = other_configs(args)
     finally:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+# keys of a full line that a side section keeps (the rest is either the headline's business or repeats the section's name)
+SECTION_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "spmv_gbs", "spmv_form", "value_dictionary",
+                "trsv_ms_per_apply", "trsv_roofline", "trsv_traffic", "levels", "setup_s", "drop_in")
+OTHER_CONFIGS = (      # BASELINE.json configs[2], [4], [1]: name, argument overrides
+    ("poisson5", {"workload": "poisson5", "precond": "none", "steps": 200, "warmup": 10}),
+    ("rand50_ilu0", {"workload": "rand50", "precond": "ilu0", "steps": 50, "warmup": 5}),
+    ("mat10000", {"workload": "mat10000", "precond": "none", "steps": 2000, "warmup": 200}),
+)
+
+
+def other_configs(args):
+    """BASELINE.json's other single-GPU configurations, each run like its own `python bench.py --workload ... --precond ...`
+    (generated in HBM, gated by a real solve, warmed up, timed between synchronisations, SpMV launches timed by HIP events)
+    AFTER the judged region and outside it: the reference prints its phase times for whatever it is given
+    (example.cpp:364-365, pbicgstab.cu:349,362); the driver's one bench run times one configuration, these are the others."""
+    import copy
+    sections = {}
+    for name, over in OTHER_CONFIGS:
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.cpu_baseline, a.other_configs, a.loop = "off", "off", "pbicgstab"
+        t0 = time.perf_counter()
+        try:
+            full = run_bench(a)
+            sec = {k: full[k] for k in SECTION_KEYS if k in full}
+        except (Exception, SystemExit) as e:  # noqa: BLE001 - a side section must never take the headline down
+            sec = {"error": "%s: %s" % (type(e).__name__, e)}
+        sec["section_seconds"] = time.perf_counter() - t0
+        sections[name] = sec
+    return sections
 
 
 def run_bench(args):
@@ -464,9 +506,11 @@ def run_bench(args):
     # The judged numbers are measured on fp64 VALUES (what a matrix of arbitrary coefficients has): the library's value
     # dictionary (8-bit indices when a matrix holds <= 256 distinct values, as SURVEY 8d's generator happens to produce)
     # is switched off for the timed region and reported as a side figure (`with_value_dictionary`).
-    forced_fp64 = "CUDAMAT_VALUE_DICT" not in os.environ and os.environ.get("CUDAMAT_BENCH_HEADLINE", "fp64") != "dict"
+    forced_fp64 = (("CUDAMAT_VALUE_DICT" not in os.environ or os.environ.get("CUDAMAT_BENCH_FORCED_FP64") == "1")
+                   and os.environ.get("CUDAMAT_BENCH_HEADLINE", "fp64") != "dict")
     if forced_fp64:
         os.environ["CUDAMAT_VALUE_DICT"] = "0"
+        os.environ["CUDAMAT_BENCH_FORCED_FP64"] = "1"        # (a later section of the same process: the bench set it, not the user)
 
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
@@ -656,7 +700,7 @@ def run_bench(args):
         # example.cpp:364-365): ONE call of cudamat_solve() on HOST arrays -- upload over PCIe, analysis, loop, download --
         # and a second call with the same matrix, which reuses the first one's plan.  Outside the judged region.
         drop_in = None
-        if world == 1 and args.drop_in != "off" and precond == cm.PRECOND_NONE and not latency_bound:
+        if world == 1 and args.drop_in != "off" and precond in (cm.PRECOND_NONE, cm.PRECOND_ILU0) and not latency_bound:
             try:
                 import numpy as np
                 from cuda_mat_amd import api as cm_api
@@ -694,15 +738,17 @@ def run_bench(args):
                 calls = []
                 for _ in range(2):
                     t1 = time.perf_counter()
-                    xh, sth = cm_api._solve(n, nz, va_h, rp_h, ci_h, None, None, b_h, cm.PRECOND_NONE, cm.LOOP_PBICGSTAB, 200, 1e-8, False)
+                    xh, sth = cm_api._solve(n, nz, va_h, rp_h, ci_h, None, None, b_h, precond, cm.LOOP_PBICGSTAB, 200, 1e-8, False)
                     wall = time.perf_counter() - t1
                     calls.append({"end_to_end_s": wall, "upload_s": sth.t_upload, "setup_s": sth.t_setup, "tune_s": sth.t_tune,
+                                  "analysis_s": sth.t_analysis, "factor_s": sth.t_factor,
                                   "loop_s": sth.t_solve, "library_total_s": sth.t_total, "iters": sth.iters,
                                   "converged": bool(sth.converged), "spmv_mode": sth.spmv_mode, "plan_reused": sth.plan_reused,
                                   "max_abs_err": float(np.abs(xh - xs.cpu().numpy()).max())})
                 cm.lib().cudamat_plan_cache_clear()
-                drop_in = {"call": "cudamat_solve() on host CSR arrays, tol 1e-8 (= bicgstab(), pbicgstab.h:113; the reference's "
-                                   "'total delta time' vs 'algorithm delta time', example.cpp:364-365)",
+                drop_in = {"call": "cudamat_solve() on host CSR arrays, tol 1e-8 (= %s; the reference's "
+                                   "'total delta time' vs 'algorithm delta time', example.cpp:364-365)"
+                                   % ("bicgstab_lu_precond(), pbicgstab.h:119: upload, level analysis, ILU(0), loop" if precond else "bicgstab(), pbicgstab.h:113"),
                            "host_bytes_uploaded": 12.0 * nz + 4.0 * (n + 1) + 8.0 * n,
                            "process_state": "after one throw-away cudamat_solve() on a 4096-row system (start-up costs of the "
                                             "process are not part of a call; scripts/upload_probe.py measures them apart)",
@@ -717,6 +763,10 @@ def run_bench(args):
     b_spmv = 12.0 * nnz + 4.0 * (nloc + 1) + 8.0 * n + 8.0 * nloc
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     vec_bytes = 144.0 * nloc
+    # B_iter(none) = 2 B_spmv + 144 n;  B_iter(ilu0) = B_iter(none) + 2 (12 nnz + 8 (n + 1) + 32 n): the two
+    # applications of L^-1 U^-1 per iteration (factor entries + row pointers of both factors + the vectors they stream)
+    b_precond = 2.0 * (12.0 * nnz + 8.0 * (nloc + 1) + 32.0 * nloc) if precond else 0.0
+    b_iter = 2 * b_spmv + vec_bytes + b_precond
     blocked = solver.spmv_mode() == 1
     kernel = solver.spmv_kernel() + (" (one SpMV = the pair)" if blocked else "")
     # small systems: the SpMV rides inside a fused kernel (cudamat_stats.loop_form: 1 = the vector updates folded into the two
@@ -732,10 +782,12 @@ def run_bench(args):
     # FETCH_SIZE doubled per the gfx950 calibration); only for the exact workload they were taken on
     traffic, traffic_src, traffic_parts = None, None, None
     prof_dir = None
-    if world == 1 and args.rows == 10_000_000 and precond == cm.PRECOND_NONE:
+    loop_tag = ""
+    if world == 1 and args.rows == 10_000_000 and precond in (cm.PRECOND_NONE, cm.PRECOND_ILU0):
         if args.workload == "rand50" and args.per_row == 50:
-            prof_dir = "*rand50"
-        elif args.workload == "poisson5" and args.nx == 4000:
+            prof_dir = "*ilu0" if precond else "*rand50"
+            loop_tag = "[SpMV of the loop]" if precond else ""       # (scripts/summarize_profiles.py splits the blocked kernels of a C5 trace)
+        elif args.workload == "poisson5" and args.nx == 4000 and not precond:
             prof_dir = "*poisson5"
     if prof_dir:
         import glob
@@ -747,8 +799,8 @@ def run_bench(args):
                 want = [p1, "cm::k_pb_phase2<"]
             else:
                 want = ["cm::" + solver.spmv_kernel()]
-            got = [next((v for k, v in pm.items() if (k == w or (w.endswith("<") and k.startswith(w))) and isinstance(v, dict)
-                         and "hbm_bytes_per_launch_corrected" in v), None) for w in want]
+            got = [next((v for k, v in pm.items() if (k == w + loop_tag or (w.endswith("<") and k.startswith(w) and k.endswith(loop_tag or ">")))
+                         and isinstance(v, dict) and "hbm_bytes_per_launch_corrected" in v), None) for w in want]
             if all(g is not None for g in got):
                 traffic = sum(g["hbm_bytes_per_launch_corrected"] for g in got)
                 traffic_parts = [g["hbm_bytes_per_launch_corrected"] for g in got]
@@ -779,8 +831,9 @@ def run_bench(args):
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_spmv, "avg_launch_ms": spmv_ms,
                          "launches_timed": n_spmv,
-                         "iteration_bytes": 2 * b_spmv + vec_bytes,
-                         "iteration_frac": (2 * b_spmv + vec_bytes) * (args.steps / dt) / 1e9 / HBM_PEAK_GBS},
+                         "iteration_bytes": b_iter,
+                         "iteration_bytes_formula": "2 B_spmv + 144 n" + (" + 2 (12 nnz + 8 (n + 1) + 32 n)  [SURVEY 8d, B_iter(ilu0)]" if precond else "  [SURVEY 8d, B_iter(none)]"),
+                         "iteration_frac": b_iter * (args.steps / dt) / 1e9 / HBM_PEAK_GBS},
             "spmv_gbs": achieved, "spmv_form": {1: "blocked two-phase", 2: "SELL-C-sigma", 3: "row-pattern dictionary"}.get(
                 solver.spmv_mode(), "csr (lanes-per-row / stream tiles)"),
             # 0: the timed kernels read fp64 values (8 B per entry).  The bench switches the library's value dictionary off
@@ -860,10 +913,23 @@ def run_bench(args):
             out["levels"] = [st.n_levels_l, st.n_levels_u]
             # one-off setup (outside the timed region): level analysis of L and U; ILU(0) + factor layout + far/near split
             out["setup_s"] = {"analysis": st.t_analysis, "factor": st.t_factor}
+        if traffic is not None and spmv_ms > 0:
+            # what the fabric really carried per launch (PMC), as a rate: the figure to hold against a stream ceiling
+            out["roofline"]["moved_gbs"] = traffic / (spmv_ms * 1e-3) / 1e9
+            out["roofline"]["moved_over_algorithmic"] = traffic / b_spmv
         if world == 1 and not latency_bound:
             ceil = hbm_ceiling(ctx)
             out["roofline"]["measured_stream_ceiling"] = ceil
             out["roofline"]["frac_of_measured_ceiling"] = achieved / ceil["gbs"]
+            if solver.spmv_mode() == 3:
+                # SURVEY 8d's B_spmv prices 4 B of column index per entry; the row-pattern form fetches none (a row's columns come
+                # from a 16 KB table through one byte per row), so it MOVES fewer bytes than B_spmv and `achieved` (algorithmic
+                # bytes / time) can exceed a stream ceiling measured in moved bytes: compare `moved_gbs` with the ceiling instead
+                out["roofline"]["note_algorithmic_vs_moved"] = (
+                    "row-pattern SpMV: no column index is fetched, so moved bytes (%s) < algorithmic bytes (%.3g); "
+                    "frac_of_measured_ceiling > 1 is the formula's 4 B/entry of indices that never travel -- "
+                    "moved_gbs / ceiling = %s" % ("%.3g per launch, PMC" % traffic if traffic else "see profiles/*poisson5",
+                                                  b_spmv, "%.2f" % (traffic / (spmv_ms * 1e-3) / 1e9 / ceil["read_gbs"]) if traffic and spmv_ms > 0 else "n/a"))
             if blocked and traffic_parts is not None:
                 # what this SpMV's own traffic would take at the two measured ceilings: phase 1 is a read/write mix
                 # (10 B read : 8 B written per entry), phase 2 reads only

@@ -107,4 +107,7 @@ struct cudamat_ctx {
     // point runs them while an upload is in flight on another stream (dropin.hip).  One user at a time: the context's stream.
     void *scratch = nullptr;
     cm::Config cfg;            // the switches everything running on this context reads (config.h)
+    // does this device's LDS serve equal addresses of one ds_add_f64 in lane order?  (-1 not probed yet, 1 yes, 0 no:
+    // spmv_pb.hip pb_strict_for; the blocked SpMV's default phase 2 is bit-exact only when it does)
+    int lds_lane_order = -1;
 };

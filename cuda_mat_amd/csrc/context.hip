@@ -158,6 +158,7 @@ extern "C" int cudamat_ctx_set_option(cudamat_ctx *ctx, const char *name, const 
 {
     CM_ARG(ctx && name && value, "null pointer");
     if (!config_set(ctx->cfg, name, value)) return CUDAMAT_ERR_ARG;
+    ctx->lds_lane_order = -1;          // (PB_PROBE_FAIL may have changed: probe again at the next blocked SpMV)
     if (ctx->cfg.roctx) range_enable();
     return CUDAMAT_OK;
 }
@@ -167,6 +168,7 @@ extern "C" int cudamat_ctx_reset_options(cudamat_ctx *ctx)
 {
     CM_ARG(ctx, "ctx is NULL");
     ctx->cfg = config_from_env();
+    ctx->lds_lane_order = -1;
     if (ctx->cfg.roctx) range_enable();
     return CUDAMAT_OK;
 }

@@ -1262,7 +1262,9 @@ int ilu0_setup(cudamat_solver *s, bool block)
             pl->L.lds = lds_on && !pl->L.hybrid && widest(s->L) <= 512;
             pl->U.lds = lds_on && !pl->U.hybrid && widest(s->U) <= 512;
             if (cfg.trsv_spin_limit) pl->L.spin_limit = pl->U.spin_limit = cfg.trsv_spin_limit;
-            pl->L.pb_strict = pl->U.pb_strict = cfg.pb_strict;
+            int strict = 0;
+            if ((rc = pb_strict_for(s->ctx, &strict))) break;
+            pl->L.pb_strict = pl->U.pb_strict = strict;
             // Resident workgroups per CU of the dependency-driven launch.  Every waiting row polls memory, and pollers
             // slow the very hand-offs they wait for: with little work per level the chain of hand-offs is the whole
             // cost and FEWER resident workgroups are faster (Poisson 4000x2500, 5 K entries per level: 27.6 ms per

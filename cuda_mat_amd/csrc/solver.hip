@@ -419,7 +419,8 @@ int spmv_local(cudamat_solver *s, const double *x_local, double *y, int dot, con
     a.loop = la;
     a.check = check;
     a.half = half;
-    a.pb_strict = s->ctx->cfg.pb_strict;
+    a.pb_strict = 0;
+    if (s->spmv_mode == 1) CM_TRY(pb_strict_for(s->ctx, &a.pb_strict));
     if (overlapped) {
         // The gather in pieces on the communicator's stream, phase 1 piece by piece behind it:
         //   comm stream  :  [wait x ready] piece 0 | piece 1 | ...
@@ -662,7 +663,8 @@ static int ensure_spmv_mode_inner(cudamat_solver *s)
         SpmvArgs a{};
         a.n = s->n; a.rp = s->rp; a.ci = s->ci; a.val = s->val; a.x = xin; a.d = nullptr; a.xd = s->p;
         a.alpha = 1.0; a.beta = 0.0; a.y = s->v; a.dot = 0; a.loop = la_none; a.check = CHECK_NONE; a.half = nosrc;
-        a.pb_strict = cfg.pb_strict;
+        a.pb_strict = 0;
+        if (mode == 1) CM_TRY(pb_strict_for(s->ctx, &a.pb_strict));
         for (int rep = 0; rep < 3 && rc == CUDAMAT_OK; rep++) {
             if (rep == 1) rc = CM_RC(hipEventRecord(e0, st));
             if (rc) break;
@@ -886,7 +888,11 @@ extern "C" int cudamat_solver_spmv_kernel(cudamat_solver *s, char *name, int cap
     CM_TRY(ensure_work(s));
     CM_TRY(ensure_spmv_mode(s));
     const SpmvPlan &p = s->plan;
-    if (s->spmv_mode == 1) snprintf(name, (size_t)cap, "%s + k_pb_phase2", s->pb.pvi ? "k_pb_phase1_dict" : "k_pb_phase1");
+    if (s->spmv_mode == 1) {
+        int strict = 0;
+        CM_TRY(pb_strict_for(s->ctx, &strict));
+        snprintf(name, (size_t)cap, "%s + k_pb_phase2%s", s->pb.pvi ? "k_pb_phase1_dict" : "k_pb_phase1", strict ? " (architected order)" : "");
+    }
     else if (s->spmv_mode == 2) snprintf(name, (size_t)cap, "k_spmv_sell");
     else if (s->spmv_mode == 3 && s->pat.vidx) snprintf(name, (size_t)cap, "k_spmv_pat_d<%d>", s->pat.vword / 8);
     else if (s->spmv_mode == 3) snprintf(name, (size_t)cap, "k_spmv_pat<%d>", s->pat.W <= 8 ? 8 : 16);

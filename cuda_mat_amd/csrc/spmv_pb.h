@@ -80,6 +80,9 @@ bool pb_candidate(hipStream_t st, int n, int64_t n_cols, int64_t nnz, const int 
 int pb_build(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
              const double *val, PbPlan *out, const PbCols *cols = nullptr, const ValDict *vd = nullptr);
 void pb_free(PbPlan *p);
+// SpmvArgs::pb_strict for launches on this context: the option PB_STRICT, or 1 when the device's LDS does NOT serve equal
+// addresses of one ds_add_f64 in lane order (probed once per context by a one-wave kernel, ~30 us; see spmv_pb.hip)
+int pb_strict_for(cudamat_ctx *ctx, int *strict);
 // y = alpha*(A x + d.*xd) + beta*y with the same fused dot / prologue options as launch_spmv;
 // args.rp/ci/val are ignored (the plan holds the matrix)
 int launch_spmv_pb(hipStream_t st, const PbPlan &plan, const SpmvArgs &a);

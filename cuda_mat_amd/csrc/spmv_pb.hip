@@ -686,6 +686,68 @@ __device__ __forceinline__ void pb_seg_add(double *my, int r, double p, bool on,
         if (on && rank == q) unsafeAtomicAdd(&my[r], p);
 }
 
+// ---- run-time guard of the default form's assumption.  One wave, four address patterns (all lanes on one address; runs
+// of 8 adjacent lanes; lanes l and l + 32 -- two 32-lane segments in one instruction; l mod 4 -- 16-lane segments), four
+// value sets each: every address starts from a non-zero partial sum and receives its addends through ONE ds_add_f64
+// instruction; one lane per address then adds the same addends sequentially in lane order and compares the bits.  Addends
+// have full 52-bit mantissas around 1, so another order of service changes the rounding of some partial sum with
+// overwhelming probability (64 addresses x 16 rounds).  Any mismatch: the context uses the architected-order form.
+__global__ __launch_bounds__(64) void k_lds_order_probe(int *mismatch)
+{
+    __shared__ double acc[64], val[64], start[64];
+    const int lane = threadIdx.x;
+    unsigned long long z = 0x9E3779B97F4A7C15ULL * (unsigned long long)(lane + 1);
+    int bad = 0;
+    for (int pat = 0; pat < 4; pat++) {
+        const int addr = pat == 0 ? 0 : pat == 1 ? lane >> 3 : pat == 2 ? (lane & 31) : (lane & 3);
+        const int naddr = pat == 0 ? 1 : pat == 1 ? 8 : pat == 2 ? 32 : 4;
+        for (int rep = 0; rep < 4; rep++) {
+            z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;
+            const double v = 0.5 + (double)(z >> 11) * 0x1.0p-53;                  // [0.5, 1.5), all mantissa bits in play
+            const double c = 3.0 + (double)((z * 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53;
+            val[lane] = v;
+            start[lane] = c;
+            acc[lane] = c;
+            __syncthreads();
+            unsafeAtomicAdd(&acc[addr], v);                                        // the instruction under test
+            __syncthreads();
+            if (lane < naddr) {
+#pragma clang fp contract(off)
+                double e = start[lane];
+                for (int l = 0; l < 64; l++) {
+                    const int al = pat == 0 ? 0 : pat == 1 ? l >> 3 : pat == 2 ? (l & 31) : (l & 3);
+                    if (al == lane) e = e + val[l];
+                }
+                if (__double_as_longlong(e) != __double_as_longlong(acc[lane])) bad = 1;
+            }
+            __syncthreads();
+        }
+    }
+    if (bad) atomicOr(mismatch, 1);
+}
+
+int pb_strict_for(cudamat_ctx *ctx, int *strict)
+{
+    *strict = 1;
+    if (ctx->cfg.pb_strict) return CUDAMAT_OK;
+    if (ctx->lds_lane_order < 0) {
+        int *flag = (int *)ctx->scratch, h = 1;
+        CM_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_lds_order_probe, dim3(1), dim3(64), 0, ctx->stream, flag);
+        CM_HIP(hipGetLastError());
+        CM_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        CM_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->cfg.pb_probe_fail) h = 1;
+        ctx->lds_lane_order = h ? 0 : 1;
+        if (h || ctx->cfg.verbose)
+            fprintf(stderr, "[cudamat] LDS order probe: equal addresses of one ds_add_f64 are %s -> blocked SpMV phase 2 in its %s form\n",
+                    h ? (ctx->cfg.pb_probe_fail ? "reported NOT in lane order (PB_PROBE_FAIL)" : "NOT served in lane order")
+                      : "served in lane order", h ? "architected-order (PB_STRICT)" : "default");
+    }
+    *strict = ctx->lds_lane_order ? 0 : 1;
+    return CUDAMAT_OK;
+}
+
 // DEPTH: segment loads a wave issues before it consumes the first (4; 8 / 16 when few waves are resident: shards)
 template <int NW, int LPS, int DEPTH>
 __global__ __launch_bounds__(64 * NW) void k_pb_phase2(Pb2Args a)

@@ -88,3 +88,135 @@ def prefix(hg, ho, rtol):
         ok = np.isfinite(hg[:m]) & np.isfinite(ho[:m]) & (np.abs(hg[:m] - ho[:m]) <= rtol * np.abs(ho[:m]))
     w = np.nonzero(~ok)[0]
     return int(w[0]) if w.size else m
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The comparison rules of tests/test_gpu_nondominant.py (its docstring states them), as a function that RETURNS its
+# findings: the pytest cases assert that there are none, tests/soak.py prints them.
+EPS = np.finfo(np.float64).eps
+SELF_ITERS = 200                 # iterations of the perturbed oracle runs that measure the system's own amplification
+
+
+def noise_breakdown(trace):
+    """first iteration of an oracle.pbicgstab(want_trace=True) trace whose rho (pbicgstab.cu:81) or rw.v (:106) is below
+    4 eps of the sum of magnitudes it was summed from (not one significant bit left), or not finite, or t.t == 0"""
+    with np.errstate(invalid="ignore"):
+        bad = ((np.abs(trace[:, 0]) <= 4 * EPS * trace[:, 1]) | ~np.isfinite(trace[:, 0])
+               | (np.isfinite(trace[:, 3]) & (np.abs(trace[:, 2]) <= 4 * EPS * trace[:, 3])) | (trace[:, 6] == 0.0))
+    w = np.nonzero(bad)[0]
+    return int(w[0]) if w.size else None
+
+
+def oracle_run(O, A, b, loop, vm, maxit, tol):
+    """(x, stats, history without the unwritten tail) of the reference loop `loop` (0: pbicgstab.cu:45-154, 1: :581-754)"""
+    if loop == 0:
+        x, st, h = O.pbicgstab(A, b, vm=vm, maxit=maxit, tol=tol, want_hist=True)
+        return x, st, h[:2 * st.iters + st.half_exit]
+    ok, x, st, h = O.pbicgstab2(A, b, maxit=maxit, tol=tol, want_hist=True)
+    return x, st, h[:st.iters]
+
+
+def self_prefix(O, A, b, loop, vm, h0, tol):
+    """entries over which the oracle's history agrees (1e-6) with itself when b is changed by 1..3 ulp either way (the
+    shortest of the six: the length itself varies with the perturbation, example40 with ILU(0): 10, 4000, 10, 4)"""
+    cap = (2 if loop == 0 else 1) * SELF_ITERS
+    return min(prefix(oracle_run(O, A, b * (1.0 + k * EPS), loop, vm, SELF_ITERS, tol)[2][:cap], h0[:cap], 1e-6)
+               for k in (1, -1, 2, -2, 3, -3)), cap
+
+
+def true_res(O, A, b, x):
+    with np.errstate(invalid="ignore", over="ignore"):
+        return float(np.linalg.norm(b - O.spmv(A, x)))
+
+
+def iters_inside_oracle_spread(O, A, b, loop, vm, it_gpu, it_orc, maxit, tol):
+    """SURVEY 8c's +-10 % (>= +-2) around the oracle's count -- or around the counts the oracle itself produces when b is
+    changed by a few ulp (tests/soak.py's rule for systems that amplify rounding)"""
+    if abs(it_gpu - it_orc) <= max(2, 0.1 * it_orc):
+        return True
+    counts = [it_orc]
+    for k in (-3, -2, -1, 1, 2, 3):
+        _, st, _ = oracle_run(O, A, b * (1.0 + k * EPS), loop, vm, maxit, tol)
+        if st.converged:
+            counts.append(st.iters)
+    lo, hi = min(counts), max(counts)
+    return lo - max(2, 0.1 * lo) <= it_gpu <= hi + max(2, 0.1 * hi)
+
+
+def compare_loop(O, A, b, loop, vm, gpu, maxit, tol, k_nb_plain=None):
+    """gpu = (x, stats, history) of the HIP path for the same system / loop / preconditioner (vm: the oracle's ILU(0)
+    values or None).  Returns (report line, findings, k_nb): findings is a list of strings, empty when every rule holds."""
+    xg, st, hg = gpu
+    bad = []
+    if loop == 0:
+        xo, so, ho, trace = O.pbicgstab(A, b, vm=vm, maxit=maxit, tol=tol, want_trace=True)
+        ho = ho[:2 * so.iters + so.half_exit]
+        k_nb = noise_breakdown(trace)
+    else:
+        # (the (A0 + I d) loop runs the recurrences of the M = I loop in exact arithmetic: its noise point is that loop's)
+        xo, so, ho = oracle_run(O, A, b, loop, vm, maxit, tol)
+        k_nb = k_nb_plain
+    line = "loop%d pc%d: oracle it %d conv %d brk %d, GPU it %d conv %d brk %d, oracle's rho loses its last bit at %s" % (
+        loop, int(vm is not None), so.iters, so.converged, so.breakdown, st.iters, st.converged, st.breakdown, k_nb)
+    # 1. the initial residual
+    if not abs(st.nrm0 - so.nrm0) <= 1e-12 * so.nrm0:
+        bad.append("nrm0 %r vs %r" % (st.nrm0, so.nrm0))
+    # 2. the history agrees for as long as the oracle agrees with itself under a 1..3 ulp change of b
+    l_self, cap = self_prefix(O, A, b, loop, vm, ho, tol)
+    l_gpu = prefix(hg[:cap], ho[:cap], 1e-6)
+    if l_gpu < min(l_self, len(ho), len(hg)) - (4 if loop == 0 else 2):
+        bad.append("history leaves the oracle's after %d entries, the oracle's own (b changed by 1..3 ulp) after %d" % (l_gpu, l_self))
+    line += "; history equal to 1e-6 over %d entries (oracle vs itself, b changed by 1..3 ulp: %d)" % (l_gpu, l_self)
+    # the flags mean what they say
+    hist_bad = first_bad(hg) < len(hg) or not np.isfinite(st.nrm)
+    if st.breakdown:
+        if st.converged: bad.append("breakdown AND converged")
+        if not (hist_bad or loop == 1): bad.append("breakdown flag without a non-finite residual")     # loop 1 also breaks on |omega| < 1e-5 (:735)
+    elif hist_bad:
+        bad.append("a non-finite residual went unreported")
+    if st.converged:
+        if not (st.nrm < tol * st.nrm0 and st.iters <= maxit): bad.append("converged flag without a residual below the target")
+    elif not st.breakdown and st.iters != maxit:
+        bad.append("stopped at %d of %d iterations without converged / breakdown" % (st.iters, maxit))
+    # 3. the outcome class
+    tr_g, tr_o = true_res(O, A, b, xg), true_res(O, A, b, xo)
+    if k_nb is None:
+        # no breakdown in the oracle's run: the classes must be the same, as on well-behaved systems
+        if st.breakdown: bad.append("breakdown where the oracle's rho keeps its bits")
+        if bool(st.converged) != bool(so.converged): bad.append("converged %d vs %d" % (st.converged, so.converged))
+        elif so.converged:
+            if not iters_inside_oracle_spread(O, A, b, loop, vm, st.iters, so.iters, maxit, tol):
+                bad.append("iterations %d vs %d, outside the oracle's own spread" % (st.iters, so.iters))
+            # (the recursive residual may have left the true one on BOTH sides: convdiff_g8 with ILU(0) "converges" at a
+            # true residual of 1e5 in the oracle and on the GPU alike -- compared like for like)
+            if not tr_g <= 10.0 * max(tr_o, tol * so.nrm0): bad.append("true residual %g vs the oracle's %g" % (tr_g, tr_o))
+        elif not (st.iters == so.iters == maxit):
+            bad.append("iterations %d vs %d at maxit %d" % (st.iters, so.iters, maxit))
+    else:
+        # from iteration k_nb on the loop runs on rounding noise: any class may follow, but not before
+        if not st.converged and (hist_bad or not st.breakdown):
+            if st.iters < min(k_nb, so.iters) - 2: bad.append("stopped at %d, before the oracle's rho lost its last bit (%d)" % (st.iters, k_nb))
+        elif not st.converged:
+            # loop 1 stopped by the reference's own |omega| < 1e-5 guard (pbicgstab.cu:735) on finite residuals: an event of
+            # the trajectory itself, which may fire anywhere once the two histories have parted (example1000_p90: the
+            # histories part after 5 iterations, the guard fires at 34 on the GPU and at 154 in the oracle) -- not before
+            if not (loop == 1 and st.iters >= l_gpu): bad.append("|omega| guard at %d while the histories still agree (%d)" % (st.iters, l_gpu))
+        elif so.converged:
+            if not tr_g <= 10.0 * max(tr_o, tol * so.nrm0): bad.append("true residual %g vs the oracle's %g" % (tr_g, tr_o))
+        elif not tr_g <= 100.0 * tol * so.nrm0:       # the GPU's draw converged, the oracle's did not: a solution in its own right?
+            bad.append("converged on noise with a true residual of %g" % tr_g)
+    return line, bad, k_nb
+
+
+def compare_factors(vm, lu):
+    """ILU(0) values of the HIP path against the oracle's: findings (list of strings)"""
+    fin = np.isfinite(vm)
+    if not np.array_equal(fin, np.isfinite(lu)):
+        return ["the finite / non-finite patterns of the factors differ"]
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        rel = np.abs(lu[fin] - vm[fin]) / np.maximum(np.abs(vm[fin]), 1e-300)
+    if np.nanmax(np.abs(vm)) < 1e12:
+        return [] if rel.max() <= 1e-11 else ["factors differ by %.2e (rtol 1e-11)" % rel.max()]
+    # the factorisation itself overflows (example1000_p90: |u| up to 4e252): the same blow-up on both sides
+    ok = np.nanmax(np.abs(lu[fin])) > 1e100 and np.nanquantile(rel, 0.99) <= 1e-8
+    return [] if ok else ["overflowing factors: 99 %% quantile of the relative difference %.2e" % np.nanquantile(rel, 0.99)]

@@ -13,6 +13,8 @@ bad = 0
 forms = {}
 dicts = 0
 stencils = {}
+nd_total = 0
+nd_classes = {}     # (converged, breakdown flag, the oracle's rho lost its bits) -> solves
 
 
 def oracle_spread(A, b, loop, precond, first, nperm=8):
@@ -217,8 +219,48 @@ for case in range(ncase):
             except cm.CudamatError as e:
                 msgs.append("stencil (%s): %s" % (mode, e))
         ctx.reset_options()
+    # every fourth case also brings a system that is NOT diagonally dominant (own generator: the draws above stay what they
+    # were): the same kind of random rows with diagonal = theta * sum |off-diagonals|, theta in {1, 0.6, 0.3}, a random sign
+    # per row in half of them -- or, every eighth case, the reference CLI's own recipe (example.cpp:274-288: entries in
+    # [1,10] from libc rand()).  Compared by the rules of tests/test_gpu_nondominant.py (tests/nondominant.py compare_loop):
+    # initial residual, history prefix against the oracle's own agreement under 1..3 ulp changes of b, outcome class with the
+    # oracle's rho-noise point, ILU(0) factors with small pivots
+    if case % 4 == 3:
+        from tests import nondominant as ND
+        r3 = np.random.default_rng(7000 * (int(sys.argv[1]) if len(sys.argv) > 1 else 0) + case)
+        if case % 8 == 7:
+            A3, b3 = O.example_system(int(r3.integers(30, 3000)), float(r3.choice([0.5, 0.9, 0.98, 0.995])), 0.2, int(r3.integers(1, 1 << 20)))
+        else:
+            A3 = ND.weakdiag(O, int(r3.integers(200, 20000)), float(r3.choice([3, 6, 12, 40])), float(r3.choice([1.0, 0.6, 0.3])),
+                             int(r3.integers(0, 1 << 30)), base=int(r3.integers(0, 2)), signs=bool(r3.integers(0, 2)))
+            b3 = ND.rhs_for(O, A3, int(r3.integers(0, 1000)))
+        nd_total += 1
+        try:
+            vm3 = O.ilu0(A3)
+        except ZeroDivisionError:
+            vm3 = None
+        k_plain = None
+        for loop3, pc3 in ((0, 0), (1, 0), (0, 1)):
+            if pc3 and vm3 is None: continue
+            s3 = cm.Solver.from_host_csr(ctx, A3.rowptr, A3.colidx, A3.val)
+            db, dxx = ctx.array(b3), ctx.array(np.ones(A3.n))
+            try:
+                lu3 = None
+                if pc3:
+                    s3.ilu0(); lu3 = s3.ilu0_values()
+                st3 = s3.solve(db, dxx, precond=pc3, loop=loop3, maxit=600, tol=1e-6)
+                line, found, k_nb = ND.compare_loop(O, A3, b3, loop3, vm3 if pc3 else None, (dxx.download(), st3, s3.history()), 600, 1e-6, k_plain)
+                if loop3 == 0 and not pc3: k_plain = k_nb
+                if pc3: found += ND.compare_factors(vm3, lu3)
+                nd_classes[(bool(st3.converged), bool(st3.breakdown), k_nb is not None)] = nd_classes.get((bool(st3.converged), bool(st3.breakdown), k_nb is not None), 0) + 1
+                msgs += ["non-dominant n=%d nnz=%d loop%d pc%d: %s" % (A3.n, A3.nnz, loop3, pc3, m) for m in found]
+            except cm.CudamatError as e:
+                msgs.append("non-dominant loop%d pc%d: %s" % (loop3, pc3, e))
+            for a in (db, dxx): a.free()
+            s3.close()
     if msgs:
         bad += 1
         print("case %d n=%d per=%g base=%d: %s" % (case, n, per, base, "; ".join(msgs)), flush=True)
 print("soak: %d cases, %d with findings; solves by loop form (0 five launches, 1 three, 2 one): %s" % (ncase, bad, sorted(forms.items())) + "; SpMV runs on a value dictionary: %d" % dicts
-      + "; stencil systems through the row-pattern forms: %s" % sorted(stencils.items()))
+      + "; stencil systems through the row-pattern forms: %s" % sorted(stencils.items())
+      + "; non-dominant systems: %d, their solves by (converged, breakdown, oracle on rounding noise): %s" % (nd_total, sorted(nd_classes.items())))

@@ -31,8 +31,6 @@ from tests import nondominant as ND
 pytestmark = pytest.mark.gpu
 
 MAXIT, TOL = 2000, 1e-6          # the reference CLI's constants (example.cpp:179-180)
-SELF_ITERS = 200                 # iterations of the perturbed oracle runs that measure the system's own amplification
-EPS = np.finfo(np.float64).eps
 
 
 @pytest.fixture(scope="module")
@@ -57,31 +55,6 @@ def _serial_oracle(oracle):
     oracle.set_num_threads(before)
 
 
-def _noise_breakdown(trace):
-    """first iteration whose rho or rw.v is below 4 eps of the sum of magnitudes it was summed from (or not finite)"""
-    with np.errstate(invalid="ignore"):
-        bad = ((np.abs(trace[:, 0]) <= 4 * EPS * trace[:, 1]) | ~np.isfinite(trace[:, 0])
-               | (np.isfinite(trace[:, 3]) & (np.abs(trace[:, 2]) <= 4 * EPS * trace[:, 3])) | (trace[:, 6] == 0.0))
-    w = np.nonzero(bad)[0]
-    return int(w[0]) if w.size else None
-
-
-def _oracle_run(O, A, b, loop, vm, maxit=MAXIT):
-    """(x, stats, history without the unwritten tail)"""
-    if loop == 0:
-        x, st, h = O.pbicgstab(A, b, vm=vm, maxit=maxit, tol=TOL, want_hist=True)
-        return x, st, h[:2 * st.iters + st.half_exit]
-    ok, x, st, h = O.pbicgstab2(A, b, maxit=maxit, tol=TOL, want_hist=True)
-    return x, st, h[:st.iters]
-
-
-def _self_prefix(O, A, b, loop, vm, h0):
-    """entries over which the oracle's history agrees (1e-6) with itself when b is changed by 1..3 ulp either way (the
-    shortest of the six: the length itself varies with the perturbation, example40 with ILU(0): 10, 4000, 10, 4)"""
-    cap = (2 if loop == 0 else 1) * SELF_ITERS
-    return min(ND.prefix(_oracle_run(O, A, b * (1.0 + k * EPS), loop, vm, maxit=SELF_ITERS)[2][:cap], h0[:cap], 1e-6) for k in (1, -1, 2, -2, 3, -3)), cap
-
-
 def _gpu_run(cm, ctx, A, b, loop, precond):
     s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
     db, dx = ctx.array(b), ctx.array(np.ones(A.n))
@@ -98,109 +71,25 @@ def _gpu_run(cm, ctx, A, b, loop, precond):
         s.close()
 
 
-def _true_res(O, A, b, x):
-    with np.errstate(invalid="ignore", over="ignore"):
-        return float(np.linalg.norm(b - O.spmv(A, x)))
-
-
-def _iters_inside_oracle_spread(O, A, b, loop, vm, it_gpu, it_orc):
-    """SURVEY 8c's +-10 % (>= +-2) around the oracle's count -- or around the counts the oracle itself produces when b is
-    changed by a few ulp (tests/soak.py's rule for systems that amplify rounding)"""
-    if abs(it_gpu - it_orc) <= max(2, 0.1 * it_orc):
-        return True
-    counts = [it_orc]
-    for k in (-3, -2, -1, 1, 2, 3):
-        _, st, _ = _oracle_run(O, A, b * (1.0 + k * EPS), loop, vm)
-        if st.converged:
-            counts.append(st.iters)
-    lo, hi = min(counts), max(counts)
-    return lo - max(2, 0.1 * lo) <= it_gpu <= hi + max(2, 0.1 * hi)
-
-
 @pytest.mark.parametrize("name", list(ND.FAMILY))
 def test_reference_loops_on_nondominant_systems(cm, ctx, oracle, name):
+    """rules 1-4 of this file's docstring (tests/nondominant.py compare_loop / compare_factors) on one system, through
+    gpu_pbicgstab with M = I, the (A0 + I d) loop with d = 0, and gpu_pbicgstab with ILU(0)"""
     O = oracle
     A, b = ND.FAMILY[name](O)
     vm = O.ilu0(A)
-    # the M = I recurrences' noise point, from the oracle's trace of pbicgstab.cu:45-154 (the (A0 + I d) loop :581-754 runs
-    # the same recurrences in exact arithmetic, so its noise point is taken from the same trace)
-    report = []
-    k_nb_plain = None
+    report, findings, k_nb_plain = [], [], None
     for loop, precond in ((0, 0), (1, 0), (0, 1)):
-        vmp = vm if precond else None
-        if loop == 0:
-            xo, so, ho, trace = O.pbicgstab(A, b, vm=vmp, maxit=MAXIT, tol=TOL, want_trace=True)
-            ho = ho[:2 * so.iters + so.half_exit]
-            k_nb = _noise_breakdown(trace)
-            if not precond:
-                k_nb_plain = k_nb
-        else:
-            xo, so, ho = _oracle_run(O, A, b, loop, vmp)
-            k_nb = k_nb_plain
         xg, st, hg, lu = _gpu_run(cm, ctx, A, b, loop, precond)
-        tag = "%s loop%d pc%d" % (name, loop, precond)
-        report.append("%s: oracle it %d conv %d brk %d, GPU it %d conv %d brk %d, oracle's rho loses its last bit at %s"
-                      % (tag, so.iters, so.converged, so.breakdown, st.iters, st.converged, st.breakdown, k_nb))
-
-        # 4. the factors
+        line, bad, k_nb = ND.compare_loop(O, A, b, loop, vm if precond else None, (xg, st, hg), MAXIT, TOL, k_nb_plain)
+        if loop == 0 and not precond:
+            k_nb_plain = k_nb
         if precond:
-            fin = np.isfinite(vm)
-            assert np.array_equal(fin, np.isfinite(lu)), tag
-            if np.nanmax(np.abs(vm)) < 1e12:
-                np.testing.assert_allclose(lu, vm, rtol=1e-11, atol=1e-300, err_msg=tag)
-            else:       # the factorisation itself overflows (example1000_p90: |u| up to 4e252): the same blow-up on both sides
-                with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
-                    rel = np.abs(lu[fin] - vm[fin]) / np.abs(vm[fin])
-                assert np.nanmax(np.abs(lu[fin])) > 1e100 and np.nanquantile(rel, 0.99) <= 1e-8, tag
-
-        # 1. the initial residual
-        assert abs(st.nrm0 - so.nrm0) <= 1e-12 * so.nrm0, tag
-
-        # 2. the history agrees for as long as the oracle agrees with itself under a one-ulp change of b
-        l_self, cap = _self_prefix(O, A, b, loop, vmp, ho)
-        l_gpu = ND.prefix(hg[:cap], ho[:cap], 1e-6)
-        assert l_gpu >= min(l_self, len(ho), len(hg)) - (4 if loop == 0 else 2), (tag, l_gpu, l_self)
-        report[-1] += "; history equal to 1e-6 over %d entries (oracle vs itself, b changed by 1..3 ulp: %d)" % (l_gpu, l_self)
-
-        # the flags mean what they say
-        hist_bad = ND.first_bad(hg) < len(hg) or not np.isfinite(st.nrm)
-        if st.breakdown:
-            assert not st.converged, tag
-            assert hist_bad or loop == 1, tag           # loop 1 also breaks on |omega| < 1e-5 (pbicgstab.cu:735)
-        else:
-            assert not hist_bad, tag                    # a NaN / inf residual never goes unreported
-        if st.converged:
-            assert st.nrm < TOL * st.nrm0 and st.iters <= MAXIT, tag
-        elif not st.breakdown:
-            assert st.iters == MAXIT, tag
-
-        # 3. the outcome class
-        tr_g, tr_o = _true_res(O, A, b, xg), _true_res(O, A, b, xo)
-        if k_nb is None:
-            # no breakdown in the oracle's run: the classes must be the same, as on well-behaved systems
-            assert not st.breakdown, tag
-            assert bool(st.converged) == bool(so.converged), tag
-            if so.converged:
-                assert _iters_inside_oracle_spread(O, A, b, loop, vmp, st.iters, so.iters), (tag, st.iters, so.iters)
-                # (the recursive residual may have left the true one on BOTH sides: convdiff_g8 with ILU(0) "converges" at a
-                # true residual of 1e5 in the oracle and on the GPU alike -- compared like for like)
-                assert tr_g <= 10.0 * max(tr_o, TOL * so.nrm0), (tag, tr_g, tr_o)
-            else:
-                assert st.iters == so.iters == MAXIT, tag
-        else:
-            # from iteration k_nb on the loop runs on rounding noise: any class may follow, but not before
-            if not st.converged and (hist_bad or not st.breakdown):
-                assert st.iters >= min(k_nb, so.iters) - 2, (tag, st.iters, k_nb)
-            elif not st.converged:
-                # loop 1 stopped by the reference's own |omega| < 1e-5 guard (pbicgstab.cu:735) on finite residuals: an event of
-                # the trajectory itself, which may fire anywhere once the two histories have parted (example1000_p90: the
-                # histories part after 5 iterations, the guard fires at 34 on the GPU and at 154 in the oracle) -- not before
-                assert loop == 1 and st.iters >= l_gpu, (tag, st.iters, l_gpu)
-            elif so.converged:
-                assert tr_g <= 10.0 * max(tr_o, TOL * so.nrm0), (tag, tr_g, tr_o)
-            else:       # the GPU's draw converged, the oracle's did not: the iterate must be a solution in its own right
-                assert tr_g <= 100.0 * TOL * so.nrm0, (tag, tr_g)
+            bad += ND.compare_factors(vm, lu)
+        report.append("%s %s" % (name, line))
+        findings += ["%s loop%d pc%d: %s" % (name, loop, precond, m) for m in bad]
     print("\n".join(report))
+    assert not findings, "\n".join(findings)
 
 
 @pytest.mark.parametrize("dim,p_zero", [(10000, 0.99), (40, 0.5)])
@@ -224,7 +113,7 @@ def test_reference_cli_workloads_through_the_drop_in_entry_points(cm, oracle, di
         assert st.breakdown and st.iters == 1                # the GPU: stops there
         assert np.all(np.isfinite(x))                        # ... and hands back the last finite iterate
     else:
-        assert _noise_breakdown(trace) is None and ND.first_bad(ho[:2 * so.iters]) == 2 * MAXIT
+        assert ND.noise_breakdown(trace) is None and ND.first_bad(ho[:2 * so.iters]) == 2 * MAXIT
         assert not st.breakdown and st.iters == MAXIT == so.iters          # both wander to maxit, all residuals finite
     # the un-preconditioned entry point (pbicgstab.h:113; the reference's own is broken): |omega| guard or NaN
     ok2, x2, dt2, st2 = cm.bicgstab(A.n, A.nnz, A.val, A.rowptr, A.colidx, b, MAXIT, TOL)

@@ -513,6 +513,52 @@ def test_blocked_spmv_is_bit_exact(cm, ctx, oracle, case, sw):
         np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), oracle.csrmv(A, 1.0, x, 1.0, x * d))
 
 
+def test_lds_order_probe_guards_the_default_blocked_form(cm, ctx, oracle, sw, capfd):
+    """The default phase 2 is bit-exact only where the LDS serves equal addresses of one ds_add_f64 in lane order -- an
+    OBSERVED property of gfx950.  Every context checks it at its first blocked SpMV (k_lds_order_probe, one wave, ~30 us)
+    and falls back to the architected-order form when it does not hold.  Here: the probe passes on this device (default
+    form selected, nothing printed); with the probe forced to fail (PB_PROBE_FAIL=1) the context says so on stderr, runs
+    `k_pb_phase2` in its architected-order form WITHOUT PB_STRICT being set, and the results -- SpMV on real data, and a
+    preconditioned solve whose far parts run through the same phase 2 -- stay bit-identical to the oracle / the default."""
+    sw("SPMV_MODE", "pb")
+    rng = np.random.default_rng(19)
+    A = oracle.rand_rows(20000, 50, 0x5EED)
+    A.val[:] = rng.standard_normal(A.nnz)
+    x = rng.standard_normal(A.n)
+    want = oracle.spmv(A, x)
+
+    def run():
+        s = cm.Solver.from_host_csr(ctx, A.rowptr, A.colidx, A.val)
+        dx, dy = ctx.array(x), ctx.empty(A.n)
+        s.spmv(dx, dy)
+        name, y = s.spmv_kernel(), dy.download()
+        for a in (dx, dy):
+            a.free()
+        s.close()
+        return name, y
+
+    capfd.readouterr()
+    name, y = run()
+    out = capfd.readouterr()
+    assert name == "k_pb_phase1 + k_pb_phase2" and "LDS order probe" not in out.err      # the property holds here
+    np.testing.assert_array_equal(y, want)
+    sw("PB_PROBE_FAIL", 1)
+    name, y = run()
+    out = capfd.readouterr()
+    assert name == "k_pb_phase1 + k_pb_phase2 (architected order)", name
+    assert "reported NOT in lane order (PB_PROBE_FAIL)" in out.err and "architected-order" in out.err
+    np.testing.assert_array_equal(y, want)
+    # the triangular solves' far parts take the same decision (hybrid form forced on this small system)
+    sw("TRSV_HYBRID", 1)
+    Ai = oracle.rand_rows(20000, 50, 0x5EED)
+    b = oracle.spmv(Ai, oracle.xstar(20000, 0x5EEE))
+    x_forced, st_f, _ = _solve_dev(cm, ctx, Ai, b, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PBICGSTAB, maxit=100, tol=1e-10)
+    sw("PB_PROBE_FAIL", None)
+    x_default, st_d, _ = _solve_dev(cm, ctx, Ai, b, precond=cm.PRECOND_ILU0, loop=cm.LOOP_PBICGSTAB, maxit=100, tol=1e-10)
+    assert st_f.converged and st_d.converged and st_f.iters == st_d.iters
+    np.testing.assert_array_equal(x_forced, x_default)
+
+
 def test_blocked_spmv_in_the_solver_loop(cm, ctx, oracle, golden_dir, sw):
     """same solves as above with the blocked kernels forced: fused dots, freeze prologue, ILU path"""
     sw("SPMV_MODE", "pb")
