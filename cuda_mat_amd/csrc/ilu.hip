@@ -818,42 +818,92 @@ static void plan_groups(const Config &cfg, const TriFactor &F, TriHost &H, bool 
 }
 
 // ---- hybrid split of a level-major factor into near (same group) and far (earlier groups) entries
-__global__ __launch_bounds__(kBlock) void k_group_of_row(int n, const int *lev, const unsigned char *group_of_level, unsigned char *grp)
+// Rows are in level-major order, a group is a range of positions: the group of a row or of a (relabelled) column follows
+// from its position by comparison with the group boundaries (<= 17 by default) -- no per-row group table, no gather for it.
+struct GroupCuts {
+    int K;
+    int start[130];         // start[g] = first level-major position of group g; start[K] = n  (TRSV_GROUPS <= 128)
+};
+
+__device__ __forceinline__ void group_range(const GroupCuts &gc, int pr, int *gs, int *ge)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) grp[i] = group_of_level[lev[i]];
+    int g = 0;
+#pragma unroll 1
+    for (int q = 1; q < gc.K; q++) g += gc.start[q] <= pr ? 1 : 0;
+    *gs = gc.start[g];
+    *ge = gc.start[g + 1];
 }
 
-__global__ __launch_bounds__(kBlock) void k_split_count(int n, const int *frp, const int *fci, const int *row_of,
-                                                        const unsigned char *grp, int *cnt_near, int *cnt_far)
+// Pass 1, one wavefront per row (coalesced reads of the row's columns): relabel the columns to level-major positions
+// -- the ONE random gather per entry of the whole split, written out so that pass 2 streams -- and count the row's near
+// entries (position inside the row's own group) and far ones.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_split_count(int n, const int *frp, const int *fci, const int *pos, GroupCuts gc,
+                                                           int *ci_new, int *cnt_near, int *cnt_far)
 {
-    const int pr = blockIdx.x * kBlock + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long pr = (long long)blockIdx.x * WAVES + wave;
     if (pr >= n) return;
-    const int g = grp[row_of[pr]];
-    int nn = 0, nf = 0;
-    for (int k = frp[pr]; k < frp[pr + 1]; k++) {
-        if (grp[fci[k]] == g) nn++; else nf++;
+    int gs, ge;
+    group_range(gc, (int)pr, &gs, &ge);
+    const int s0 = frp[pr], len = frp[pr + 1] - s0;
+    int nn = 0;
+    for (int k = lane; k < len; k += 64) {
+        const int p = pos[fci[s0 + k]];
+        ci_new[s0 + k] = p;
+        nn += (p >= gs && p < ge) ? 1 : 0;
     }
-    cnt_near[pr] = nn;
-    cnt_far[pr] = nf;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 64);
+    if (lane == 0) {
+        cnt_near[pr] = nn;
+        cnt_far[pr] = len - nn;
+    }
 }
 
-// pos: level-major position of every original row -- the stored columns become indices into the level-major `out`.
-// Near entries keep their order (a row is still summed in its original column order); far entries are sorted by
-// their new column afterwards (k_sort_rows: the blocked builder needs increasing columns).
-__global__ __launch_bounds__(kBlock) void k_split_fill(int n, const int *frp, const int *fci, const double *fval,
-                                                       const int *row_of, const unsigned char *grp, const int *pos,
-                                                       const int *nrp, int *nci, double *nval, const int *qrp,
-                                                       int *qci, double *qval)
+// Pass 2, one wavefront per row: near entries keep their order (a row is still summed in its original column order:
+// ballot-ranked compaction), far entries go straight to their place in increasing order of the new column (the blocked
+// builder needs increasing columns): the row's far columns are staged in LDS and every far entry counts the smaller
+// ones -- columns are distinct; <= kSortRowMax entries per row (the hybrid form is not taken otherwise).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_split_fill(int n, const int *frp, const int *ci_new, const double *fval, GroupCuts gc,
+                                                          const int *nrp, int *nci, double *nval, const int *qrp, int *qci,
+                                                          double *qval)
 {
-    const int pr = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ int key[WAVES][kSortRowMax];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long pr = (long long)blockIdx.x * WAVES + wave;
     if (pr >= n) return;
-    const int g = grp[row_of[pr]];
-    int on = nrp[pr], of = qrp[pr];
-    for (int k = frp[pr]; k < frp[pr + 1]; k++) {
-        const int c = fci[k];
-        if (grp[c] == g) { nci[on] = pos[c]; nval[on++] = fval[k]; }
-        else { qci[of] = pos[c]; qval[of++] = fval[k]; }
+    int gs, ge;
+    group_range(gc, (int)pr, &gs, &ge);
+    const int s0 = frp[pr], len = frp[pr + 1] - s0;
+    int *kk = key[wave];
+    for (int k = lane; k < len; k += 64) {
+        const int p = ci_new[s0 + k];
+        kk[k] = (p >= gs && p < ge) ? 0x7fffffff : p;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int on = nrp[pr], of = qrp[pr];
+    int run_near = 0;
+    for (int k0 = 0; k0 < len; k0 += 64) {
+        const int k = k0 + lane;
+        const bool active = k < len;
+        const int p = active ? ci_new[s0 + k] : 0;
+        const bool near = active && p >= gs && p < ge;
+        const unsigned long long m = __ballot(near);
+        if (near) {
+            const int dst = on + run_near + __popcll(m & ((1ULL << lane) - 1ULL));
+            nci[dst] = p;
+            nval[dst] = fval[s0 + k];
+        }
+        run_near += __popcll(m);
+        if (active && !near) {
+            int rank = 0;
+            for (int j = 0; j < len; j++) rank += kk[j] < p ? 1 : 0;
+            qci[of + rank] = p;
+            qval[of + rank] = fval[s0 + k];
+        }
     }
 }
 
@@ -919,25 +969,21 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
     const int n = s->n;
     const int K = (int)H.grp_level.size() - 1;
     double t_stamp = now_s();
-    // group of every level (the group of a row = that of its level: on the device, from the levels kept there)
-    std::vector<unsigned char> g_of_level((size_t)(F.nlevels > 0 ? F.nlevels : 1));
-    for (int g = 0; g < K; g++)
-        for (int l = H.grp_level[(size_t)g]; l < H.grp_level[(size_t)g + 1]; l++) g_of_level[(size_t)l] = (unsigned char)g;
-    unsigned char *d_gtab = nullptr;
-    unsigned char *d_grp = nullptr;
-    int *d_cn = nullptr, *d_cf = nullptr, *nrp = nullptr, *qrp = nullptr, *nci = nullptr, *qci = nullptr, *qci2 = nullptr;
-    double *nval = nullptr, *qval = nullptr, *qval2 = nullptr;
+    // the groups as ranges of level-major positions (rows are stored level by level)
+    GroupCuts gc{};
+    if (K > 128) { set_error("factor split: more than 128 groups"); return CUDAMAT_ERR_ARG; }
+    gc.K = K;
+    for (int g = 0; g <= K; g++) gc.start[g] = F.level_ptr[(size_t)H.grp_level[(size_t)g]];
+    int *d_cn = nullptr, *d_cf = nullptr, *nrp = nullptr, *qrp = nullptr, *nci = nullptr, *qci = nullptr, *ci_new = nullptr;
+    double *nval = nullptr, *qval = nullptr;
     int rc = CUDAMAT_OK;
     do {
-        if ((rc = dalloc(&d_grp, (size_t)n))) break;
         if ((rc = dalloc(&d_cn, (size_t)n))) break;
         if ((rc = dalloc(&d_cf, (size_t)n))) break;
-        if (!H.lev_dev) { rc = CUDAMAT_ERR_ARG; set_error("factor split: the levels of the rows are gone"); break; }
-        if ((rc = dalloc(&d_gtab, g_of_level.size()))) break;
-        if (hipMemcpy(d_gtab, g_of_level.data(), g_of_level.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
-        const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_group_of_row, dim3(grid), dim3(kBlock), 0, st, n, H.lev_dev, d_gtab, d_grp);
-        hipLaunchKernelGGL(k_split_count, dim3(grid), dim3(kBlock), 0, st, n, F.rp, F.ci, F.row_of, d_grp, d_cn, d_cf);
+        if ((rc = dalloc(&ci_new, (size_t)(F.nnz > 0 ? F.nnz : 1)))) break;
+        constexpr int kSplitWaves = 4;
+        const unsigned grid = (unsigned)((n + kSplitWaves - 1) / kSplitWaves);
+        hipLaunchKernelGGL(k_split_count<kSplitWaves>, dim3(grid), dim3(64 * kSplitWaves), 0, st, n, F.rp, F.ci, pos, gc, ci_new, d_cn, d_cf);
         // row pointers of the near and the far part: prefix sums on the device; the host needs the two totals and the far
         // pointer at the group boundaries only
         if ((rc = dalloc(&nrp, (size_t)n + 1))) break;
@@ -957,16 +1003,11 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
         if ((rc = dalloc(&nval, (size_t)nnz_near))) break;
         if ((rc = dalloc(&qci, (size_t)nnz_far))) break;
         if ((rc = dalloc(&qval, (size_t)nnz_far))) break;
-        hipLaunchKernelGGL(k_split_fill, dim3(grid), dim3(kBlock), 0, st, n, F.rp, F.ci, F.val, F.row_of, d_grp, pos, nrp, nci,
+        // (far rows come out in increasing level-major column order, as the blocked builder needs them)
+        hipLaunchKernelGGL(k_split_fill<kSplitWaves>, dim3(grid), dim3(64 * kSplitWaves), 0, st, n, F.rp, ci_new, F.val, gc, nrp, nci,
                            nval, qrp, qci, qval);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("factor split failed"); break; }
-        CM_STAMP("split fill");
-        // the far rows in increasing (level-major) column order, as the blocked builder needs them
-        if ((rc = dalloc(&qci2, (size_t)nnz_far))) break;
-        if ((rc = dalloc(&qval2, (size_t)nnz_far))) break;
-        if ((rc = launch_sort_rows(st, n, qrp, nullptr, qrp, qci, qval, nullptr, qci2, qval2))) break;
-        if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("far row sort failed"); break; }
-        CM_STAMP("far rows sorted by position");
+        CM_STAMP("split fill (far rows sorted)");
         // one blocked SpMV plan per group: rows of the group (level-major, contiguous) x the columns of the EARLIER
         // groups -- in level-major space those are the positions [0, r0), so only that prefix of `out` is tiled
         H.far.assign((size_t)K, PbPlan());
@@ -974,7 +1015,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
             const int r0 = F.level_ptr[(size_t)H.grp_level[(size_t)g]], r1 = F.level_ptr[(size_t)H.grp_level[(size_t)g + 1]];
             const int64_t cnt = (int64_t)hf_grp[(size_t)g + 1] - hf_grp[(size_t)g];
             if (r1 <= r0 || cnt <= 0) continue;
-            rc = pb_build(st, s->ctx->cfg, r1 - r0, r0, cnt, qrp + r0, qci2, qval2, &H.far[(size_t)g]);
+            rc = pb_build(st, s->ctx->cfg, r1 - r0, r0, cnt, qrp + r0, qci, qval, &H.far[(size_t)g]);
         }
         CM_STAMP("far plans (pb_build)");
         if (rc) break;
@@ -987,7 +1028,7 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
         nrp = nullptr; nci = nullptr; nval = nullptr;
         H.lanes = pick_lanes(n ? (double)F.nnz / n : 1.0);
     } while (0);
-    void *tmp[] = {d_grp, d_gtab, d_cn, d_cf, nrp, qrp, nci, qci, nval, qval, qci2, qval2};
+    void *tmp[] = {d_cn, d_cf, nrp, qrp, nci, qci, nval, qval, ci_new};
     for (void *q : tmp)
         if (q) CM_DROP(hipFree(q));
     free_levels(H);
@@ -1320,6 +1361,7 @@ int ilu_perm_matrix(cudamat_solver *s)
     const int n = s->n;
     const int64_t nnz = s->pm_nnz;
     const double t0 = now_s();
+    double t_stamp = t0;
     int *d_rp = nullptr, *d_ci = nullptr, *d_len = nullptr;
     double *d_val = nullptr;
     int rc = CUDAMAT_OK;
@@ -1328,14 +1370,18 @@ int ilu_perm_matrix(cudamat_solver *s)
         if ((rc = dalloc(&d_len, (size_t)n))) break;
         if ((rc = dalloc(&d_ci, (size_t)nnz))) break;
         if ((rc = dalloc(&d_val, (size_t)nnz))) break;
+        CM_STAMP("perm: allocations");
         // row pointers of the permuted matrix: lengths of the rows in L's order, prefix sums on the device
         hipLaunchKernelGGL(k_perm_row_len, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, s->pm_rp, s->L.row_of, d_len);
         if ((rc = device_exclusive_scan(st, n, d_len, d_rp))) break;
         if ((rc = launch_sort_rows(st, n, s->pm_rp, s->L.row_of, d_rp, s->pm_ci, s->pm_val, pl->posU, d_ci, d_val))) break;
+        CM_STAMP("perm: rows permuted and sorted");
         if (nnz >= (1 << 20)) {
             if ((rc = valdict_build(st, s->ctx->cfg, nnz, d_val, &s->vd_perm))) break;       // (n == 0 afterwards: no dictionary, fp64 values)
         }
+        CM_STAMP("perm: value dictionary");
         if ((rc = pb_build(st, s->ctx->cfg, n, n, nnz, d_rp, d_ci, d_val, &s->pb_perm, nullptr, &s->vd_perm))) break;
+        CM_STAMP("perm: blocked copy");
         if (!s->x_perm && (rc = dalloc(&s->x_perm, (size_t)(s->n_pad > n ? s->n_pad : n)))) break;
         if (!s->b_perm && (rc = dalloc(&s->b_perm, (size_t)(s->n_pad > n ? s->n_pad : n)))) break;
         if (hipStreamSynchronize(st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("permuted matrix build failed"); break; }
@@ -1343,6 +1389,7 @@ int ilu_perm_matrix(cudamat_solver *s)
     void *tmp[] = {d_rp, d_ci, d_val, d_len};
     for (void *q : tmp)
         if (q) CM_DROP(hipFree(q));
+    CM_STAMP("perm: temporaries freed");
     if (rc) {
         pb_free(&s->pb_perm);
         valdict_free(&s->vd_perm);

@@ -62,6 +62,13 @@ struct PbBuild {
     size_t cap = 0;            // entries of the value / column / row / product arrays (with the blocks' alignment pads)
     double t0 = 0.0;
     bool verbose = false;      // Config::verbose at the count pass: pb_build_end prints the plan and its segment lengths
+    // two-pass fill (k_pb_group + k_pb_scatter): groups of GB column blocks, NG groups; one packed (block, column, row) word
+    // per entry between the passes (the values travel in the product stream), first entry of every (sub-block, group) bucket
+    bool two_pass = false;
+    int fill_occ = 0;          // Config::pb_fill_occ: resident waves per CU of pass A (0: default)
+    int GB = 1, NG = 1;
+    unsigned long long *smeta = nullptr;
+    int *gstart = nullptr;
 };
 int pb_build_begin(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int64_t nnz, const int *rp, const int *ci,
                    const PbCols *cols, PbBuild *b);

@@ -89,6 +89,39 @@ __device__ __forceinline__ int col_to_cb(const PbCut &c, int col)
     return (q * c.chunks + ch) * c.bpc + off / c.CB;
 }
 
+// the same for the builders' inner loops: one slice, one piece (an unsharded copy) is a single division, done in double
+// precision (exact for 0 <= col < 2^31: the quotient of two integers below 2^31 differs from the next integer by more than
+// 2^-31, a double's relative error is 2^-53) -- three 32-bit integer divisions cost ~100 instructions of a wave otherwise
+__device__ __forceinline__ int col_to_cb_fast(const PbCut &c, double inv_cb, int col)
+{
+    if (c.chunks == 1 && col < c.per) {
+        int cb = (int)((double)col * inv_cb);
+        cb -= (long long)cb * c.CB > (long long)col ? 1 : 0;
+        cb += (long long)(cb + 1) * c.CB <= (long long)col ? 1 : 0;
+        return cb;
+    }
+    return col_to_cb(c, col);
+}
+
+// Rank of every active lane among the EARLIER active lanes holding the same key (0 <= key < nkeys <= 64), and for lane q <
+// nkeys the number of lanes holding key q.  One 64-bit word of LDS per key, owned by this wave: lanes OR their bit into
+// their key's word (integer ORs: any order of service gives the same word), read it back and count the bits below their own.
+// ~15 instructions for what a ballot per key costs ~10 each.
+__device__ __forceinline__ int wave_match_rank(unsigned long long *tab, int key, bool active, int lane, int nkeys, int *count_of_key_lane)
+{
+    if (lane < nkeys) tab[lane] = 0ULL;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (active) atomicOr(&tab[key], 1ULL << lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long mine = active ? tab[key] : 0ULL;
+    *count_of_key_lane = lane < nkeys ? __popcll(tab[lane]) : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return __popcll(mine & ((1ULL << lane) - 1ULL));
+}
+
 // The launch covers the sub-blocks [sub0, sub1) (the drop-in entry point fills a blocked copy piece by piece while the
 // values are still being uploaded: rows are independent here).
 template <bool FILL>
@@ -142,6 +175,233 @@ __global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_rows(int n, const int
     }
     if (!FILL)
         for (int c = lane; c < NCB; c += 64) bins[(size_t)c * NSUB + sub] = cur[c];
+}
+
+// ------------------------------------------------------------------ fill in two passes (round 5)
+// k_pb_rows<true> scatters every entry straight to its (column block, sub-block) segment: a wave keeps NCB (768 at C4)
+// write streams open for as long as it walks its sub-block, each fed 8 + 2 + 2 bytes at a time, and the partly written
+// 128-byte lines leave the L2 long before they are complete (55 GB moved for a 16 GB job, 41 ms at C4).  The same
+// permutation as a two-level partition whose streams stay few and whose runs are whole segments:
+//   pass A (k_pb_group)    a wave walks its sub-block as before but sorts the entries only by GROUP of GB consecutive
+//                          column blocks (<= 32 groups): <= 32 streams per wave, each fed ~1.5 entries per row, all inside
+//                          the wave's own contiguous scratch region [rp[row0], rp[row1]) -- value (8 B, or the 8-bit
+//                          dictionary index) into the product stream P (not needed before the first SpMV), packed
+//                          (column block, local column, local row) into an 8-byte scratch word;
+//   pass B (k_pb_scatter)  one wave per (sub-block, group) bucket (~1300 entries at C4, in (row, column) order): a stable
+//                          counting sort by column block -- ranks by ballot per block, no atomics, no order left to the
+//                          hardware -- gives every entry its place; the inverse permutation is kept in LDS (2 bytes per
+//                          entry) and the bucket is then written in DESTINATION order: GB whole (sub-block, column block)
+//                          segments, consecutive lanes to consecutive addresses.
+// The result is the array k_pb_rows<true> builds, bit for bit (tests: every blocked-SpMV test compares with the oracle).
+constexpr int kPbGroups = 32;            // pass-A streams per wave at most
+constexpr int kPbRpMax = 2047;           // rows of a sub-block whose row pointers pass A stages in LDS (longer sub-blocks read them from L2)
+constexpr int kPbBucketMax = 2048;       // entries of a bucket that is sorted in the wave's LDS slice (8-byte word + 2-byte index each)
+
+__device__ __forceinline__ unsigned long long pb_pack(int cb, int pc, int pr)
+{
+    return ((unsigned long long)(unsigned)cb << 32) | ((unsigned long long)(unsigned)(pc & 0xffff) << 16) | (unsigned long long)(unsigned)(pr & 0xffff);
+}
+
+// Count pass (the pattern only): entries of every (column block, sub-block) segment.  One wave per sub-block streams its
+// entries [rp[row0], rp[row1]) 64 at a time -- no per-row round trips -- and counts into LDS (integer adds: any order).
+__global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_count(int n, const int *rp, const int *ci, PbCut cut, int NCB, int SR, int NSUB,
+                                                                int *bins, int sub0, int sub1)
+{
+    extern __shared__ int lds_i[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub = sub0 + blockIdx.x * kPbBuildWaves + wave;
+    if (sub >= sub1) return;
+    int *cur = lds_i + (size_t)wave * NCB;
+    for (int c = lane; c < NCB; c += 64) cur[c] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const long long row0 = (long long)sub * SR;
+    const int row1 = (int)(row0 + SR < n ? row0 + SR : n);
+    const int e0 = row0 < n ? rp[row0] : rp[n], e1 = rp[row1];
+    const double inv_cb = 1.0 / (double)cut.CB;
+    for (int k0 = e0; k0 < e1; k0 += 256) {
+        int col[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) col[u] = k0 + 64 * u + lane < e1 ? ci[k0 + 64 * u + lane] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (col[u] >= 0) atomicAdd(&cur[col_to_cb_fast(cut, inv_cb, col[u])], 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < NCB; c += 64) bins[(size_t)c * NSUB + sub] = cur[c];
+}
+
+// gstart: [NSUB][NG + 1] first scratch entry of every (sub-block, group) bucket (written here, read by pass B)
+// The wave streams its sub-block's entries 64 at a time in CSR order (= (row, column) order); an entry of group g goes
+// behind the earlier entries of g: ranks by one ballot per group present, the groups' cursors live in lane g's register.
+__global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_group(int n, const int *rp, const int *ci, const double *val,
+                                                                const unsigned char *vidx, PbCut cut, const int *col0, int NCB,
+                                                                int SR, const int *slen, int GB, int NG, int *gstart,
+                                                                double *sval, unsigned char *sval8, unsigned long long *smeta,
+                                                                int sub0, int sub1)
+{
+    __shared__ unsigned long long tab_all[kPbBuildWaves][kPbGroups];
+    __shared__ int lrp_all[kPbBuildWaves][kPbRpMax + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub = sub0 + blockIdx.x * kPbBuildWaves + wave;
+    if (sub >= sub1) return;
+    unsigned long long *tab = tab_all[wave];
+    int *lrp = lrp_all[wave];
+    const int gshift = 31 - __builtin_clz(GB);                  // GB is a power of two
+    const double inv_cb = 1.0 / (double)cut.CB;
+    const long long row0 = (long long)sub * SR;
+    const int row1 = (int)(row0 + SR < n ? row0 + SR : n);
+    // entries of this sub-block per group, from the count pass's segment lengths: lane g sums its GB blocks
+    int cnt = 0;
+    if (lane < NG) {
+        const int *sl = slen + (size_t)sub * NCB;
+        for (int c = lane * GB; c < (lane + 1) * GB && c < NCB; c++) cnt += sl[c];
+    }
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    const int e0 = row0 < n ? rp[row0] : rp[n], e1 = rp[row1];
+    const int base = e0 - rp[0];
+    const int total = __builtin_amdgcn_readlane(inc, 63);      // (lanes >= NG add nothing)
+    int run = base + inc - cnt;                                 // lane g: next scratch slot of group g
+    if (lane < NG) gstart[(size_t)sub * (NG + 1) + lane] = run;
+    if (lane == NG) gstart[(size_t)sub * (NG + 1) + NG] = base + total;
+    // Nothing a chunk needs may wait for a load issued in that chunk (a wave walks ~640 chunks one after the other: every
+    // exposed round trip costs the launch ~1 us x 640): the sub-block's row pointers are staged in LDS once, the columns AND
+    // values of the next chunk are in flight while this one is placed, the local column follows from the block by arithmetic.
+    const int nrows = row1 - (int)row0;
+    const bool rp_lds = nrows <= kPbRpMax;
+    if (rp_lds)
+        for (int i = lane; i <= nrows; i += 64) lrp[i] = rp[row0 + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool one_piece = cut.chunks == 1 && cut.bpc >= NCB;   // one slice, one piece: block cb starts at column cb * CB
+    int rbase = 0;                                              // (row - row0) of the current chunk's first entry, or an empty row before it
+    int col_n = e0 + lane < e1 ? ci[e0 + lane] : -1;
+    double val_n = 0.0;
+    unsigned char vidx_n = 0;
+    if (e0 + lane < e1) { if (sval8) vidx_n = vidx[e0 + lane]; else val_n = val[e0 + lane]; }
+    for (int k0 = e0; k0 < e1; k0 += 64) {
+        const int k = k0 + lane;
+        const bool active = k < e1;
+        const int col = col_n;
+        const double v = val_n;
+        const unsigned char vi = vidx_n;
+        col_n = k + 64 < e1 ? ci[k + 64] : -1;
+        if (k + 64 < e1) { if (sval8) vidx_n = vidx[k + 64]; else val_n = val[k + 64]; }
+        int r = rbase;
+        if (active) {
+            if (rp_lds) { while (k >= lrp[r + 1]) r++; }        // (rows may be empty)
+            else { while (k >= rp[row0 + r + 1]) r++; }
+        }
+        const int cb = active ? col_to_cb_fast(cut, inv_cb, col) : 0;
+        const int g = cb >> gshift;
+        int added;
+        const int rank = wave_match_rank(tab, g, active, lane, NG, &added);
+        const int dest = __shfl(run, g, 64) + rank;
+        run += added;
+        if (active) {
+            if (sval8) sval8[dest] = vi;
+            else sval[dest] = v;
+            smeta[dest] = pb_pack(cb, col - (one_piece ? cb * cut.CB : col0[cb]), r);
+        }
+        // the last active lane's row starts the next chunk's search
+        const unsigned long long am = __ballot(active);
+        rbase = __builtin_amdgcn_readlane(r, 63 - __builtin_clzll(am));
+    }
+}
+
+constexpr int kPbScatterWaves = 4;
+__global__ __launch_bounds__(64 * kPbScatterWaves) void k_pb_scatter(int NCB, int NSUB, const int *slen, const int *bins, int GB, int NG,
+                                                                    const int *gstart, const double *sval, const unsigned char *sval8,
+                                                                    const unsigned long long *smeta, double *pv, unsigned char *pvi,
+                                                                    u16 *pc, u16 *pr, int sub0, int sub1)
+{
+    // 20 KB per wave: two workgroups (8 waves) per CU -- few enough for the buckets' value slices (8 B x ~1300 entries
+    // each), which the write-out gathers from, to stay in the XCD's L2
+    __shared__ unsigned long long raw_all[kPbScatterWaves][kPbBucketMax];
+    __shared__ u16 inv_all[kPbScatterWaves][kPbBucketMax];
+    __shared__ unsigned long long tab_all[kPbScatterWaves][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long bucket = (long long)blockIdx.x * kPbScatterWaves + wave;
+    const int sub = sub0 + (int)(bucket / NG), g = (int)(bucket % NG);
+    if (sub >= sub1) return;
+    u16 *inv = inv_all[wave];
+    unsigned long long *raw = raw_all[wave];
+    const int start = gstart[(size_t)sub * (NG + 1) + g], len = gstart[(size_t)sub * (NG + 1) + g + 1] - start;
+    if (len <= 0) return;
+    // lane c < GB: column block g * GB + c -- its entries in this bucket, their first position inside the bucket (blocks
+    // in order), and the first slot of its (column block, sub-block) segment in the copy
+    const int cbid = g * GB + lane;
+    const bool owner = lane < GB && cbid < NCB;
+    const int cnt = owner ? slen[(size_t)sub * NCB + cbid] : 0;
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    const int lbase = inc - cnt;
+    const int gdst = owner ? bins[(size_t)cbid * NSUB + sub] : 0;
+    const bool staged = len <= kPbBucketMax;
+    // stable ranks: the bucket is in (row, column) order; an entry of block c goes behind the earlier entries of c
+    int run = staged ? lbase : gdst;
+    unsigned long long m_next = lane < len ? smeta[start + lane] : 0ULL;       // the next chunk's words are in flight while this one is ranked
+    for (int k0 = 0; k0 < len; k0 += 64) {
+        const int k = k0 + lane;
+        const bool active = k < len;
+        const unsigned long long m = m_next;
+        m_next = k + 64 < len ? smeta[start + k + 64] : 0ULL;
+        const int cbl = active ? (int)(m >> 32) - g * GB : 0;
+        int added;
+        const int rank = wave_match_rank(tab_all[wave], cbl, active, lane, GB, &added);
+        const int r = __shfl(run, cbl, 64) + rank;
+        run += added;
+        if (active) {
+            if (staged) { inv[r] = (u16)k; raw[k] = m; }
+            else {           // a bucket too long for the LDS slice: straight to its place
+                if (pvi) pvi[r] = sval8[start + k];
+                else pv[r] = sval[start + k];
+                pc[r] = (u16)((m >> 16) & 0xffff);
+                pr[r] = (u16)(m & 0xffff);
+            }
+        }
+    }
+    if (!staged) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // destination order: position t of the sorted bucket is entry inv[t]; consecutive t of one block are consecutive slots
+    for (int t0 = 0; t0 < len; t0 += 256) {        // (uniform trip count: the lane shuffles below need every lane; four
+        unsigned long long m[4];                    // chunks' value gathers in flight together)
+        double v[4];
+        unsigned char vi[4];
+        int dest[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + 64 * u + lane;
+            const bool active = t < len;
+            const int loc = active ? (int)inv[t] : 0;
+            m[u] = raw[loc];
+            v[u] = 0.0;
+            vi[u] = 0;
+            if (active) { if (pvi) vi[u] = sval8[start + loc]; else v[u] = sval[start + loc]; }
+            const int cbl = active ? (int)(m[u] >> 32) - g * GB : 0;
+            dest[u] = __shfl(gdst, cbl, 64) + (t - __shfl(lbase, cbl, 64));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (t0 + 64 * u + lane < len) {
+                if (pvi) pvi[dest[u]] = vi[u];
+                else pv[dest[u]] = v[u];
+                pc[dest[u]] = (u16)((m[u] >> 16) & 0xffff);
+                pr[dest[u]] = (u16)(m[u] & 0xffff);
+            }
+        }
+    }
 }
 
 // ---- exclusive scan of the segment counts in storage order [column block][sub-block], on the device
@@ -236,8 +496,17 @@ static int round_blocks(int64_t n, int tile_max)
 // ---- staged construction: pb_build_begin (geometry, tables, count pass, scans: the PATTERN only) -> pb_build_values (the
 // value array: fp64 or 8-bit dictionary indices) -> pb_build_fill over sub-block ranges (any partition of [0, NSUB)) ->
 // pb_build_end.  pb_build is the four in a row; the drop-in entry point runs them while the matrix is still being uploaded.
+static void pb_scratch_free(PbBuild *b)
+{
+    if (b->smeta) CM_DROP(hipFree(b->smeta));
+    if (b->gstart) CM_DROP(hipFree(b->gstart));
+    b->smeta = nullptr;
+    b->gstart = nullptr;
+}
+
 void pb_build_abort(PbBuild *b)
 {
+    pb_scratch_free(b);
     if (b->bins) CM_DROP(hipFree(b->bins));
     b->bins = nullptr;
     pb_free(&b->p);
@@ -377,8 +646,22 @@ int pb_build_alloc(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int
         b->cut = PbCut{(int)p.per, p.chunks, (int)p.chunk_len, p.bpc, p.CB};
         if ((rc = dalloc(&p.sstart, nbins))) break;
         if ((rc = dalloc(&p.slen, nbins))) break;
-        if ((rc = set_max_lds((const void *)k_pb_rows<false>))) break;
+        if ((rc = set_max_lds((const void *)k_pb_count))) break;
         if ((rc = set_max_lds((const void *)k_pb_rows<true>))) break;
+        // the two-pass fill's scratch (see k_pb_group): one packed word per entry, the buckets' first entries
+        b->GB = 1;
+        while (b->GB * kPbGroups < p.NCB) b->GB *= 2;            // a power of two (group = block >> shift), <= kPbGroups groups
+        b->NG = (p.NCB + b->GB - 1) / b->GB;
+        b->fill_occ = cfg.pb_fill_occ;
+        b->two_pass = cfg.pb_fill2 != 0 && nnz > 0 && nnz < 0x7fffffffLL && p.SR <= 65536 && b->GB <= 64;
+        if (b->two_pass) {
+            if (dalloc(&b->smeta, (size_t)nnz) != CUDAMAT_OK || dalloc(&b->gstart, (size_t)p.NSUB * (size_t)(b->NG + 1)) != CUDAMAT_OK) {
+                // (no room for the scratch: the single-pass fill needs none)
+                if (b->smeta) CM_DROP(hipFree(b->smeta));
+                b->smeta = nullptr;
+                b->two_pass = false;
+            }
+        }
     } while (0);
     if (rc) pb_build_abort(b);
     return rc;
@@ -397,9 +680,7 @@ int pb_build_count(hipStream_t st, const Config &cfg, const int *rp, const int *
         const PbCut cut = b->cut;
         const unsigned grid = (unsigned)((p.NSUB + kPbBuildWaves - 1) / kPbBuildWaves);
         const size_t lds = sizeof(int) * (size_t)kPbBuildWaves * p.NCB;
-        hipLaunchKernelGGL(k_pb_rows<false>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, (const double *)nullptr, cut, p.col0,
-                           p.NCB, p.SR, p.NSUB, bins, (double *)nullptr, p.pc, p.pr, (const unsigned char *)nullptr, (unsigned char *)nullptr,
-                           0, p.NSUB);
+        hipLaunchKernelGGL(k_pb_count, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, n, rp, ci, cut, p.NCB, p.SR, p.NSUB, bins, 0, p.NSUB);
         if (hipGetLastError() != hipSuccess) { rc = CUDAMAT_ERR_HIP; set_error("pb count launch failed"); break; }
         hipLaunchKernelGGL(k_pb_colsum, dim3(p.NCB), dim3(kBlock), 0, st, p.NSUB, bins, p.cstart);   // cstart doubles as scratch
         hipLaunchKernelGGL(k_pb_colscan, dim3(1), dim3(kBlock), 0, st, p.NCB, p.cstart, p.cstart, align);
@@ -440,9 +721,29 @@ int pb_build_fill(hipStream_t st, PbBuild *b, const int *rp, const int *ci, cons
     if (sub1 > p.NSUB) sub1 = p.NSUB;
     if (sub1 <= sub0) return CUDAMAT_OK;
     const unsigned grid = (unsigned)((sub1 - sub0 + kPbBuildWaves - 1) / kPbBuildWaves);
-    const size_t lds = sizeof(int) * (size_t)kPbBuildWaves * p.NCB;
-    hipLaunchKernelGGL(k_pb_rows<true>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, p.n, rp, ci, val, b->cut, p.col0,
-                       p.NCB, p.SR, p.NSUB, b->bins, p.pv, p.pc, p.pr, p.pvi ? vd->idx : (const unsigned char *)nullptr, p.pvi, sub0, sub1);
+    const unsigned char *vidx = p.pvi ? vd->idx : (const unsigned char *)nullptr;
+    const int cfg_fill_occ = b->fill_occ;
+    if (b->two_pass) {
+        // the product stream is free until the first SpMV: it carries the values between the passes
+        // (dynamic LDS the kernel never touches caps the resident waves per CU)
+        // (PB_FILL_OCC, probing only: measured flat between 4 and 16 waves per CU)
+        size_t pad = 0;
+        if (cfg_fill_occ > 0) {
+            const size_t per_wg = (size_t)(160 * 1024) / (size_t)((cfg_fill_occ + kPbBuildWaves - 1) / kPbBuildWaves);
+            pad = per_wg > 40 * 1024 ? per_wg - 40 * 1024 : 0;
+            if (pad > 64 * 1024) pad = 64 * 1024;
+        }
+        hipLaunchKernelGGL(k_pb_group, dim3(grid), dim3(64 * kPbBuildWaves), pad, st, p.n, rp, ci, val, vidx, b->cut, p.col0, p.NCB, p.SR,
+                           p.slen, b->GB, b->NG, b->gstart, p.P, p.pvi ? (unsigned char *)p.P : (unsigned char *)nullptr, b->smeta, sub0, sub1);
+        const long long buckets = (long long)(sub1 - sub0) * b->NG;
+        hipLaunchKernelGGL(k_pb_scatter, dim3((unsigned)((buckets + kPbScatterWaves - 1) / kPbScatterWaves)), dim3(64 * kPbScatterWaves), 0, st,
+                           p.NCB, p.NSUB, p.slen, b->bins, b->GB, b->NG, b->gstart, p.P, p.pvi ? (const unsigned char *)p.P : (const unsigned char *)nullptr,
+                           b->smeta, p.pv, p.pvi, p.pc, p.pr, sub0, sub1);
+    } else {
+        const size_t lds = sizeof(int) * (size_t)kPbBuildWaves * p.NCB;
+        hipLaunchKernelGGL(k_pb_rows<true>, dim3(grid), dim3(64 * kPbBuildWaves), lds, st, p.n, rp, ci, val, b->cut, p.col0,
+                           p.NCB, p.SR, p.NSUB, b->bins, p.pv, p.pc, p.pr, vidx, p.pvi, sub0, sub1);
+    }
     if (hipGetLastError() != hipSuccess) { set_error("pb fill launch failed"); pb_build_abort(b); return CUDAMAT_ERR_HIP; }
     return CUDAMAT_OK;
 }
@@ -472,6 +773,7 @@ int pb_build_end(hipStream_t st, PbBuild *b, PbPlan *out)
 {
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("pb fill failed"); pb_build_abort(b); return CUDAMAT_ERR_HIP; }
     if (b->verbose) pb_print_plan(b->p);
+    pb_scratch_free(b);
     CM_DROP(hipFree(b->bins));
     b->bins = nullptr;
     b->p.build_seconds = now_s() - b->t0;
