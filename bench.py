@@ -400,6 +400,8 @@ def main():
     os.dup2(2, 1)
     try:
         out = run_bench(args)
+        if os.environ.get("CUDAMAT_BENCH_OTHER_CONFIGS") == "off":      # (scripts that profile or A/B the headline alone)
+            args.other_configs = "off"
         headline = (args.workload == "rand50" and args.rows == 10_000_000 and args.per_row == 50 and args.precond == "none"
                     and args.loop == "pbicgstab")
         if out is not None and out.get("n_gpus") == 1 and headline and args.other_configs != "off":

@@ -193,9 +193,12 @@ __global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_rows(int n, const int
 //                          entry) and the bucket is then written in DESTINATION order: GB whole (sub-block, column block)
 //                          segments, consecutive lanes to consecutive addresses.
 // The result is the array k_pb_rows<true> builds, bit for bit (tests: every blocked-SpMV test compares with the oracle).
-constexpr int kPbGroups = 32;            // pass-A streams per wave at most
+constexpr int kPbGroups = 32;            // pass-A streams per wave at most (one lane per group: <= 64).  48 groups x 1024-entry buckets
+                                         // measured 8.6 + 4.9 ms per C4 copy against 7.0 + 6.0 ms with 32 x 2048: more streams cost pass A
+                                         // what the shorter buckets save pass B
+static_assert(kPbGroups <= 64, "one lane per group");
 constexpr int kPbRpMax = 2047;           // rows of a sub-block whose row pointers pass A stages in LDS (longer sub-blocks read them from L2)
-constexpr int kPbBucketMax = 2048;       // entries of a bucket that is sorted in the wave's LDS slice (8-byte word + 2-byte index each)
+constexpr int kPbBucketMax = 2048;       // entries of a bucket that is sorted in the wave's LDS slice (7 bytes each)
 
 __device__ __forceinline__ unsigned long long pb_pack(int cb, int pc, int pr)
 {
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(64 * kPbBuildWaves) void k_pb_group(int n, const in
     const int total = __builtin_amdgcn_readlane(inc, 63);      // (lanes >= NG add nothing)
     int run = base + inc - cnt;                                 // lane g: next scratch slot of group g
     if (lane < NG) gstart[(size_t)sub * (NG + 1) + lane] = run;
-    if (lane == NG) gstart[(size_t)sub * (NG + 1) + NG] = base + total;
+    if (lane == 0) gstart[(size_t)sub * (NG + 1) + NG] = base + total;      // (NG may be 64: there is no lane NG)
     // Nothing a chunk needs may wait for a load issued in that chunk (a wave walks ~640 chunks one after the other: every
     // exposed round trip costs the launch ~1 us x 640): the sub-block's row pointers are staged in LDS once, the columns AND
     // values of the next chunk are in flight while this one is placed, the local column follows from the block by arithmetic.
@@ -321,9 +324,11 @@ __global__ __launch_bounds__(64 * kPbScatterWaves) void k_pb_scatter(int NCB, in
                                                                     const unsigned long long *smeta, double *pv, unsigned char *pvi,
                                                                     u16 *pc, u16 *pr, int sub0, int sub1)
 {
-    // 20 KB per wave: two workgroups (8 waves) per CU -- few enough for the buckets' value slices (8 B x ~1300 entries
-    // each), which the write-out gathers from, to stay in the XCD's L2
-    __shared__ unsigned long long raw_all[kPbScatterWaves][kPbBucketMax];
+    // 7 bytes per entry and wave (local column | local row, block inside the group, inverse permutation): 14.5 KB per wave,
+    // two workgroups (8 waves) per CU -- the first version kept the 8-byte word (20.5 KB per wave: ONE workgroup per CU,
+    // 7.8 ms at C4 for work that is a chain of ~40 short steps per wave)
+    __shared__ unsigned raw_all[kPbScatterWaves][kPbBucketMax];
+    __shared__ unsigned char cbl_all[kPbScatterWaves][kPbBucketMax];
     __shared__ u16 inv_all[kPbScatterWaves][kPbBucketMax];
     __shared__ unsigned long long tab_all[kPbScatterWaves][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -331,7 +336,8 @@ __global__ __launch_bounds__(64 * kPbScatterWaves) void k_pb_scatter(int NCB, in
     const int sub = sub0 + (int)(bucket / NG), g = (int)(bucket % NG);
     if (sub >= sub1) return;
     u16 *inv = inv_all[wave];
-    unsigned long long *raw = raw_all[wave];
+    unsigned *raw = raw_all[wave];
+    unsigned char *cbs = cbl_all[wave];
     const int start = gstart[(size_t)sub * (NG + 1) + g], len = gstart[(size_t)sub * (NG + 1) + g + 1] - start;
     if (len <= 0) return;
     // lane c < GB: column block g * GB + c -- its entries in this bucket, their first position inside the bucket (blocks
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(64 * kPbScatterWaves) void k_pb_scatter(int NCB, in
         const int r = __shfl(run, cbl, 64) + rank;
         run += added;
         if (active) {
-            if (staged) { inv[r] = (u16)k; raw[k] = m; }
+            if (staged) { inv[r] = (u16)k; raw[k] = (unsigned)(m & 0xffffffffULL); cbs[k] = (unsigned char)cbl; }
             else {           // a bucket too long for the LDS slice: straight to its place
                 if (pvi) pvi[r] = sval8[start + k];
                 else pv[r] = sval[start + k];
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(64 * kPbScatterWaves) void k_pb_scatter(int NCB, in
     __builtin_amdgcn_wave_barrier();
     // destination order: position t of the sorted bucket is entry inv[t]; consecutive t of one block are consecutive slots
     for (int t0 = 0; t0 < len; t0 += 256) {        // (uniform trip count: the lane shuffles below need every lane; four
-        unsigned long long m[4];                    // chunks' value gathers in flight together)
+        unsigned m[4];                              // chunks' value gathers in flight together)
         double v[4];
         unsigned char vi[4];
         int dest[4];
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(64 * kPbScatterWaves) void k_pb_scatter(int NCB, in
             v[u] = 0.0;
             vi[u] = 0;
             if (active) { if (pvi) vi[u] = sval8[start + loc]; else v[u] = sval[start + loc]; }
-            const int cbl = active ? (int)(m[u] >> 32) - g * GB : 0;
+            const int cbl = active ? (int)cbs[loc] : 0;
             dest[u] = __shfl(gdst, cbl, 64) + (t - __shfl(lbase, cbl, 64));
         }
 #pragma unroll

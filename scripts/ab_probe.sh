@@ -1,3 +1,4 @@
+export CUDAMAT_BENCH_OTHER_CONFIGS=off   # the headline alone: no side sections (bench.py other_configs) under a profiler / in an A/B
 # A/B on ONE box: cuda_mat_amd/libbase.so.keep (baseline build) vs the current libcudamat_hip.so, alternating
 cd /root/repo
 cp cuda_mat_amd/libcudamat_hip.so /tmp/new.so

@@ -1,3 +1,4 @@
+export CUDAMAT_BENCH_OTHER_CONFIGS=off   # the headline alone: no side sections (bench.py other_configs) under a profiler / in an A/B
 for a in "--workload poisson5" "--precond ilu0 --steps 10" "--precond bjilu0 --steps 10" "--workload mat10000 --steps 500 --warmup 50" "--loop pipelined --workload poisson5" "--workload mat10000 --loop pipelined --steps 500 --warmup 50" "--rows 2000000 --precond ilu0 --steps 10"; do
   python bench.py $a --cpu-baseline off 2>/tmp/err.txt | python -c "
 import json,sys

@@ -1,11 +1,12 @@
 #!/bin/bash
+export CUDAMAT_BENCH_OTHER_CONFIGS=off   # the headline alone: no side sections (bench.py other_configs) under a profiler / in an A/B
 # GPU box: is the five-launch loop host-bound at mid sizes?  Kernel-trace busy fraction of the timed region for Poisson systems
 # of a few sizes: sum of kernel durations / (last end - first start) over the last 60 % of the trace's loop kernels.
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out
 for rows in ${1:-400000 1000000 3000000}; do
   rm -rf $O/busy_$rows
-  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/busy_$rows -- python3 $R/bench.py --workload poisson5 --rows $rows --nx 1000 --steps 400 --warmup 50 --cpu-baseline off --drop-in off > $O/busy_$rows.json 2>/dev/null
+  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/busy_$rows -- python3 $R/bench.py --workload poisson5 --rows $rows --nx 1000 --steps 400 --warmup 50 --cpu-baseline off --drop-in off --other-configs off > $O/busy_$rows.json 2>/dev/null
   python3 - $O/busy_$rows $rows $O/busy_$rows.json <<'PY'
 import csv, glob, json, sys
 d, rows, js = sys.argv[1:4]

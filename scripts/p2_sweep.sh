@@ -1,4 +1,5 @@
 #!/bin/bash
+export CUDAMAT_BENCH_OTHER_CONFIGS=off   # the headline alone: no side sections (bench.py other_configs) under a profiler / in an A/B
 # GPU box: phase 2 of the blocked SpMV on a G = 8 shard and on the full matrix -- resident waves vs loads in flight
 # (CUDAMAT_PB_MIN_WAVES x CUDAMAT_PB_DEPTH), scripts/rank_probe.py's standard loop line.  usage: scripts/p2_sweep.sh
 mkdir -p gpurun_out/p2sweep

@@ -6,7 +6,7 @@ for kv in "$@"; do export "$kv"; done
 for c in FETCH_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum" "TCP_PENDING_STALL_CYCLES_sum" "TA_BUSY_avr"; do
   tag=$(echo $c | tr ' ' '_')
   rm -rf $O/pmc3q_$tag
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc3q_$tag -- python3 /root/repo/bench.py --workload poisson5 --steps 10 --warmup 2 --cpu-baseline off --drop-in off > /dev/null 2>&1 || echo "pass $c failed"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc3q_$tag -- python3 /root/repo/bench.py --workload poisson5 --steps 10 --warmup 2 --cpu-baseline off --drop-in off --other-configs off > /dev/null 2>&1 || echo "pass $c failed"
 done
 python3 - <<'PY'
 import csv,glob,collections

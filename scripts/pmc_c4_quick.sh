@@ -6,7 +6,7 @@ for kv in "$@"; do export "$kv"; done
 for c in "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum" "TCC_EA0_RDREQ_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TCC_WRITE_REQ_sum" "TCP_TOTAL_ACCESSES_sum"; do
   tag=$(echo $c | tr ' ' '_')
   rm -rf $O/pmc4q_$tag
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc4q_$tag -- python3 /root/repo/bench.py --steps 3 --warmup 1 --cpu-baseline off --drop-in off > /dev/null 2>&1 || echo "pass $c failed"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc4q_$tag -- python3 /root/repo/bench.py --steps 3 --warmup 1 --cpu-baseline off --drop-in off --other-configs off > /dev/null 2>&1 || echo "pass $c failed"
 done
 python3 - <<'PY'
 import csv,glob,collections

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CUDAMAT_BENCH_OTHER_CONFIGS=off   # the headline alone: no side sections (bench.py other_configs) under a profiler / in an A/B
 # usage: scripts/pmc_one.sh <name> <kernel substring> <bench args...>   (GPU box) -- FETCH_SIZE / WRITE_SIZE of one kernel
 cd /tmp && export TMPDIR=/tmp
 name=$1; kern=$2; shift 2

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CUDAMAT_BENCH_OTHER_CONFIGS=off   # the headline alone: no side sections (bench.py other_configs) under a profiler / in an A/B
 # kernel-trace of the C5 bench (run on the GPU box); prints the top kernels
 cd /tmp && export TMPDIR=/tmp
 O=/root/repo/gpurun_out/prof_ilu_$1

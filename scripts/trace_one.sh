@@ -1,4 +1,5 @@
 #!/bin/bash
+export CUDAMAT_BENCH_OTHER_CONFIGS=off   # the headline alone: no side sections (bench.py other_configs) under a profiler / in an A/B
 # GPU box: ONE rocprofv3 kernel-trace pass of bench.py (no counters) -> gpurun_out/trace_<name>/ and a per-kernel summary on stdout
 # usage: trace_one.sh <name> <bench args...>
 cd /tmp && export TMPDIR=/tmp

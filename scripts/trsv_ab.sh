@@ -1,4 +1,5 @@
 #!/bin/bash
+export CUDAMAT_BENCH_OTHER_CONFIGS=off   # the headline alone: no side sections (bench.py other_configs) under a profiler / in an A/B
 # GPU box: C5 per-application time of L^-1 U^-1, alternating env configurations R times
 # usage: scripts/trsv_ab.sh R "ENV=.. ENV=.." "ENV=.." ...
 R=$1; shift

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CUDAMAT_BENCH_OTHER_CONFIGS=off   # the headline alone: no side sections (bench.py other_configs) under a profiler / in an A/B
 # GPU box: C5 (ILU(0), 1e7 x 50) per-application time of L^-1 U^-1 over the knobs of the hybrid solve
 # usage: scripts/trsv_sweep.sh "K1 K2 ..." "LANES1 ..." [extra env ...]
 Ks=${1:-"5 8 12 16"}; Ls=${2:-"4"}; shift 2
