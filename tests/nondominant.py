@@ -209,14 +209,23 @@ def compare_loop(O, A, b, loop, vm, gpu, maxit, tol, k_nb_plain=None):
 
 
 def compare_factors(vm, lu):
-    """ILU(0) values of the HIP path against the oracle's: findings (list of strings)"""
+    """ILU(0) values of the HIP path against the oracle's: findings (list of strings).  Three regimes by the growth of
+    the oracle's factors: moderate (|entries| < 1e12: every entry to rtol 1e-11), large but finite (99 % of the entries to
+    1e-8: what has passed through a cancellation at 1e12+ carries no bits to compare), and an OVERFLOWING factorisation
+    (non-finite entries, or magnitudes beyond 1e150 that the next update squares): there the row updates' fma on the GPU
+    against two roundings in the oracle decide which entries end as inf, as NaN or as 1e300 -- asserted is only that the
+    GPU's factorisation blew up as well."""
     fin = np.isfinite(vm)
-    if not np.array_equal(fin, np.isfinite(lu)):
-        return ["the finite / non-finite patterns of the factors differ"]
     with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
-        rel = np.abs(lu[fin] - vm[fin]) / np.maximum(np.abs(vm[fin]), 1e-300)
-    if np.nanmax(np.abs(vm)) < 1e12:
+        big = float(np.max(np.abs(vm[fin]))) if fin.any() else np.inf
+        if not fin.all() or big >= 1e150:
+            fl = np.isfinite(lu)
+            blew = (not fl.all()) or (fl.any() and float(np.max(np.abs(lu[fl]))) >= 1e100)
+            return [] if blew else ["the oracle's factorisation overflows (max %.1e, %d non-finite), the GPU's does not" % (big, int((~fin).sum()))]
+        if not np.isfinite(lu).all():
+            return ["non-finite factor entries on the GPU only (oracle max %.1e)" % big]
+        rel = np.abs(lu - vm) / np.maximum(np.abs(vm), 1e-300)
+    if big < 1e12:
         return [] if rel.max() <= 1e-11 else ["factors differ by %.2e (rtol 1e-11)" % rel.max()]
-    # the factorisation itself overflows (example1000_p90: |u| up to 4e252): the same blow-up on both sides
-    ok = np.nanmax(np.abs(lu[fin])) > 1e100 and np.nanquantile(rel, 0.99) <= 1e-8
-    return [] if ok else ["overflowing factors: 99 %% quantile of the relative difference %.2e" % np.nanquantile(rel, 0.99)]
+    q = float(np.quantile(rel, 0.99))
+    return [] if q <= 1e-8 else ["large factors (max %.1e): 99 %% quantile of the relative difference %.2e" % (big, q)]

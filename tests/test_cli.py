@@ -44,6 +44,32 @@ def test_cli_rejects_unknown_switch_and_missing_file(built):
 
 
 @pytest.mark.gpu
+def test_cli_draws_the_reference_random_systems(built):
+    """no -M: the CLI builds the reference's random system (example.cpp:274-288) from libc rand() -- unseeded, i.e. the
+    srand(1) stream, as upstream -- and prints `nnz=` before it solves: the counts are those of the oracle's restatement of
+    the recipe (oracle.example_system), which the GPU parity tests solve.  (Like upstream, the CLI looks for its device
+    first: without one it ends before the matrix is drawn.)"""
+    from oracle import oracle as O
+    for args, dim, pz in ((["-N40", "-R0.5"], 40, 0.5), ([], 10000, 0.99)):
+        r = subprocess.run([built] + args + ["-I3"], capture_output=True, text=True)
+        A, b = O.example_system(dim, pz, 0.2, 1)
+        assert "nnz=%d\n" % A.nnz in r.stdout, r.stdout[-300:]
+    assert A.nnz == 1007629
+
+
+@pytest.mark.gpu
+def test_cli_default_workload_ends_as_the_reference_loop_would(built):
+    """`example` with no arguments (example.cpp:173-180: n = 10000, P(0) = 0.99, ILU(0), maxit 2000, tol 1e-6): the factors
+    blow the first direction up and the residual is NaN from the second iteration on (tests/test_gpu_nondominant.py has the
+    oracle comparison).  Upstream spins to maxit on NaNs and prints "success" whatever happened (pbicgstab.cu:408); here
+    the run stops at the NaN and says "method failed" with a non-zero exit status."""
+    r = subprocess.run([built, "-D"], capture_output=True, text=True)
+    assert "nnz=1007629" in r.stdout and "N=10000, nnz=1007629" in r.stdout
+    assert r.returncode != 0 and "method failed" in r.stderr and "success" not in r.stdout
+    assert "i = 0, residual norm (before precond)" in r.stdout and "i = 2," not in r.stdout
+
+
+@pytest.mark.gpu
 def test_cli_solves_the_shipped_fixtures(built):
     # the reference's own usage lines (example.cpp:188-190)
     r = subprocess.run([built, "-M" + os.path.join(GOLD, "mat10000.mtx")], capture_output=True, text=True)
