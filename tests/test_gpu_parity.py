@@ -559,6 +559,47 @@ def test_lds_order_probe_guards_the_default_blocked_form(cm, ctx, oracle, sw, ca
     np.testing.assert_array_equal(x_forced, x_default)
 
 
+@pytest.mark.parametrize("case", ["rand_real", "long_rows", "empty_and_dense", "few_values", "wide_sub_blocks"])
+def test_two_pass_fill_builds_the_copy_the_single_pass_kernel_builds(cm, ctx, oracle, case, sw):
+    """csrc/spmv_pb.hip, round 5: the blocked copy is filled by a two-level partition (k_pb_group: by group of column blocks
+    into the wave's scratch region; k_pb_scatter: a stable counting sort per bucket, written in destination order) instead of
+    k_pb_rows<true>'s 768 write streams per wave.  Same copy, bit for bit: the SpMV through either is the oracle's -- rows
+    longer than a wave, empty rows, a dense row (a bucket longer than the LDS slice: straight to its place), a value
+    dictionary (8-bit indices travel instead of values), sub-blocks of more rows than the LDS holds row pointers for."""
+    sw("SPMV_MODE", "pb")
+    rng = np.random.default_rng(23)
+    if case == "rand_real":
+        A = oracle.rand_rows(30000, 40, 7, base=1)
+        A.val[:] = rng.standard_normal(A.nnz)
+    elif case == "long_rows":
+        A = _real_sparse(oracle, 2500, 0.12, 3)                   # ~300 entries per row
+    elif case == "few_values":
+        A = oracle.rand_rows(40000, 24, 9)                        # integer values from a set of 4 + diagonals: a value dictionary
+        sw("VALUE_DICT", 1)
+    elif case == "wide_sub_blocks":
+        sw("PB_MIN_WAVES", 1024)                                  # 1024 sub-blocks of 2198 rows: row pointers read from L2, not LDS
+        A = oracle.poisson5(1500, 1500)
+        A.val[:] = rng.standard_normal(A.nnz)
+    else:
+        import scipy.sparse as sp
+        n = 20000
+        S = sp.random(n, n, density=0.0008, random_state=5, format="lil")
+        S[7, :] = 1.0                                             # one dense row
+        for r in (0, 5, 11, n - 1):
+            S[r, :] = 0                                           # empty rows
+        S = S.tocsr()
+        S.data[:] = rng.standard_normal(S.nnz)
+        S.sort_indices()
+        A = oracle.Csr(n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64), n)
+    x = rng.standard_normal(A.n)
+    d = rng.standard_normal(A.n)
+    want, want_d = oracle.spmv(A, x), oracle.csrmv(A, 1.0, x, 1.0, x * d)
+    for fill2 in ("1", "0"):
+        sw("PB_FILL2", fill2)
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x), want)
+        np.testing.assert_array_equal(_spmv_via_solver(cm, ctx, A, x, d=d), want_d)
+
+
 def test_blocked_spmv_in_the_solver_loop(cm, ctx, oracle, golden_dir, sw):
     """same solves as above with the blocked kernels forced: fused dots, freeze prologue, ILU path"""
     sw("SPMV_MODE", "pb")
