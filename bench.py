@@ -28,10 +28,26 @@ T_START = time.time()
 # may use are counted first (libgomp binds the initial thread to ONE place once OMP_PROC_BIND is set, after which
 # sched_getaffinity reports a single CPU)
 try:
-    HOST_CPUS = len(os.sched_getaffinity(0))
+    HOST_CPU_SET = set(os.sched_getaffinity(0))
+    HOST_CPUS = len(HOST_CPU_SET)
 except AttributeError:
+    HOST_CPU_SET = None
     HOST_CPUS = os.cpu_count() or 1
 os.environ.setdefault("OMP_PROC_BIND", "spread")
+
+
+def unpin_main_thread():
+    """OMP_PROC_BIND makes libgomp bind the INITIAL thread to one CPU the moment the library is loaded -- which `import torch`
+    does -- and every thread created afterwards inherits that mask: the HIP runtime's helpers and the library's uploader
+    thread would all share CPU 0 with the main thread.  On a box whose CPU 0 is busy that showed as uploads at 11-18 GB/s
+    instead of 54 and allocation-heavy set-up stages 3-8 x longer (round 5: two of seven boxes; scripts/setup_probe.py, which
+    never sets the variable, was fast on every box).  The OpenMP team of the CPU baseline keeps its places; only this thread
+    -- and what it starts -- goes back to the CPUs the process was given."""
+    if HOST_CPU_SET:
+        try:
+            os.sched_setaffinity(0, HOST_CPU_SET)
+        except OSError:
+            pass
 
 
 
@@ -449,6 +465,7 @@ def other_configs(args):
 
 def run_bench(args):
     import torch
+    unpin_main_thread()
     import cuda_mat_amd as cm
     from cuda_mat_amd.dist import RcclComm, TorchComm, shard_rows
 
@@ -742,7 +759,11 @@ def run_bench(args):
                     t1 = time.perf_counter()
                     xh, sth = cm_api._solve(n, nz, va_h, rp_h, ci_h, None, None, b_h, precond, cm.LOOP_PBICGSTAB, 200, 1e-8, False)
                     wall = time.perf_counter() - t1
-                    calls.append({"end_to_end_s": wall, "upload_s": sth.t_upload, "setup_s": sth.t_setup, "tune_s": sth.t_tune,
+                    calls.append({"end_to_end_s": wall, "upload_s": sth.t_upload,
+                                  # (the host side of a box shows here: 51-54 GB/s on most boxes of the pool, 11-18 GB/s on some,
+                                  # where allocation-heavy set-up stages are slow as well -- DESIGN 6a)
+                                  "upload_gbs": (12.0 * nz + 4.0 * (n + 1) + 8.0 * n) / sth.t_upload / 1e9 if sth.t_upload > 0 else None,
+                                  "setup_s": sth.t_setup, "tune_s": sth.t_tune,
                                   "analysis_s": sth.t_analysis, "factor_s": sth.t_factor,
                                   "loop_s": sth.t_solve, "library_total_s": sth.t_total, "iters": sth.iters,
                                   "converged": bool(sth.converged), "spmv_mode": sth.spmv_mode, "plan_reused": sth.plan_reused,

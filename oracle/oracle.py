@@ -213,7 +213,7 @@ def levels(A, upper=False):
 def pbicgstab(A, f, x0=None, vm=None, maxit=2000, tol=1e-6, want_hist=False, want_trace=False):
     """pbicgstab.cu:45-154 (x0 defaults to ones, :306-308).
     want_trace: also return the loop's scalars, one row per iteration started:
-    (rho, sum|rw_j r_j|, rw.v, sum|rw_j v_j|, alpha, t.r, t.t, omega) -- see noise_breakdown()."""
+    (rho, sum|rw_j r_j|, rw.v, sum|rw_j v_j|, alpha, t.r, t.t, omega) -- tests/nondominant.py noise_breakdown() reads it."""
     x = np.ones(A.n) if x0 is None else _f(x0).copy()
     st = Stats()
     hist = np.full(2 * maxit, np.nan) if (want_hist or want_trace) else None
@@ -228,19 +228,6 @@ def pbicgstab(A, f, x0=None, vm=None, maxit=2000, tol=1e-6, want_hist=False, wan
         started = min(maxit, st.iters + (1 if st.half_exit else 0))
         return x, st, hist, trace[:started]
     return (x, st, hist) if want_hist else (x, st)
-
-
-def noise_breakdown(trace, n):
-    """first iteration of a pbicgstab() trace whose rho (pbicgstab.cu:81) or rw.v (:106) is no larger than the worst-case
-    rounding error of its own summation, n eps sum|a_j b_j| -- from there on the reference's unguarded loop (:84,107)
-    divides rounding noise by rounding noise; also counts a rho / rw.v / t.t that is exactly 0 or not finite.  None: never."""
-    eps = np.finfo(np.float64).eps
-    with np.errstate(invalid="ignore"):
-        bad = ((np.abs(trace[:, 0]) <= n * eps * trace[:, 1]) | ~np.isfinite(trace[:, 0])
-               | (np.abs(trace[:, 2]) <= n * eps * trace[:, 3]) | (~np.isfinite(trace[:, 2]) & np.isfinite(trace[:, 1]))
-               | (trace[:, 6] == 0.0))
-    w = np.nonzero(bad)[0]
-    return int(w[0]) if w.size else None
 
 
 PIPE_RR = 32        # residual replacement period of the pipelined loop (csrc/solver.hip kPipeRR)
