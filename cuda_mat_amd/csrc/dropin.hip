@@ -266,8 +266,10 @@ int build_or_reuse_candidate(cudamat_ctx *ctx, const Config &cfg, const HostSyst
 // stream of the device), and an upload that shares the process with them was measured at a sixth of its speed.
 // speculative = false (the retry after an out-of-memory call): nothing is allocated ahead of the pattern; the SpMV form is
 // then chosen, and its copy built, after the upload by ensure_spmv_mode like in the staged cudamat_solver_create path.
+// precond == CUDAMAT_PRECOND_ILU0: the pattern-only part of the ILU(0) set-up (diagonal positions, level analysis of L and U:
+// 32 ms at C5) runs as soon as the pattern has landed, beside the upload of the values (round 5).
 int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h, double *d_b, double *d_x, double *d_d,
-                        cudamat_solver **s_out, double *t_up, bool speculative = true)
+                        cudamat_solver **s_out, double *t_up, bool speculative = true, int precond = CUDAMAT_PRECOND_NONE)
 {
     const double t0 = now_s();
     const int n = h.n, nnz = h.nnz, base = h.base;
@@ -370,6 +372,12 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
                     piecewise = true;
                 }
             }
+            // ---- the level analysis of the preconditioner needs the pattern only: its kernels (and the host's waits for their
+            // read-backs) fit into the time the values take to arrive; the fill pieces below queue up behind them
+            if (precond == CUDAMAT_PRECOND_ILU0 && cfg.early_analysis) {
+                if ((rc = ilu0_analyse_early(s))) break;
+                stamp("ILU(0) level analysis done (beside the upload)");
+            }
             // ---- values: piece by piece into the blocked copy, or all at once behind the dictionary
             if (piecewise) {
                 int sub_done = 0;
@@ -455,7 +463,7 @@ int solve_host_locked(const Config &cfg, const HostSystem &h, bool speculative, 
         if (candidate) {
             if ((rc = build_or_reuse_candidate(ctx, cfg, h, d_b, d_x, d_d, &s, &reused, &t_up))) break;
         } else {
-            if ((rc = build_beside_upload(ctx, cfg, h, d_b, d_x, d_d, &s, &t_up, speculative))) break;
+            if ((rc = build_beside_upload(ctx, cfg, h, d_b, d_x, d_d, &s, &t_up, speculative, precond))) break;
         }
         if (g_cache.d_d && !reused) { cudamat_free(ctx, g_cache.d_d); g_cache.d_d = nullptr; }
         if ((rc = cudamat_solver_set_shift(s, d_d))) break;

@@ -52,6 +52,10 @@ struct TriHost {   // host-side launch plan kept next to the TriFactor
 struct IluPlans {
     cm::TriHost L, U;
     int *err_host = nullptr, *err_dev = nullptr;   // pinned word a timed-out spin of k_trsv_syncfree sets
+    // between the pattern-only analysis and the numeric part of ilu0_setup (the drop-in call runs the former beside its upload)
+    int *d_flags = nullptr, *d_lev = nullptr;
+    int maxrow_all = 0;
+    bool analysed = false;
     // level-major index spaces (both factors hybrid): U-position of every original row (the column map of the permuted
     // matrix, solver.hip ensure_perm_matrix), scratch vectors of the original-space wrapper (precond_apply_any)
     int *posU = nullptr;

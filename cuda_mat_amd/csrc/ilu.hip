@@ -387,6 +387,8 @@ int ilu0_release(cudamat_solver *s)
             free_levels(*h);
         }
         if (pl->err_host) CM_DROP(hipHostFree(pl->err_host));
+        if (pl->d_flags) CM_DROP(hipFree(pl->d_flags));
+        if (pl->d_lev) CM_DROP(hipFree(pl->d_lev));
         if (pl->posU) CM_DROP(hipFree(pl->posU));
         if (pl->perm_a) CM_DROP(hipFree(pl->perm_a));
         if (pl->perm_b) CM_DROP(hipFree(pl->perm_b));
@@ -1133,12 +1135,11 @@ static int select_precond_matrix(cudamat_solver *s)
     return rc;       // on failure ilu0_setup's error path releases the partial copy
 }
 
-int ilu0_setup(cudamat_solver *s, bool block)
+// The PATTERN-ONLY part of the set-up (pbicgstab.cu:336-347: the two csrsv analyses; plus the diagonal positions and the
+// longest row): needs rp / ci only, so the drop-in entry point runs it while the values are still being uploaded
+// (ilu0_analyse_early); ilu0_setup runs it itself when nobody has.  Leaves its scratch (flags, levels) in the plans.
+static int ilu0_analysis(cudamat_solver *s, bool block)
 {
-    CM_ARG(block || !s->sharded, "ILU(0) of the whole matrix is single-GPU only (use the block variant)");
-    CM_ARG(s->cols_sorted, "ILU(0) needs every row's column indices strictly increasing (mmio_wrapper.h:123 delivers that)");
-    CM_HIP(hipSetDevice(s->ctx->device));
-    Range range_ilu("cudamat: ILU(0) analysis + factorisation + factor layout");
     ilu0_release(s);
     if (int rc0 = select_precond_matrix(s)) {
         char saved[512];
@@ -1151,7 +1152,7 @@ int ilu0_setup(cudamat_solver *s, bool block)
     hipStream_t st = s->ctx->stream;
     const int n = s->n;
     IluPlans *pl = plans_of(s, true);
-    int *d_flags = nullptr, *d_lev = nullptr;
+    int *&d_flags = pl->d_flags, *&d_lev = pl->d_lev;
     int rc = CUDAMAT_OK;
     const double t0 = now_s();
     double t_stamp = t0;
@@ -1164,7 +1165,6 @@ int ilu0_setup(cudamat_solver *s, bool block)
         }
         *pl->err_host = 0;
         if ((rc = dalloc(&s->diag_pos, (size_t)n))) break;
-        if ((rc = dalloc(&s->lu, (size_t)s->pm_nnz))) break;
         if (hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
         if (n) {
             hipLaunchKernelGGL(k_find_diag, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, s->pm_rp, s->pm_ci,
@@ -1201,9 +1201,51 @@ int ilu0_setup(cudamat_solver *s, bool block)
         }
         s->t_analysis_u = now_s() - tu;
         s->t_analysis = now_s() - t0;
+        pl->maxrow_all = maxrow_all;
+        pl->analysed = true;
+    } while (0);
+    if (rc) {
+        char saved[512];
+        snprintf(saved, sizeof(saved), "%s", cudamat_last_error());
+        ilu0_release(s);
+        set_error("%s", saved);
+    }
+    return rc;
+}
+
+int ilu0_analyse_early(cudamat_solver *s)
+{
+    if (s->sharded || !s->cols_sorted) return CUDAMAT_OK;      // (ilu0_setup will say what is wrong, or run the block variant)
+    CM_HIP(hipSetDevice(s->ctx->device));
+    Range range_ilu("cudamat: ILU(0) level analysis (beside the upload)");
+    return ilu0_analysis(s, false);
+}
+
+int ilu0_setup(cudamat_solver *s, bool block)
+{
+    CM_ARG(block || !s->sharded, "ILU(0) of the whole matrix is single-GPU only (use the block variant)");
+    CM_ARG(s->cols_sorted, "ILU(0) needs every row's column indices strictly increasing (mmio_wrapper.h:123 delivers that)");
+    CM_HIP(hipSetDevice(s->ctx->device));
+    Range range_ilu("cudamat: ILU(0) analysis + factorisation + factor layout");
+    {
+        IluPlans *p0 = plans_of(s, false);
+        const bool have = p0 && p0->analysed && !s->has_ilu && s->ilu_block == block;     // the drop-in call ran it beside its upload
+        if (!have) CM_TRY(ilu0_analysis(s, block));
+    }
+    hipStream_t st = s->ctx->stream;
+    const int n = s->n;
+    IluPlans *pl = plans_of(s, true);
+    pl->analysed = false;                  // (consumed: a second ilu0_setup on this solver starts over)
+    int *&d_flags = pl->d_flags, *&d_lev = pl->d_lev;
+    const int maxrow_all = pl->maxrow_all;
+    int hflags[2] = {0, 0};
+    int rc = CUDAMAT_OK;
+    double t_stamp = now_s();
+    do {
         // ---- factorisation on a copy of A's values (pbicgstab.cu:316, :356-363)
         const double t1 = now_s();
         t_stamp = t1;
+        if ((rc = dalloc(&s->lu, (size_t)s->pm_nnz))) break;
         if (hipMemcpyAsync(s->lu, s->pm_val, sizeof(double) * (size_t)s->pm_nnz, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             rc = CUDAMAT_ERR_HIP; set_error("copy of A values failed"); break;
         }
@@ -1331,6 +1373,8 @@ int ilu0_setup(cudamat_solver *s, bool block)
     } while (0);
     if (d_flags) CM_DROP(hipFree(d_flags));
     if (d_lev) CM_DROP(hipFree(d_lev));
+    d_flags = nullptr;
+    d_lev = nullptr;
     if (rc) {
         char saved[512];
         snprintf(saved, sizeof(saved), "%s", cudamat_last_error());

@@ -178,6 +178,8 @@ constexpr int kSortRowMax = 1024;     // longest row k_sort_rows stages (level-m
 int launch_sort_rows(hipStream_t st, int nrows, const int *src_rp, const int *src_of, const int *dst_rp, const int *ci,
                      const double *val, const int *colmap, int *out_ci, double *out_val);
 int ilu0_setup(cudamat_solver *s, bool block);
+// the pattern-only part of ilu0_setup (diagonal positions, level analysis of L and U), kept for the ilu0_setup that follows
+int ilu0_analyse_early(cudamat_solver *s);
 int ilu0_release(cudamat_solver *s);
 // rhs / out in the factor's own index spaces (TriFactor::rhs_of / out_of)
 int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *rhs, double *out);
