@@ -398,6 +398,7 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
         if (rc) up.failed = 1;
     }      // (the uploader's threads are joined here whatever happened)
     // ---- the rest may allocate and free again
+    if (s) ilu0_flush_deferred(s);
     do {
         if (rc) break;
         if ((rc = solver_setup_values(s))) break;

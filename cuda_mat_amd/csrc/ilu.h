@@ -56,6 +56,7 @@ struct IluPlans {
     int *d_flags = nullptr, *d_lev = nullptr;
     int maxrow_all = 0;
     bool analysed = false;
+    std::vector<void *> deferred;                   // temporaries of an analysis that ran beside an upload, freed after it
     // level-major index spaces (both factors hybrid): U-position of every original row (the column map of the permuted
     // matrix, solver.hip ensure_perm_matrix), scratch vectors of the original-space wrapper (precond_apply_any)
     int *posU = nullptr;

@@ -47,6 +47,17 @@ static double now_s()
     } while (0)
 
 
+// Temporaries of the pattern-only analysis when it runs beside an upload (dropin.hip): hipFree waits for every stream of
+// the device, i.e. for the copy piece in flight (2.4 ms each at C4) -- the frees are collected and carried out after the
+// last byte has landed (ilu0_flush_deferred).  nullptr: free at once.
+static thread_local std::vector<void *> *t_deferred = nullptr;
+static void afree(void *p)
+{
+    if (!p) return;
+    if (t_deferred) t_deferred->push_back(p);
+    else CM_DROP(hipFree(p));
+}
+
 template <typename T>
 static int dalloc(T **p, size_t count)
 {
@@ -389,6 +400,7 @@ int ilu0_release(cudamat_solver *s)
         if (pl->err_host) CM_DROP(hipHostFree(pl->err_host));
         if (pl->d_flags) CM_DROP(hipFree(pl->d_flags));
         if (pl->d_lev) CM_DROP(hipFree(pl->d_lev));
+        for (void *q : pl->deferred) CM_DROP(hipFree(q));
         if (pl->posU) CM_DROP(hipFree(pl->posU));
         if (pl->perm_a) CM_DROP(hipFree(pl->perm_a));
         if (pl->perm_b) CM_DROP(hipFree(pl->perm_b));
@@ -474,7 +486,7 @@ static int device_exclusive_scan(hipStream_t st, int n, const int *in, int *out)
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)(((long long)n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, tile_sum, out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    CM_DROP(hipFree(tile_sum));
+    afree(tile_sum);
     CM_HIP(e);
     return CUDAMAT_OK;
 }
@@ -675,8 +687,7 @@ static int sort_rows_by_level(hipStream_t st, int n, const int *d_lev, int **row
         lp = nullptr;
     } while (0);
     void *tmp[] = {kb[0], kb[1], rb[0], rb[1], cnt, tot, maxv, lp};
-    for (void *q : tmp)
-        if (q) CM_DROP(hipFree(q));
+    for (void *q : tmp) afree(q);
     return rc;
 }
 
@@ -758,13 +769,12 @@ static int build_levels(cudamat_solver *s, bool upper, int *d_lev, int *d_flags,
         int rcs = hipGetLastError() == hipSuccess ? device_exclusive_scan(st, n, d_len, F.rp) : CUDAMAT_ERR_HIP;
         int total = 0;
         if (!rcs && hipMemcpy(&total, F.rp + n, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rcs = CUDAMAT_ERR_HIP;
-        CM_DROP(hipFree(d_len));
+        afree(d_len);
         if (rcs) { set_error("factor row pointers failed"); return rcs; }
         F.nnz = total;
     }
-    CM_TRY(dalloc(&F.ci, (size_t)F.nnz));
-    CM_TRY(dalloc(&F.val, (size_t)F.nnz));
-    if (upper) CM_TRY(dalloc(&F.dinv, (size_t)n));
+    // (F.ci / F.val / F.dinv -- 3 GB per factor at C5 -- are allocated by fill_factor: this function may run beside an upload,
+    // which multi-GB allocations slow down)
     F.rhs_of = F.out_of = F.row_of;            // original index space (until both factors go level-major, ilu0_setup)
     F.lm = false;
     CM_STAMP("factor row pointers + arrays");
@@ -1047,6 +1057,9 @@ static int split_factor(cudamat_solver *s, TriFactor &F, TriHost &H, const int *
 static int fill_factor(cudamat_solver *s, bool upper, TriFactor &F)
 {
     const int n = s->n;
+    if (!F.ci) CM_TRY(dalloc(&F.ci, (size_t)F.nnz));
+    if (!F.val) CM_TRY(dalloc(&F.val, (size_t)F.nnz));
+    if (upper && !F.dinv) CM_TRY(dalloc(&F.dinv, (size_t)n));
     if (!n) return CUDAMAT_OK;
     const long long threads = (long long)n * 8;
     const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
@@ -1218,7 +1231,24 @@ int ilu0_analyse_early(cudamat_solver *s)
     if (s->sharded || !s->cols_sorted) return CUDAMAT_OK;      // (ilu0_setup will say what is wrong, or run the block variant)
     CM_HIP(hipSetDevice(s->ctx->device));
     Range range_ilu("cudamat: ILU(0) level analysis (beside the upload)");
-    return ilu0_analysis(s, false);
+    IluPlans *pl = plans_of(s, true);
+    std::vector<void *> keep;
+    t_deferred = &keep;
+    const int rc = ilu0_analysis(s, false);                     // (releases and re-creates the plans: `pl` is stale after this)
+    t_deferred = nullptr;
+    (void)pl;
+    if (IluPlans *p2 = plans_of(s, false)) p2->deferred.insert(p2->deferred.end(), keep.begin(), keep.end());
+    else for (void *q : keep) CM_DROP(hipFree(q));
+    return rc;
+}
+
+// the temporaries of an analysis that ran beside an upload: free them now (the upload is over)
+void ilu0_flush_deferred(cudamat_solver *s)
+{
+    if (IluPlans *pl = plans_of(s, false)) {
+        for (void *q : pl->deferred) CM_DROP(hipFree(q));
+        pl->deferred.clear();
+    }
 }
 
 int ilu0_setup(cudamat_solver *s, bool block)
