@@ -1473,6 +1473,7 @@ int ilu_perm_matrix(cudamat_solver *s)
     CM_DROP(hipFree(pl->posU));
     pl->posU = nullptr;
     s->t_perm_matrix = now_s() - t0;
+    s->t_factor += s->t_perm_matrix;       // (cudamat_stats.t_factor: everything between the level analysis and the first iteration)
     if (s->ctx->cfg.verbose) fprintf(stderr, "[cudamat] ilu0 permuted matrix (rows in L order, columns in U positions) %8.3f ms\n", s->t_perm_matrix * 1e3);
     return CUDAMAT_OK;
 }

@@ -91,7 +91,8 @@ typedef struct cudamat_stats {
     double nrm0;        /* ||r0||                                                        */
     double nrm;         /* last residual norm the loop computed                          */
     double t_analysis;  /* s, level analysis           (pbicgstab.cu:335-347)            */
-    double t_factor;    /* s, ILU(0) factorisation     (pbicgstab.cu:356-363)            */
+    double t_factor;    /* s, ILU(0) factorisation     (pbicgstab.cu:356-363), the factors' layout and, at the first
+                         * preconditioned solve of a big system, the matrix copy in the factors' index spaces */
     double t_solve;     /* s, iteration loop = dtAlg   (pbicgstab.cu:365-374)            */
     double t_total;     /* s, whole call incl. H2D/D2H                                   */
     /* CUDAMAT_FLAG_PROFILE: device time by kernel class inside the loop                */
