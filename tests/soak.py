@@ -249,10 +249,19 @@ for case in range(ncase):
                 if pc3:
                     s3.ilu0(); lu3 = s3.ilu0_values()
                 st3 = s3.solve(db, dxx, precond=pc3, loop=loop3, maxit=600, tol=1e-6)
+                lost = False
+                if pc3:
+                    fbad, lost = ND.compare_factors(vm3, lu3, float(np.max(np.abs(A3.val))))
+                    msgs += ["non-dominant n=%d nnz=%d ILU(0): %s" % (A3.n, A3.nnz, m) for m in fbad]
+                if lost:               # factors without a digit left: the preconditioned loop is noise on both sides
+                    nd_classes[("factors without digits",)] = nd_classes.get(("factors without digits",), 0) + 1
+                    for a in (db, dxx): a.free()
+                    s3.close()
+                    continue
                 line, found, k_nb = ND.compare_loop(O, A3, b3, loop3, vm3 if pc3 else None, (dxx.download(), st3, s3.history()), 600, 1e-6, k_plain)
                 if loop3 == 0 and not pc3: k_plain = k_nb
-                if pc3: found += ND.compare_factors(vm3, lu3)
-                nd_classes[(bool(st3.converged), bool(st3.breakdown), k_nb is not None)] = nd_classes.get((bool(st3.converged), bool(st3.breakdown), k_nb is not None), 0) + 1
+                key = (bool(st3.converged), bool(st3.breakdown), k_nb[1] is not None)
+                nd_classes[key] = nd_classes.get(key, 0) + 1
                 msgs += ["non-dominant n=%d nnz=%d loop%d pc%d: %s" % (A3.n, A3.nnz, loop3, pc3, m) for m in found]
             except cm.CudamatError as e:
                 msgs.append("non-dominant loop%d pc%d: %s" % (loop3, pc3, e))
@@ -263,4 +272,4 @@ for case in range(ncase):
         print("case %d n=%d per=%g base=%d: %s" % (case, n, per, base, "; ".join(msgs)), flush=True)
 print("soak: %d cases, %d with findings; solves by loop form (0 five launches, 1 three, 2 one): %s" % (ncase, bad, sorted(forms.items())) + "; SpMV runs on a value dictionary: %d" % dicts
       + "; stencil systems through the row-pattern forms: %s" % sorted(stencils.items())
-      + "; non-dominant systems: %d, their solves by (converged, breakdown, oracle on rounding noise): %s" % (nd_total, sorted(nd_classes.items())))
+      + "; non-dominant systems: %d, their solves by (converged, breakdown, oracle on rounding noise): %s" % (nd_total, sorted(nd_classes.items(), key=str)))
