@@ -50,6 +50,37 @@ def unpin_main_thread():
             pass
 
 
+def _cpulist(text):
+    cpus = set()
+    for tok in text.strip().split(","):
+        if not tok:
+            continue
+        a, _, b = tok.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def bind_near_gpu(torch, local_rank):
+    """A two-socket host reaches a GPU through ONE socket: host threads (and the pages they first touch: the arrays a drop-in
+    call uploads) on the other socket cost the upload two thirds of its rate and make allocation-heavy set-up stages
+    several times slower (round 5: uploads at 11-18 GB/s instead of 54 on the boxes whose GPU hangs off the other socket
+    than the one the scheduler happened to pick).  This thread -- and what it starts -- moves to the CPUs the kernel lists
+    as local to the device, within the set the process was given.  Returns a note for the JSON line."""
+    if not HOST_CPU_SET or os.environ.get("CUDAMAT_BENCH_BIND", "near") == "off":
+        return None
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        local = _cpulist(open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read()) & HOST_CPU_SET
+        node = open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip()
+        if not local:
+            return None
+        os.sched_setaffinity(0, local)
+        return {"gpu_pci": bdf, "numa_node": int(node), "cpus_near_gpu": len(local), "cpus_of_process": len(HOST_CPU_SET)}
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
 
 def cpu_quota():
     """CPUs' worth of time the container may use (cgroup v2 cpu.max), or None when unlimited / unknown: a one-GPU box of
@@ -303,6 +334,7 @@ def cpu_baseline(args):
     construction.  The one-off transposition (Transpose2, a serial loop upstream: ~70 s at this size) is done with
     every thread and reported beside the rate, not in it."""
     from oracle import oracle as O
+    unpin_main_thread()          # (the GPU sections ran on the CPUs near the GPU: the baseline gets every CPU the process was given)
     O.set_num_threads(min(HOST_CPUS, 64))
     full_rows = args.rows
 
@@ -484,6 +516,7 @@ def run_bench(args):
     backend = os.environ.get("CUDAMAT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    host_placement = bind_near_gpu(torch, local_rank)
     # CUDAMAT_FORCE_SHARDED=1 under torchrun --nproc-per-node 1 exercises the whole N > 1 code path
     # (process group, TorchComm callbacks, sharded loop) on a single GPU
     use_dist = world > 1 or (os.environ.get("CUDAMAT_FORCE_SHARDED") == "1" and "MASTER_ADDR" in os.environ)
@@ -863,6 +896,8 @@ def run_bench(args):
             # (CUDAMAT_VALUE_DICT=0) unless CUDAMAT_BENCH_HEADLINE=dict: SURVEY 8d's generator draws from 39 distinct values,
             # which the 8-bit dictionary form would exploit -- that run is the side figure `with_value_dictionary`
             "value_dictionary": solver.value_dict(),
+            # where the host side of this process runs: the CPUs local to the GPU's PCIe root (bind_near_gpu)
+            "host_placement": host_placement,
         }
         if side is not None:
             if side.get("avg_launch_ms", 0) > 0:

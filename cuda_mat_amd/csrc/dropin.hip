@@ -16,6 +16,9 @@
 #include <atomic>
 #include <chrono>
 #include <mutex>
+#include <pthread.h>
+#include <sched.h>
+#include <ctype.h>
 #include <thread>
 #include <vector>
 #include <math.h>
@@ -32,6 +35,39 @@ static double now_s()
 }
 
 namespace {
+
+// A two-socket host reaches a GPU through ONE socket's PCIe root: a thread that feeds the runtime's pageable copies from the
+// other socket moved 11-18 GB/s where a thread on the near socket moves 54 (round 5: the one-GPU boxes of the pool show 256
+// CPUs on two NUMA nodes and hand out GPUs of either).  The uploader thread is the library's own: it runs on the CPUs the
+// kernel lists as local to the device (/sys/bus/pci/devices/<bdf>/local_cpulist), within the mask the process already
+// has; anything missing or unreadable leaves the thread where it is.
+static void bind_thread_near_device(int device)
+{
+    char bdf[32] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return;
+    for (char *c = bdf; *c; c++) *c = (char)tolower((unsigned char)*c);
+    char path[128];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    char list[1024] = {0};
+    const bool got = fgets(list, sizeof(list), f) != nullptr;
+    fclose(f);
+    if (!got) return;
+    cpu_set_t have, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(have), &have) != 0) return;
+    int picked = 0;
+    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k < 1) continue;
+        if (k == 1) b = a;
+        for (int cpu = a; cpu <= b && cpu < CPU_SETSIZE; cpu++)
+            if (cpu >= 0 && CPU_ISSET(cpu, &have)) { CPU_SET(cpu, &want); picked++; }
+    }
+    if (picked > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(want), &want);
+}
 
 // ---------------------------------------------------------------------------------------------------- uploader
 // One thread hands the runtime the caller's (pageable) arrays in order, 128 MB at a time (hipMemcpyAsync from pageable
@@ -94,6 +130,7 @@ struct Uploader {
             return true;
         };
         if (bad(hipSetDevice(device), "hipSetDevice")) return;
+        bind_thread_near_device(device);
         for (size_t c = 0; c < chunks.size(); c++) {
             if (failed) return;
             if (bad(hipMemcpyAsync(chunks[c].dst, chunks[c].src, chunks[c].bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync")) return;
@@ -269,7 +306,8 @@ int build_or_reuse_candidate(cudamat_ctx *ctx, const Config &cfg, const HostSyst
 // precond == CUDAMAT_PRECOND_ILU0: the pattern-only part of the ILU(0) set-up (diagonal positions, level analysis of L and U:
 // 32 ms at C5) runs as soon as the pattern has landed, beside the upload of the values (round 5).
 int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h, double *d_b, double *d_x, double *d_d,
-                        cudamat_solver **s_out, double *t_up, bool speculative = true, int precond = CUDAMAT_PRECOND_NONE)
+                        cudamat_solver **s_out, double *t_up, bool speculative = true, int precond = CUDAMAT_PRECOND_NONE,
+                        int loop = CUDAMAT_LOOP_PBICGSTAB)
 {
     const double t0 = now_s();
     const int n = h.n, nnz = h.nnz, base = h.base;
@@ -355,7 +393,19 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
             }
             if ((rc = solver_setup_pattern(s))) break;
             stamp("pattern stage done (validation, CSR plan)");
-            if (pb_open && (rc = spmv_mode_is_blocked_early(s, &blocked))) break;
+            // ---- the level analysis of the preconditioner needs the pattern only: its kernels (and the host's waits for their
+            // read-backs) fit into the time the values take to arrive; the fill pieces below queue up behind them
+            bool loop_in_level_major = false;
+            if (precond == CUDAMAT_PRECOND_ILU0 && cfg.early_analysis) {
+                if ((rc = ilu0_analyse_early(s))) break;
+                stamp("ILU(0) level analysis done (beside the upload)");
+                // Both factors hybrid: the preconditioned reference loop runs in the level-major spaces on its OWN blocked copy
+                // (rows in L's order, columns in U's positions; loops.hip) and never touches one in the original space -- that
+                // copy (12 ms of fill whose tail is not hidden, 10 GB) is then not built; a later un-preconditioned solve on
+                // the same matrix builds it at its first SpMV (ensure_spmv_mode).
+                loop_in_level_major = cfg.skip_orig_copy && loop == CUDAMAT_LOOP_PBICGSTAB && !h.d && cfg.trsv_perm && ilu0_will_use_level_major(s);
+            }
+            if (pb_open && !loop_in_level_major && (rc = spmv_mode_is_blocked_early(s, &blocked))) break;
             t_pb0 = now_s();
             if (pb_open && blocked) {
                 if ((rc = pb_build_count(st, cfg, s->rp, s->ci, &pb))) { pb_open = false; break; }
@@ -371,12 +421,6 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
                     s->vd_tried = true;                  // (more than 256 distinct values, or the dictionary is switched off)
                     piecewise = true;
                 }
-            }
-            // ---- the level analysis of the preconditioner needs the pattern only: its kernels (and the host's waits for their
-            // read-backs) fit into the time the values take to arrive; the fill pieces below queue up behind them
-            if (precond == CUDAMAT_PRECOND_ILU0 && cfg.early_analysis) {
-                if ((rc = ilu0_analyse_early(s))) break;
-                stamp("ILU(0) level analysis done (beside the upload)");
             }
             // ---- values: piece by piece into the blocked copy, or all at once behind the dictionary
             if (piecewise) {
@@ -464,7 +508,7 @@ int solve_host_locked(const Config &cfg, const HostSystem &h, bool speculative, 
         if (candidate) {
             if ((rc = build_or_reuse_candidate(ctx, cfg, h, d_b, d_x, d_d, &s, &reused, &t_up))) break;
         } else {
-            if ((rc = build_beside_upload(ctx, cfg, h, d_b, d_x, d_d, &s, &t_up, speculative, precond))) break;
+            if ((rc = build_beside_upload(ctx, cfg, h, d_b, d_x, d_d, &s, &t_up, speculative, precond, loop))) break;
         }
         if (g_cache.d_d && !reused) { cudamat_free(ctx, g_cache.d_d); g_cache.d_d = nullptr; }
         if ((rc = cudamat_solver_set_shift(s, d_d))) break;

@@ -1242,6 +1242,14 @@ int ilu0_analyse_early(cudamat_solver *s)
     return rc;
 }
 
+// after ilu0_analyse_early: will both factors take the hybrid solve, i.e. will the preconditioned reference loop run in the
+// level-major index spaces on the permuted copy of the matrix (loops.hip)?
+bool ilu0_will_use_level_major(cudamat_solver *s)
+{
+    IluPlans *pl = plans_of(s, false);
+    return pl && pl->analysed && pl->L.hybrid && pl->U.hybrid;
+}
+
 // the temporaries of an analysis that ran beside an upload: free them now (the upload is over)
 void ilu0_flush_deferred(cudamat_solver *s)
 {

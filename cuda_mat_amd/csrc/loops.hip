@@ -100,7 +100,10 @@ int Solve::setup()
     x_user = x;
     {
         int rc_setup = ensure_work(s);
-        if (rc_setup == CUDAMAT_OK) rc_setup = ensure_spmv_mode(s);
+        // (a solver whose SpMV form is still undecided -- the drop-in call leaves it so when the preconditioned loop will run
+        // in the level-major spaces on its own copy of the matrix -- gets its factors first: the choice below may not be needed)
+        const bool defer_form = s->spmv_mode < 0 && precond == CUDAMAT_PRECOND_ILU0 && !s->sharded;
+        if (rc_setup == CUDAMAT_OK && !defer_form) rc_setup = ensure_spmv_mode(s);
         if (rc_setup == CUDAMAT_OK && precond && (!s->has_ilu || (s->sharded && !s->ilu_block)))
             rc_setup = ilu0_setup(s, precond == CUDAMAT_PRECOND_BLOCK_ILU0);
         CM_TRY(setup_agree(s, rc_setup));        // sharded: every rank learns of a failure on any rank
@@ -121,6 +124,7 @@ int Solve::setup()
         else CM_TRY(rcp);                                                        // application, and do not try again on every solve
     }
     s->perm_active = perm;
+    if (!perm && s->spmv_mode < 0) CM_TRY(ensure_spmv_mode(s));     // (deferred above; the loop runs in the original space after all)
     if (perm) {
         CM_TRY(perm_to_space(s, false, b, s->b_perm));
         if (!(flags & CUDAMAT_FLAG_X0_ONES)) CM_TRY(perm_to_space(s, true, x, s->x_perm));
@@ -580,7 +584,7 @@ int Solve::finish(bool *precond_gave_up, cudamat_stats *out)
     stt.ms_spmv_alone = s->ms_spmv_alone;
     stt.t_setup = s->t_create + s->t_spmv_setup;
     stt.t_tune = s->t_spmv_timing;
-    stt.spmv_mode = s->spmv_mode;
+    stt.spmv_mode = s->spmv_mode < 0 && s->perm_active ? 1 : s->spmv_mode;      // (the permuted copy is a blocked two-phase copy)
     if (s->profiling) {
         // exposed part of an overlapped gather: the waits (kind 1), clipped to the gather they wait for only by
         // construction -- the solver's stream idles there for nothing else

@@ -180,7 +180,8 @@ int launch_sort_rows(hipStream_t st, int nrows, const int *src_rp, const int *sr
 int ilu0_setup(cudamat_solver *s, bool block);
 // the pattern-only part of ilu0_setup (diagonal positions, level analysis of L and U), kept for the ilu0_setup that follows
 int ilu0_analyse_early(cudamat_solver *s);
-void ilu0_flush_deferred(cudamat_solver *s);    // ... and the temporaries it kept alive while the upload ran
+void ilu0_flush_deferred(cudamat_solver *s);
+bool ilu0_will_use_level_major(cudamat_solver *s);    // ... and the temporaries it kept alive while the upload ran
 int ilu0_release(cudamat_solver *s);
 // rhs / out in the factor's own index spaces (TriFactor::rhs_of / out_of)
 int trsv_apply(cudamat_solver *s, const TriFactor &F, bool upper, const double *rhs, double *out);

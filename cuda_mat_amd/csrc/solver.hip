@@ -420,7 +420,7 @@ int spmv_local(cudamat_solver *s, const double *x_local, double *y, int dot, con
     a.check = check;
     a.half = half;
     a.pb_strict = 0;
-    if (s->spmv_mode == 1) CM_TRY(pb_strict_for(s->ctx, &a.pb_strict));
+    if (s->spmv_mode == 1 || s->perm_active) CM_TRY(pb_strict_for(s->ctx, &a.pb_strict));
     if (overlapped) {
         // The gather in pieces on the communicator's stream, phase 1 piece by piece behind it:
         //   comm stream  :  [wait x ready] piece 0 | piece 1 | ...
