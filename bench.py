@@ -121,6 +121,10 @@ def parse():
                          "twice (one GPU only; the second call reuses the first one's plan)")
     ap.add_argument("--cpu-iters-full", type=int, default=2, help="iterations of the CPU baseline on the full matrix, per OpenMP team size")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    ap.add_argument("--gpu-warm-seconds", type=float, default=3.0,
+                    help="untimed iterations of the same loop BEFORE the W warm-up steps, for this long: the first process on an idle "
+                         "box finds the GPU in its low-power state and its first seconds of work run 6-8 %% slower (round 5: "
+                         "the first bench.py on a fresh box 175-176 it/s, every later one 181-190); 0 = none")
     ap.add_argument("--other-configs", default="auto", choices=["auto", "off"],
                     help="auto: after the judged region of the default (headline) invocation on one GPU, also run BASELINE.json's "
                          "other single-GPU configurations -- C3 poisson5, C5 rand50 + ILU(0), C2 mat10000 -- as side sections "
@@ -708,6 +712,14 @@ def run_bench(args):
                 dist.barrier()
             torch.cuda.synchronize()
 
+        # the GPU out of its idle power state first (see --gpu-warm-seconds), then the contract's W untimed steps
+        t_warm0, warm_steps = time.perf_counter(), 0
+        while args.gpu_warm_seconds > 0 and time.perf_counter() - t_warm0 < args.gpu_warm_seconds:
+            run(25 if precond else CHUNK, flags)
+            torch.cuda.synchronize()
+            warm_steps += 25 if precond else CHUNK
+        if use_dist:
+            dist.barrier()
         run(args.warmup, flags)
         timed_steps[0] = 0
         exch.clear()
@@ -721,6 +733,11 @@ def run_bench(args):
         barrier()
         dt = time.perf_counter() - t0
         dt = host_allreduce(dt, "max")
+
+        # what the output needs to know about the resident solver; it is closed before the drop-in calls below, so that those
+        # run like a host program's would -- not beside a second ~50 GB solver of the same matrix -- and draw on the blocks it
+        # hands back to the library's pool (csrc/pool.cpp)
+        sv_mode, sv_kernel, sv_dict = solver.spmv_mode(), solver.spmv_kernel(), solver.value_dict()
 
         # The value dictionary as a side figure: the same workload timed -- outside the judged region, one GPU only -- with
         # the 8-bit value indices the library would pick by itself for this matrix (<= 256 distinct values)
@@ -752,7 +769,11 @@ def run_bench(args):
         # example.cpp:364-365): ONE call of cudamat_solve() on HOST arrays -- upload over PCIe, analysis, loop, download --
         # and a second call with the same matrix, which reuses the first one's plan.  Outside the judged region.
         drop_in = None
+        ceil = hbm_ceiling(ctx) if (world == 1 and not latency_bound) else None
         if world == 1 and args.drop_in != "off" and precond in (cm.PRECOND_NONE, cm.PRECOND_ILU0) and not latency_bound:
+            solver.set_comm(None) if comm is not None else None
+            solver.close()
+            solver = None
             try:
                 import numpy as np
                 from cuda_mat_amd import api as cm_api
@@ -823,15 +844,15 @@ def run_bench(args):
     # applications of L^-1 U^-1 per iteration (factor entries + row pointers of both factors + the vectors they stream)
     b_precond = 2.0 * (12.0 * nnz + 8.0 * (nloc + 1) + 32.0 * nloc) if precond else 0.0
     b_iter = 2 * b_spmv + vec_bytes + b_precond
-    blocked = solver.spmv_mode() == 1
-    kernel = solver.spmv_kernel() + (" (one SpMV = the pair)" if blocked else "")
+    blocked = sv_mode == 1
+    kernel = sv_kernel + (" (one SpMV = the pair)" if blocked else "")
     # small systems: the SpMV rides inside a fused kernel (cudamat_stats.loop_form: 1 = the vector updates folded into the two
     # SpMV launches, 2 = the whole loop in ONE launch) -- name the kernel a trace of the timed region shows
     if st.loop_form == 2:
         kernel = "k_resident_loop<%d> (the whole loop in one launch, grid barriers between its phases; SpMV rows as %s)" % (
-            256, solver.spmv_kernel())
+            256, sv_kernel)
     elif st.loop_form == 1:
-        kernel = "k_fspmv (vector updates folded into the two SpMV launches of an iteration; rows as %s)" % solver.spmv_kernel()
+        kernel = "k_fspmv (vector updates folded into the two SpMV launches of an iteration; rows as %s)" % sv_kernel
     if n_spmv == 0:
         kernel += " (L2-resident, launch-latency-bound: per-launch timing off, no roofline quoted)"
     # HBM bytes per SpMV launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
@@ -851,10 +872,10 @@ def run_bench(args):
             pm = json.load(open(f))
             # (kernel names as the trace prints them, without argument lists; phase 1 has a dictionary form)
             if blocked:
-                p1 = "cm::k_pb_phase1_dict" if solver.value_dict() > 0 else "cm::k_pb_phase1"
+                p1 = "cm::k_pb_phase1_dict" if sv_dict > 0 else "cm::k_pb_phase1"
                 want = [p1, "cm::k_pb_phase2<"]
             else:
-                want = ["cm::" + solver.spmv_kernel()]
+                want = ["cm::" + sv_kernel]
             got = [next((v for k, v in pm.items() if (k == w + loop_tag or (w.endswith("<") and k.startswith(w) and k.endswith(loop_tag or ">")))
                          and isinstance(v, dict) and "hbm_bytes_per_launch_corrected" in v), None) for w in want]
             if all(g is not None for g in got):
@@ -891,11 +912,13 @@ def run_bench(args):
                          "iteration_bytes_formula": "2 B_spmv + 144 n" + (" + 2 (12 nnz + 8 (n + 1) + 32 n)  [SURVEY 8d, B_iter(ilu0)]" if precond else "  [SURVEY 8d, B_iter(none)]"),
                          "iteration_frac": b_iter * (args.steps / dt) / 1e9 / HBM_PEAK_GBS},
             "spmv_gbs": achieved, "spmv_form": {1: "blocked two-phase", 2: "SELL-C-sigma", 3: "row-pattern dictionary"}.get(
-                solver.spmv_mode(), "csr (lanes-per-row / stream tiles)"),
+                sv_mode, "csr (lanes-per-row / stream tiles)"),
             # 0: the timed kernels read fp64 values (8 B per entry).  The bench switches the library's value dictionary off
             # (CUDAMAT_VALUE_DICT=0) unless CUDAMAT_BENCH_HEADLINE=dict: SURVEY 8d's generator draws from 39 distinct values,
             # which the 8-bit dictionary form would exploit -- that run is the side figure `with_value_dictionary`
-            "value_dictionary": solver.value_dict(),
+            "value_dictionary": sv_dict,
+            # untimed iterations run before the W warm-up steps to bring the GPU out of its idle power state (--gpu-warm-seconds)
+            "gpu_warm": {"seconds": args.gpu_warm_seconds, "steps": warm_steps},
             # where the host side of this process runs: the CPUs local to the GPU's PCIe root (bind_near_gpu)
             "host_placement": host_placement,
         }
@@ -976,10 +999,9 @@ def run_bench(args):
             out["roofline"]["moved_gbs"] = traffic / (spmv_ms * 1e-3) / 1e9
             out["roofline"]["moved_over_algorithmic"] = traffic / b_spmv
         if world == 1 and not latency_bound:
-            ceil = hbm_ceiling(ctx)
             out["roofline"]["measured_stream_ceiling"] = ceil
             out["roofline"]["frac_of_measured_ceiling"] = achieved / ceil["gbs"]
-            if solver.spmv_mode() == 3:
+            if sv_mode == 3:
                 # SURVEY 8d's B_spmv prices 4 B of column index per entry; the row-pattern form fetches none (a row's columns come
                 # from a 16 KB table through one byte per row), so it MOVES fewer bytes than B_spmv and `achieved` (algorithmic
                 # bytes / time) can exceed a stream ceiling measured in moved bytes: compare `moved_gbs` with the ceiling instead
@@ -997,7 +1019,8 @@ def run_bench(args):
                                                     "the launch pair runs at %.2f of that" % (t_floor / spmv_ms if spmv_ms > 0 else 0.0))
         if world == 1 and args.cpu_baseline != "off":
             out["cpu_baseline"] = cpu_baseline(args)
-    solver.close()
+    if solver is not None:
+        solver.close()
     if comm is not None and hasattr(comm, "close"):
         comm.close()
     ctx.close()

@@ -128,6 +128,8 @@ _SIGS = {
     "cudamat_solve": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                                 C.c_double, C.c_int, _P, C.POINTER(Stats)]),
     "cudamat_plan_cache_clear": (C.c_int, []),
+    "cudamat_pool_trim": (C.c_int, []),
+    "cudamat_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "cudamat_poisson5_nnz": (C.c_int64, [C.c_int, C.c_int]),
     "cudamat_gen_poisson5": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P]),
     "cudamat_rand_row_nnz": (C.c_int, [C.c_int64, C.c_int]),

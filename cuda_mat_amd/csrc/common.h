@@ -12,6 +12,18 @@
 
 namespace cm {
 
+// device memory comes from a recycling pool (pool.cpp): every hipMalloc / hipFree of this library's translation units
+hipError_t pool_malloc(void **out, size_t bytes);
+hipError_t pool_free(void *p);
+void pool_trim();                 // free blocks back to the driver (cudamat_plan_cache_clear, out-of-memory retries)
+size_t pool_free_bytes();         // what the current device's pool could hand out without asking the driver
+
+}  // namespace cm
+#define hipMalloc(p, bytes) cm::pool_malloc((void **)(p), (bytes))
+#define hipFree(p) cm::pool_free((void *)(p))
+
+namespace cm {
+
 void set_error(const char *fmt, ...);
 int fail_hip(hipError_t e, const char *what, const char *file, int line);
 inline int rc_of(hipError_t e, const char *what, const char *file, int line)

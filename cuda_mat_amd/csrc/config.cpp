@@ -48,6 +48,7 @@ const Option kOptions[] = {
     OPT_FLAG("VALUE_DICT", value_dict, "0: keep fp64 values even when the matrix has <= 256 distinct ones"),
     OPT_INT("PB_MIN_WAVES", pb_min_waves, 256, 1 << 20, "blocked form: fewest phase-2 waves"),
     OPT_INT("PB_DEPTH", pb_depth, 4, 16, "blocked form: segment loads in flight per phase-2 wave (4, 8 or 16)"),
+    OPT_FLAG("POOL", pool, "0: device memory straight from hipMalloc / hipFree instead of the library's recycling pool (read once per process)"),
     OPT_FLAG("SKIP_ORIG_COPY", skip_orig_copy, "0: cudamat_solve with ILU(0) builds the blocked copy in the original index space even when its loop will run in the level-major spaces"),
     OPT_FLAG("EARLY_ANALYSIS", early_analysis, "0: cudamat_solve analyses the ILU(0) levels after the upload of the values instead of beside it"),
     OPT_INT("PB_FILL_OCC", pb_fill_occ, 0, 64, "resident waves per CU of the two-pass fill's first pass (0: 8; probing)"),

@@ -28,6 +28,7 @@ struct Config {
     int value_dict = 1;           // VALUE_DICT         0: keep fp64 values even when the matrix has <= 256 distinct ones
     int pb_min_waves = 0;         // PB_MIN_WAVES       blocked form: fewest phase-2 waves (0: 2048 / 4096 by shape)
     int pb_depth = 0;             // PB_DEPTH           blocked form: segment loads in flight per wave, 4 | 8 | 16 (0: by shape)
+    int pool = 1;                 // POOL               0: every allocation goes to the runtime (read once per process)
     int skip_orig_copy = 1;       // SKIP_ORIG_COPY     0: the preconditioned drop-in call builds the original-space blocked copy although its loop runs on the permuted one
     int early_analysis = 1;       // EARLY_ANALYSIS     0: the drop-in call runs the ILU(0) level analysis after its upload, not beside it
     int pb_fill_occ = 0;          // PB_FILL_OCC        resident waves per CU of the two-pass fill's first pass (0: 8)

@@ -224,7 +224,29 @@ static int device_equal(hipStream_t st, const void *a, const void *b, size_t byt
 extern "C" int cudamat_plan_cache_clear(void)
 {
     std::lock_guard<std::mutex> lk(g_cache.mu);
-    cache_drop_locked();
+    cache_drop_locked();     // (its memory goes back to the library's pool: cudamat_pool_trim returns that to the driver)
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_pool_trim(void)
+{
+    pool_trim();
+    return CUDAMAT_OK;
+}
+
+extern "C" int cudamat_mem_info(int device, size_t *driver_free, size_t *driver_total, size_t *pool_free)
+{
+    int before = 0;
+    CM_TRY(CM_RC(hipGetDevice(&before)));
+    CM_TRY(CM_RC(hipSetDevice(device)));
+    size_t f = 0, t = 0;
+    const hipError_t e = hipMemGetInfo(&f, &t);
+    const size_t pf = pool_free_bytes();
+    (void)hipSetDevice(before);
+    if (e != hipSuccess) return CM_RC(e);
+    if (driver_free) *driver_free = f;
+    if (driver_total) *driver_total = t;
+    if (pool_free) *pool_free = pf;
     return CUDAMAT_OK;
 }
 
@@ -334,7 +356,7 @@ int build_beside_upload(cudamat_ctx *ctx, const Config &cfg, const HostSystem &h
         // pattern only while it leaves as much again free -- otherwise a later stage (value dictionary, ILU(0), a cached
         // system) could run out of memory where the staged path would have fitted
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (size_t)20 * (size_t)nnz) want_pb = false;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b + pool_free_bytes() < 2 * (size_t)20 * (size_t)nnz) want_pb = false;
     }
     if (want_pb) {
         const int rcb = pb_build_alloc(st, cfg, n, n_cols, nnz, nullptr, &pb);
@@ -580,6 +602,7 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
         // the solver kept from the previous call (several GB at the BASELINE sizes) may be what is in the way: the
         // reference frees everything per call (pbicgstab.cu:392-405), so release it and try once more
         cache_drop_locked();
+        pool_trim();
         rc = solve_host_locked(cfg, h, false, precond, loop, maxit, tol, debug, x, out);
     }
     return rc;

@@ -337,6 +337,18 @@ int cudamat_solve(int n, int nnz, const double *A, const int *iA, const int *jA,
  * it before it starts; cudamat_plan_cache_clear() (or CUDAMAT_PLAN_CACHE=0 in the environment) releases / disables it.  */
 int cudamat_plan_cache_clear(void);
 
+/* Device memory of this library comes from a recycling pool (csrc/pool.cpp): what a solver, a context or
+ * cudamat_plan_cache_clear() frees stays with the library and serves its later requests -- on this platform a fresh
+ * hipMalloc is not uniformly cheap (0.3 ms for 8 GB, but 26 ms per GB on some boxes once a process holds more than ~40 GB,
+ * and seconds for single calls), and a host program that solves system after system would pay that every time.  The pool
+ * keeps at most 96 GB free per device and empties itself when an allocation would fail.  cudamat_pool_trim() hands every
+ * free block back to the driver -- for a host program that shares the device with other allocators; CUDAMAT_POOL=0 (read
+ * once per process) turns the pool off.  The reference allocates and frees per call (pbicgstab.cu:243-255,392-405).   */
+int cudamat_pool_trim(void);
+/* what the driver reports free / in total on `device` (hipMemGetInfo) and, of the memory the driver counts as used, how
+ * much the library's pool could hand out again without asking it; any pointer may be NULL */
+int cudamat_mem_info(int device, size_t *driver_free, size_t *driver_total, size_t *pool_free);
+
 /* The same solve over `ngpu` GPUs of this node, from one process: uniform row blocks, one host
  * thread and one RCCL rank per device (csrc/sharded.cpp).  precond: NONE or BLOCK_ILU0 (each
  * rank's diagonal block; ILU0 of the whole matrix does not shard => CUDAMAT_ERR_ARG).

@@ -1952,3 +1952,48 @@ def test_row_pattern_form_in_the_solver_loop_and_auto_selection(cm, ctx, oracle,
             np.testing.assert_allclose(h[:20], ref[:20], rtol=1e-9)
     xo, so, ho = oracle.pbicgstab(A, b, maxit=60, tol=0.0, want_hist=True)
     np.testing.assert_allclose(h[:20], ho[:20], rtol=1e-8)
+
+
+def test_device_memory_pool_recycles_and_trims(cm, ctx):
+    """csrc/pool.cpp: a freed block stays with the library and serves the next request of that size (no driver call: the
+    device's free memory does not move, the address is the same); a larger request splits a free block; neighbours merge
+    when freed; cudamat_pool_trim() hands everything back to the driver.  (Why a pool: DESIGN 6a -- a fresh hipMalloc costs
+    up to 26 ms/GB on this platform once a process has allocated tens of GB.)"""
+    import ctypes as C
+    lib = cm.lib()
+    GB = 1 << 30
+
+    def free_now(pool=False):
+        ctx.sync()
+        f, t, pf = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        assert lib.cudamat_mem_info(0, C.byref(f), C.byref(t), C.byref(pf)) == 0
+        return pf.value if pool else f.value
+
+    lib.cudamat_plan_cache_clear()               # nothing of an earlier test's solver is left in a partly used segment
+    assert lib.cudamat_pool_trim() == 0
+    f0 = free_now()
+    a = ctx.empty(GB // 8)                       # 1 GB
+    pa = a.ptr
+    assert free_now() <= f0 - GB + (64 << 20)
+    a.free()
+    f1 = free_now()
+    assert f1 <= f0 - GB + (64 << 20) and free_now(pool=True) >= GB            # still with the pool
+    b = ctx.empty(GB // 8)
+    assert b.ptr == pa and free_now() == f1      # recycled, no driver call
+    b.free()
+    # two halves out of the one free block, written and read back: distinct memory
+    c, d = ctx.empty(GB // 32), ctx.empty(GB // 32)          # 256 MB each: the 1 GB block is split (>= 64 MB left over)
+    assert free_now() == f1 and c.ptr == pa and d.ptr == pa + (GB // 4)
+    c.upload(np.full(GB // 32, 1.5))
+    d.upload(np.full(GB // 32, -2.5))
+    assert c.download()[-1] == 1.5 and d.download()[0] == -2.5
+    c.free()
+    d.free()
+    e = ctx.empty(GB // 8)                       # the pieces merged again: the whole 1 GB fits where it was
+    assert e.ptr == pa and free_now() == f1
+    e.free()
+    # a small request is not pooled
+    s = ctx.empty(1000)
+    s.free()
+    assert lib.cudamat_pool_trim() == 0
+    assert free_now() >= f0 - (64 << 20) and free_now(pool=True) == 0
