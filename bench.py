@@ -82,6 +82,53 @@ def bind_near_gpu(torch, local_rank):
 
 
 
+class GpuStateSampler:
+    """The device's own core clock, package power and temperature while the timed region runs (sysfs hwmon of its PCI device,
+    readable by an ordinary user; 20 samples a second from a thread that only reads three small files).  Why it is in the
+    JSON line: the streaming ceilings measured in one process agree to 2 % from box to box, the blocked SpMV's launch time
+    does not (2.50-2.73 ms) -- the core clock under the board's power management is the one thing left that differs."""
+
+    def __init__(self, bdf):
+        import glob
+        import threading
+        self.rows, self.stop_flag, self.thread = [], threading.Event(), None
+        hw = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf) if bdf else []
+        self.files = None
+        if hw:
+            f = {"sclk_hz": "freq1_input", "power_uw": "power1_input", "temp_mc": "temp2_input"}
+            self.files = {k: os.path.join(hw[0], v) for k, v in f.items() if os.path.exists(os.path.join(hw[0], v))}
+        if self.files:
+            self.thread = threading.Thread(target=self._loop, daemon=True)
+
+    def _loop(self):
+        while not self.stop_flag.is_set():
+            row = {}
+            for k, path in self.files.items():
+                try:
+                    row[k] = float(open(path).read())
+                except (OSError, ValueError):
+                    pass
+            self.rows.append(row)
+            time.sleep(0.05)
+
+    def start(self):
+        if self.thread:
+            self.thread.start()
+        return self
+
+    def stop(self):
+        if not self.thread:
+            return None
+        self.stop_flag.set()
+        self.thread.join()
+
+        def stat(key, scale):
+            v = sorted(r[key] * scale for r in self.rows if key in r)
+            return None if not v else {"min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)}
+        return {"samples": len(self.rows), "sclk_mhz": stat("sclk_hz", 1e-6), "power_w": stat("power_uw", 1e-6),
+                "junction_c": stat("temp_mc", 1e-3), "source": "hwmon of the device, sampled during the timed region"}
+
+
 def cpu_quota():
     """CPUs' worth of time the container may use (cgroup v2 cpu.max), or None when unlimited / unknown: a one-GPU box of
     the pool shows 256 CPUs and is throttled to 16"""
@@ -468,7 +515,7 @@ def main():
 
 # keys of a full line that a side section keeps (the rest is either the headline's business or repeats the section's name)
 SECTION_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "spmv_gbs", "spmv_form", "value_dictionary",
-                "trsv_ms_per_apply", "trsv_roofline", "trsv_traffic", "levels", "setup_s", "drop_in")
+                "trsv_ms_per_apply", "trsv_roofline", "trsv_traffic", "levels", "setup_s", "drop_in", "gpu_state")
 OTHER_CONFIGS = (      # BASELINE.json configs[2], [4], [1]: name, argument overrides
     ("poisson5", {"workload": "poisson5", "precond": "none", "steps": 200, "warmup": 10}),
     ("rand50_ilu0", {"workload": "rand50", "precond": "ilu0", "steps": 50, "warmup": 5}),
@@ -724,6 +771,7 @@ def run_bench(args):
         timed_steps[0] = 0
         exch.clear()
         barrier()
+        sampler = GpuStateSampler((host_placement or {}).get("gpu_pci") if rank == 0 else None).start()
         t0 = time.perf_counter()
         # per-launch SpMV timing = HIP events around every SpMV inside the loop; on L2-resident systems
         # (C2) the four event records per iteration would dominate the ~28 us iteration, and no roofline
@@ -732,6 +780,7 @@ def run_bench(args):
         ms_spmv, n_spmv, ms_trsv, n_trsv, st = run(args.steps, flags | (0 if latency_bound else cm.FLAG_PROFILE))
         barrier()
         dt = time.perf_counter() - t0
+        gpu_state = sampler.stop()
         dt = host_allreduce(dt, "max")
 
         # what the output needs to know about the resident solver; it is closed before the drop-in calls below, so that those
@@ -921,6 +970,8 @@ def run_bench(args):
             "gpu_warm": {"seconds": args.gpu_warm_seconds, "steps": warm_steps},
             # where the host side of this process runs: the CPUs local to the GPU's PCIe root (bind_near_gpu)
             "host_placement": host_placement,
+            # the device's core clock / power / temperature during the timed region (GpuStateSampler)
+            "gpu_state": gpu_state,
         }
         if side is not None:
             if side.get("avg_launch_ms", 0) > 0:

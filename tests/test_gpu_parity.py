@@ -1969,6 +1969,9 @@ def test_device_memory_pool_recycles_and_trims(cm, ctx):
         assert lib.cudamat_mem_info(0, C.byref(f), C.byref(t), C.byref(pf)) == 0
         return pf.value if pool else f.value
 
+    def same(a, b):
+        return abs(a - b) <= (32 << 20)          # (the runtime's own staging buffers for the uploads below come and go: 2 MB seen)
+
     lib.cudamat_plan_cache_clear()               # nothing of an earlier test's solver is left in a partly used segment
     assert lib.cudamat_pool_trim() == 0
     f0 = free_now()
@@ -1979,18 +1982,18 @@ def test_device_memory_pool_recycles_and_trims(cm, ctx):
     f1 = free_now()
     assert f1 <= f0 - GB + (64 << 20) and free_now(pool=True) >= GB            # still with the pool
     b = ctx.empty(GB // 8)
-    assert b.ptr == pa and free_now() == f1      # recycled, no driver call
+    assert b.ptr == pa and same(free_now(), f1)      # recycled, no driver call
     b.free()
     # two halves out of the one free block, written and read back: distinct memory
     c, d = ctx.empty(GB // 32), ctx.empty(GB // 32)          # 256 MB each: the 1 GB block is split (>= 64 MB left over)
-    assert free_now() == f1 and c.ptr == pa and d.ptr == pa + (GB // 4)
+    assert same(free_now(), f1) and c.ptr == pa and d.ptr == pa + (GB // 4)
     c.upload(np.full(GB // 32, 1.5))
     d.upload(np.full(GB // 32, -2.5))
     assert c.download()[-1] == 1.5 and d.download()[0] == -2.5
     c.free()
     d.free()
     e = ctx.empty(GB // 8)                       # the pieces merged again: the whole 1 GB fits where it was
-    assert e.ptr == pa and free_now() == f1
+    assert e.ptr == pa and same(free_now(), f1)
     e.free()
     # a small request is not pooled
     s = ctx.empty(1000)
