@@ -33,7 +33,25 @@ try:
 except AttributeError:
     HOST_CPU_SET = None
     HOST_CPUS = os.cpu_count() or 1
-os.environ.setdefault("OMP_PROC_BIND", "spread")
+
+
+def _several_ranks():
+    """True for every process of an N > 1 run (launcher, supervisors, workers): none of them runs the CPU baseline"""
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+        return True
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv) and sys.argv[i + 1].isdigit():
+            return int(sys.argv[i + 1]) > 1
+        if a.startswith("--gpus=") and a[7:].isdigit():
+            return int(a[7:]) > 1
+    return False
+
+
+# Only the process that times the CPU baseline (rank 0 at N = 1) asks for bound OpenMP threads: with the variable set,
+# libgomp pins the initial thread of EVERY process that loads it to one CPU, and the children a launcher or supervisor
+# starts inherit that one-CPU mask (a two-rank rehearsal showed `cpus_of_process: 1` in each worker).
+if not _several_ranks():
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
 
 
 def unpin_main_thread():
@@ -267,6 +285,7 @@ def supervisor(argv):
     import tempfile
     import torch
     import torch.distributed as dist
+    unpin_main_thread()      # (an OMP_PROC_BIND from the caller's environment: the workers started below inherit this thread's mask)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
     backend = os.environ.get("CUDAMAT_BENCH_BACKEND", "nccl")
