@@ -113,7 +113,7 @@ class GpuStateSampler:
         hw = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf) if bdf else []
         self.files = None
         if hw:
-            f = {"sclk_hz": "freq1_input", "power_uw": "power1_input", "temp_mc": "temp2_input"}
+            f = {"sclk_hz": "freq1_input", "power_uw": "power1_input", "temp_mc": "temp2_input", "mem_temp_mc": "temp3_input"}
             self.files = {k: os.path.join(hw[0], v) for k, v in f.items() if os.path.exists(os.path.join(hw[0], v))}
         if self.files:
             self.thread = threading.Thread(target=self._loop, daemon=True)
@@ -144,7 +144,7 @@ class GpuStateSampler:
             v = sorted(r[key] * scale for r in self.rows if key in r)
             return None if not v else {"min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)}
         return {"samples": len(self.rows), "sclk_mhz": stat("sclk_hz", 1e-6), "power_w": stat("power_uw", 1e-6),
-                "junction_c": stat("temp_mc", 1e-3), "source": "hwmon of the device, sampled during the timed region"}
+                "junction_c": stat("temp_mc", 1e-3), "hbm_c": stat("mem_temp_mc", 1e-3), "source": "hwmon of the device, sampled during the timed region"}
 
 
 def cpu_quota():
@@ -795,7 +795,7 @@ def run_bench(args):
         # per-launch SpMV timing = HIP events around every SpMV inside the loop; on L2-resident systems
         # (C2) the four event records per iteration would dominate the ~28 us iteration, and no roofline
         # is quoted for that latency-bound case anyway
-        latency_bound = n <= 200_000
+        latency_bound = n <= 200_000 or os.environ.get("CUDAMAT_BENCH_NO_EVENTS") == "1"      # (the switch: an A/B of the event records themselves, scripts/events_ab.sh)
         ms_spmv, n_spmv, ms_trsv, n_trsv, st = run(args.steps, flags | (0 if latency_bound else cm.FLAG_PROFILE))
         barrier()
         dt = time.perf_counter() - t0

@@ -70,6 +70,9 @@ int ensure_work(cudamat_solver *s)
         CM_TRY(dev_alloc((void **)q, nb));
         CM_HIP(hipMemsetAsync(*q, 0, nb, st));
     }
+    if (s->ctx->cfg.verbose)
+        fprintf(stderr, "[cudamat] work vectors: r %p rw %p p %p pw %p s %p t %p v %p (%zu bytes each)\n", (void *)s->r, (void *)s->rw, (void *)s->p,
+                (void *)s->pw, (void *)s->s, (void *)s->t, (void *)s->v, nb);
     if (s->sharded) {
         CM_TRY(dev_alloc((void **)&s->gather, nb * (size_t)s->comm.world));
         CM_HIP(hipMemsetAsync(s->gather, 0, nb * (size_t)s->comm.world, st));

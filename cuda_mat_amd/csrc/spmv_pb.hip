@@ -768,6 +768,8 @@ static void pb_print_plan(const PbPlan &p)
         hist[v == 0 ? 0 : v <= 8 ? 1 : v <= 24 ? 2 : v <= 48 ? 3 : v <= 64 ? 4 : v <= 128 ? 5 : 6]++;
         if (v > 64) in_long += v;
     }
+    fprintf(stderr, "[cudamat] pb arrays: pv %p pvi %p pc %p pr %p P %p sstart %p slen %p cstart %p\n", (void *)p.pv, (void *)p.pvi, (void *)p.pc,
+            (void *)p.pr, (void *)p.P, (void *)p.sstart, (void *)p.slen, (void *)p.cstart);
     fprintf(stderr, "[cudamat] pb plan: %d x %lld, nnz %lld, NCB %d (CB %d), NSUB %d (NW %d, SR %d), LPS %d, depth %d; segments: "
                     "empty %lld, 1-8 %lld, 9-24 %lld, 25-48 %lld, 49-64 %lld, 65-128 %lld, >128 %lld; %.1f %% of the entries in "
                     "segments longer than a wave\n",
