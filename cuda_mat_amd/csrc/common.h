@@ -15,6 +15,11 @@ namespace cm {
 // device memory comes from a recycling pool (pool.cpp): every hipMalloc / hipFree of this library's translation units
 hipError_t pool_malloc(void **out, size_t bytes);
 hipError_t pool_free(void *p);
+void pool_shrink(void *p, size_t bytes);      // keep the first `bytes` of a block, the rest goes back to the free list
+bool pool_segment_of(const void *p, char **seg_base, size_t *block_bytes);
+bool pool_split(void *p, size_t offset);      // one block in use becomes two, each freed on its own
+unsigned pool_generation();                   // moves whenever a segment went back to the driver
+bool pool_enabled();
 void pool_trim();                 // free blocks back to the driver (cudamat_plan_cache_clear, out-of-memory retries)
 size_t pool_free_bytes();         // what the current device's pool could hand out without asking the driver
 

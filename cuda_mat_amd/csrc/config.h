@@ -33,6 +33,7 @@ struct Config {
     int early_analysis = 1;       // EARLY_ANALYSIS     0: the drop-in call runs the ILU(0) level analysis after its upload, not beside it
     int pb_fill_occ = 0;          // PB_FILL_OCC        resident waves per CU of the two-pass fill's first pass (0: 8)
     int pb_fill2 = 1;             // PB_FILL2           0: the blocked copy is filled by the single-pass kernel of rounds 1-4
+    int pb_place = 1;             // PB_PLACE           large blocked copies: product stream in a memory class of its own (1: resident solvers, 2: drop-in calls too, 0: off)
     int pb_probe_fail = 0;        // PB_PROBE_FAIL      1 (tests): the LDS-order probe reports "not lane order"
     int pb_strict = 0;            // PB_STRICT          1: phase 2 adds a row's products of one wave instruction rank by rank (architected order)
     // ---- loop forms

@@ -515,7 +515,10 @@ int solve_host_locked(const Config &cfg, const HostSystem &h, bool speculative, 
                            g_cache.ctx->cfg == cfg;
     if (!candidate) cache_drop_locked();
     cudamat_ctx *ctx = candidate ? g_cache.ctx : nullptr;
-    if (!ctx) CM_TRY(cudamat_ctx_create(0, nullptr, &ctx));
+    if (!ctx) {
+        CM_TRY(cudamat_ctx_create(0, nullptr, &ctx));
+        ctx->cfg.pb_place = cfg.pb_place;          // (the one switch this entry point overrides, see cudamat_solve)
+    }
     double *d_b = nullptr, *d_x = nullptr, *d_d = nullptr;
     cudamat_solver *s = nullptr;
     bool reused = false, built_ilu = false;
@@ -594,7 +597,10 @@ extern "C" int cudamat_solve(int n, int nnz, const double *A, const int *iA, con
     CM_ARG(base == 0 || base == 1, "iA[0] must be 0 or 1");
     CM_ARG(iA[n] - base == nnz, "nnz != iA[n] - iA[0]");
     if (debug && loop == CUDAMAT_LOOP_PBICGSTAB) printf("N=%d, nnz=%d\n", n, nnz);   // :204
-    const Config cfg = config_from_env();                          // no caller-made context: the switches of THIS call
+    Config cfg = config_from_env();                                // no caller-made context: the switches of THIS call
+    // (placing a copy's arrays by memory class costs 10-35 ms of probing before the upload can start -- a fifth of a C4-sized
+    // call for a loop of a few iterations: only on request here, PB_PLACE=2)
+    cfg.pb_place = cfg.pb_place >= 2 ? 1 : 0;
     const HostSystem h{n, nnz, base, (int64_t)n, A, iA, jA, d, x0, b};
     std::lock_guard<std::mutex> cache_lock(g_cache.mu);            // (the entry points are not re-entrant upstream either)
     int rc = solve_host_locked(cfg, h, true, precond, loop, maxit, tol, debug, x, out);

@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 
@@ -45,6 +46,7 @@ struct DevicePool {
 
 std::mutex g_mu;
 std::map<int, DevicePool> g_pools;
+std::atomic<unsigned> g_generation{0};
 int g_enabled = -1;
 
 bool enabled()
@@ -78,6 +80,7 @@ void trim_locked(DevicePool &dp, size_t keep)
         if (whole_segment) {
             unlist_free(dp, base, b.size);
             (void)hipFree(base);
+            g_generation.fetch_add(1);
             it = dp.blocks.erase(it);
         } else {
             it = next;
@@ -86,6 +89,8 @@ void trim_locked(DevicePool &dp, size_t keep)
 }
 
 }  // namespace
+
+bool pool_enabled() { return enabled(); }
 
 hipError_t pool_malloc(void **out, size_t bytes)
 {
@@ -174,6 +179,72 @@ hipError_t pool_free(void *p)
     if (dp.free_bytes > kKeepFree) trim_locked(dp, kKeepFree);
     return es;
 }
+
+// keep the first `bytes` of a pooled block, hand the rest back to the free list (a caller that asked for more than it keeps:
+// the placement search of spmv_pb.hip walks device memory in steps larger than the array it places)
+void pool_shrink(void *p, size_t bytes)
+{
+    if (!p || !enabled()) return;
+    const size_t want = (bytes + kGranule - 1) / kGranule * kGranule;
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto &kv : g_pools) {
+        DevicePool &dp = kv.second;
+        auto it = dp.blocks.find((char *)p);
+        if (it == dp.blocks.end()) continue;
+        Block &b = it->second;
+        if (b.free || b.size < want + kSplitSlack) return;
+        char *rest = (char *)p + want;
+        const size_t rest_size = b.size - want;
+        b.size = want;
+        // (nothing of this process ever touched the tail except the placement probe, which has completed: no synchronisation)
+        auto ins = dp.blocks.emplace(rest, Block{rest_size, true, b.seg}).first;
+        auto next = std::next(ins);
+        if (next != dp.blocks.end() && next->second.free && next->second.seg == b.seg && rest + rest_size == next->first) {
+            unlist_free(dp, next->first, next->second.size);
+            ins->second.size += next->second.size;
+            dp.blocks.erase(next);
+        }
+        list_free(dp, rest, ins->second.size);
+        return;
+    }
+}
+
+// the driver allocation (segment) a pooled block was cut from; false for pointers the pool does not know
+bool pool_segment_of(const void *p, char **seg_base, size_t *block_bytes)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto &kv : g_pools) {
+        auto it = kv.second.blocks.find((char *)p);
+        if (it == kv.second.blocks.end()) continue;
+        if (seg_base) *seg_base = it->second.seg;
+        if (block_bytes) *block_bytes = it->second.size;
+        return true;
+    }
+    return false;
+}
+
+// one allocated block becomes two allocated blocks, the second starting `offset` bytes in (a multiple of the pool's 2 MB
+// granule); each is then freed on its own.  false: not a pooled block in use, or the offset does not fit
+bool pool_split(void *p, size_t offset)
+{
+    if (!p || offset == 0 || offset % kGranule) return false;
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto &kv : g_pools) {
+        DevicePool &dp = kv.second;
+        auto it = dp.blocks.find((char *)p);
+        if (it == dp.blocks.end()) continue;
+        Block &b = it->second;
+        if (b.free || offset >= b.size) return false;
+        dp.blocks[(char *)p + offset] = Block{b.size - offset, false, b.seg};
+        b.size = offset;
+        return true;
+    }
+    return false;
+}
+
+// counts the segments handed back to the driver: whoever remembers something about pooled ADDRESSES (the memory classes of
+// spmv_pb.hip's placement) forgets it when this moves
+unsigned pool_generation() { return g_generation.load(); }
 
 // everything the pool holds free goes back to the driver (cudamat_pool_trim, out-of-memory retries)
 void pool_trim()

@@ -48,6 +48,7 @@ struct PbPlan {
     // phase-1 launch parts: part 0 = the blocks of the local slice, part 1 + c = piece c of every other slice
     int *order = nullptr;          // NCB block ids, part after part
     int part_off[kPbMaxChunks + 2] = {0};
+    bool pc_zeroed = false;        // (construction: the alignment pads of pc are in place)
     double build_seconds = 0.0;
 };
 
@@ -65,6 +66,7 @@ struct PbBuild {
     // two-pass fill (k_pb_group + k_pb_scatter): groups of GB column blocks, NG groups; one packed (block, column, row) word
     // per entry between the passes (the values travel in the product stream), first entry of every (sub-block, group) bucket
     bool two_pass = false;
+    int place = 0;             // Config::pb_place
     int fill_occ = 0;          // Config::pb_fill_occ: resident waves per CU of pass A (0: default)
     int GB = 1, NG = 1;
     unsigned long long *smeta = nullptr;

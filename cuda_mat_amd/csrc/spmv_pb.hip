@@ -21,6 +21,9 @@
 // HBM traffic per SpMV: 10 B/nnz read + 8 B/nnz written (phase 1), 10 B/nnz read (phase 2).
 #include <algorithm>
 #include <chrono>
+#include <map>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "spmv_pb.h"
@@ -606,10 +609,7 @@ int pb_build_alloc(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int
         constexpr int align = kPbAlign;
         const size_t cap = (size_t)nnz + (size_t)(align - 1) * (size_t)p.NCB + 16;
         b->cap = cap;
-        if ((rc = dalloc(&p.pc, cap))) break;
-        if (align > 1 && hipMemsetAsync(p.pc, 0, sizeof(u16) * cap, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
-        if ((rc = dalloc(&p.pr, cap))) break;
-        if ((rc = dalloc(&p.P, cap))) break;
+        // (pc, pr, P and the value array: pb_build_values, which places them)
         if ((rc = dalloc(&p.cstart, (size_t)p.NCB + 1))) break;
         if ((rc = dalloc(&p.col0, (size_t)p.NCB + 1))) break;
         if ((rc = dalloc(&p.order, (size_t)p.NCB))) break;
@@ -659,6 +659,8 @@ int pb_build_alloc(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int
         while (b->GB * kPbGroups < p.NCB) b->GB *= 2;            // a power of two (group = block >> shift), <= kPbGroups groups
         b->NG = (p.NCB + b->GB - 1) / b->GB;
         b->fill_occ = cfg.pb_fill_occ;
+        b->place = cfg.pb_place;
+        b->verbose = cfg.verbose != 0;
         b->two_pass = cfg.pb_fill2 != 0 && nnz > 0 && nnz < 0x7fffffffLL && p.SR <= 65536 && b->GB <= 64;
         if (b->two_pass) {
             if (dalloc(&b->smeta, (size_t)nnz) != CUDAMAT_OK || dalloc(&b->gstart, (size_t)p.NSUB * (size_t)(b->NG + 1)) != CUDAMAT_OK) {
@@ -705,17 +707,281 @@ int pb_build_count(hipStream_t st, const Config &cfg, const int *rp, const int *
 }
 
 // the value array of the copy under construction: 8-bit indices into vd's dictionary when it has one, else fp64 values
+// ---- where the big arrays of a copy go (round 5) ---------------------------------------------------------------------
+// Device memory is not uniform for a kernel that reads one array while it writes another.  scripts/probe_classes.hip (48 chunks
+// of 2 GB, chunk i read while chunk j is written, every pair): 5.05 TB/s for some pairs, 5.52 for the others, nothing in
+// between -- and "slow together" is an equivalence relation with three classes (the stack ids of the 12-high HBM stacks,
+// presumably), each 2 GB block of the driver's allocator wholly in one, the classes following each other in runs of 1, 2, 4,
+// 8 ... blocks along the allocation order.  A phase-1-shaped kernel (8 B + 2 B read, 8 B written per entry) loses 5.5 % when
+// values and products share a class, 1.7 % when indices and products do; a phase-2-shaped one (8 B + 2 B read) 2.3 % when
+// products and indices do.  A process that allocates its arrays one after the other gets them from one class or from
+// whatever mixture the allocation order crosses: the judged SpMV pair took 2.50 ... 2.73 ms with identical code, from box
+// to box, from process to process, and alternating with every re-creation of a solver inside one process
+// (scripts/placement_probe*.py) -- the "+- 5 % box variance" of rounds 1-4.
+// So the four big arrays of a large copy are PLACED: slabs of 16 GB are taken from the allocator, cut into the driver's
+// 2 GB blocks (from the segment's start), every block is classified by timing (read a known block of class k, write this
+// one: slow = same class; <= 2 launches of 0.4 ms per block, remembered per address), and the arrays are cut out of runs
+// of blocks: the product stream in a class of its own, values and indices in another.  What is not used goes back to the
+// pool.  Bounded (<= 96 GB held, <= 0.3 s); if no such arrangement turns up the arrays are allocated as before round 5.
+__global__ __launch_bounds__(1024) void k_place_probe(const double2 *rd, double2 *wr, long n2)
+{
+    const long per = (n2 + gridDim.x - 1) / gridDim.x;
+    const long lo = blockIdx.x * per, hi = lo + per < n2 ? lo + per : n2;
+    for (long i = lo + threadIdx.x; i < hi; i += 1024) {
+        const double2 v = rd[i];
+        double2 o;
+        o.x = v.x * 1.5;
+        o.y = v.y + 1.0;
+        wr[i] = o;
+    }
+}
+
+struct PlaceTimer {
+    hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = false;
+    int launches = 0;
+    explicit PlaceTimer(hipStream_t s) : st(s) { ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess; }
+    ~PlaceTimer()
+    {
+        if (e0) CM_DROP(hipEventDestroy(e0));
+        if (e1) CM_DROP(hipEventDestroy(e1));
+    }
+    // faster of two timed launches after one untimed; < 0 on error
+    float ms(const void *rd, void *wr, size_t bytes)
+    {
+        float best = -1.f;
+        for (int rep = 0; rep < 3 && ok; rep++) {
+            if (hipEventRecord(e0, st) != hipSuccess) { ok = false; break; }
+            hipLaunchKernelGGL(k_place_probe, dim3(256), dim3(1024), 0, st, (const double2 *)rd, (double2 *)wr, (long)(bytes / 16));
+            float t = 0.f;
+            if (hipGetLastError() != hipSuccess || hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&t, e0, e1) != hipSuccess) { ok = false; break; }
+            launches++;
+            if (rep > 0 && (best < 0.f || t < best)) best = t;
+        }
+        return ok ? best : -1.f;
+    }
+};
+
+constexpr size_t kPlaceBlock = (size_t)2 << 30;           // the driver hands out device memory in blocks of at most 2 GB
+constexpr size_t kPlaceSample = (size_t)896 << 20;        // bytes read and bytes written by one timed launch: well beyond the 256 MB
+                                                          // Infinity Cache (256 MB samples read 0.101 against 0.097 ms whatever the classes)
+constexpr size_t kPlaceSlab = (size_t)16 << 30;
+constexpr size_t kPlaceMinBytes = (size_t)2 << 30;        // copies whose product stream is smaller are not placed
+constexpr size_t kPlaceMaxHeld = (size_t)96 << 30;
+constexpr double kPlaceMaxSeconds = 0.3;
+constexpr float kPlaceRatio = 0.97f;                      // another class: reading the reference beside the writes takes less than this
+                                                          // fraction of reading and writing inside one block (measured: 0.93-0.95 / 1.0)
+
+// what is known about pooled addresses: the class of every 2 GB block met so far, one reference block per class, the time of
+// a sample read and written inside one block.  Forgotten when the pool hands a segment back to the driver.
+struct PlaceMemo {
+    std::mutex mu;
+    unsigned gen = ~0u;
+    std::map<char *, int> cls;
+    std::vector<char *> ref;
+    float t_own = 0.f;
+};
+static PlaceMemo g_place;
+
+struct PlaceRun { size_t slab; size_t first, count; int cls; };      // blocks [first, first + count) of one slab, all of one class
+
+struct PlaceSlab {
+    char *base = nullptr;        // the pooled block
+    size_t bytes = 0;
+    char *b0 = nullptr;          // first whole 2 GB block inside it (from the segment's start)
+    std::vector<int> cls;        // class of every whole block
+    std::vector<char> taken;
+};
+
+// class of the 2 GB block at `blk` (memo held by the caller's lock); -1: no verdict
+static int place_class_of(PlaceTimer &tm, PlaceMemo &m, char *blk)
+{
+    auto it = m.cls.find(blk);
+    if (it != m.cls.end()) return it->second;
+    if (m.t_own <= 0.f) {
+        m.t_own = tm.ms(blk, blk + kPlaceBlock - kPlaceSample, kPlaceSample);
+        if (m.t_own <= 0.f) return -1;
+    }
+    int c = -1;
+    for (size_t k = 0; k < m.ref.size() && c < 0; k++) {
+        if (k + 1 == m.ref.size() && m.ref.size() >= 3) { c = (int)k; break; }          // (three classes: not the first two = the third)
+        const float t = tm.ms(m.ref[k], blk + kPlaceBlock - kPlaceSample, kPlaceSample);
+        if (t <= 0.f) return -1;
+        if (t >= kPlaceRatio * m.t_own) c = (int)k;
+    }
+    if (c < 0) {
+        c = (int)m.ref.size();
+        m.ref.push_back(blk);
+    }
+    m.cls[blk] = c;
+    return c;
+}
+
+// the first run of >= `need` free blocks of class `want` (>= 0) or of any class but `avoid`; false if none
+static bool place_find(std::vector<PlaceSlab> &slabs, size_t need, int want, int avoid, PlaceRun *out)
+{
+    for (size_t si = 0; si < slabs.size(); si++) {
+        PlaceSlab &sl = slabs[si];
+        for (size_t i = 0; i + need <= sl.cls.size(); i++) {
+            const int c = sl.cls[i];
+            if (c < 0 || (want >= 0 && c != want) || c == avoid) continue;
+            bool ok = true;
+            for (size_t j = i; j < i + need && ok; j++) ok = !sl.taken[j] && sl.cls[j] == c;
+            if (!ok) continue;
+            for (size_t j = i; j < i + need; j++) sl.taken[j] = 1;
+            *out = PlaceRun{si, i, need, c};
+            return true;
+        }
+    }
+    return false;
+}
+
+// the four big arrays of a copy, placed (see above).  sizes in bytes; vals / idx / prod receive pointers that are pooled blocks
+// of their own (freed one by one as ever).  CUDAMAT_OK with *placed = false: nothing allocated, allocate as before.
+static int place_copy(hipStream_t st, bool verbose, size_t b_vals, size_t b_idx, size_t b_prod, void **vals, void **pc, void **pr, void **prod, bool *placed)
+{
+    *placed = false;
+    if (!pool_enabled()) return CUDAMAT_OK;
+    const double t0 = now_s();
+    PlaceTimer tm(st);
+    if (!tm.ok) return CUDAMAT_OK;
+    std::lock_guard<std::mutex> lock(g_place.mu);
+    PlaceMemo &m = g_place;
+    if (m.gen != pool_generation()) {
+        m.gen = pool_generation();
+        m.cls.clear();
+        m.ref.clear();
+    }
+    const size_t gran = (size_t)2 << 20;
+    auto up = [&](size_t x) { return (x + gran - 1) / gran * gran; };
+    const size_t a_vals = up(b_vals), a_idx = up(b_idx), a_prod = up(b_prod);
+    const size_t n_prod = (a_prod + kPlaceBlock - 1) / kPlaceBlock, n_rest = (a_vals + 2 * a_idx + kPlaceBlock - 1) / kPlaceBlock;
+    const size_t slab_bytes = std::max(kPlaceSlab, (n_prod + n_rest + 1) * kPlaceBlock);
+    std::vector<PlaceSlab> slabs;
+    PlaceRun r_prod{}, r_rest{};
+    bool found = false;
+    size_t held = 0;
+    while (!found) {
+        if (held + slab_bytes > kPlaceMaxHeld || now_s() - t0 > kPlaceMaxSeconds) break;
+        PlaceSlab sl;
+        if (hipMalloc(&sl.base, slab_bytes) != hipSuccess) { CM_DROP(hipGetLastError()); break; }
+        sl.bytes = slab_bytes;
+        held += slab_bytes;
+        char *seg = nullptr;
+        size_t blk_bytes = 0;
+        if (!pool_segment_of(sl.base, &seg, &blk_bytes)) { slabs.push_back(sl); break; }
+        sl.bytes = blk_bytes;
+        sl.b0 = seg + ((size_t)(sl.base - seg) + kPlaceBlock - 1) / kPlaceBlock * kPlaceBlock;
+        const size_t whole = sl.b0 + kPlaceBlock <= sl.base + sl.bytes ? (size_t)(sl.base + sl.bytes - sl.b0) / kPlaceBlock : 0;
+        bool verdicts = true;
+        for (size_t i = 0; i < whole && verdicts; i++) {
+            const int c = place_class_of(tm, m, sl.b0 + i * kPlaceBlock);
+            verdicts = c >= 0;
+            sl.cls.push_back(c);
+        }
+        sl.taken.assign(sl.cls.size(), 0);
+        slabs.push_back(sl);
+        if (!verdicts) break;
+        // the product stream in a class of its own: try every class met so far for it
+        for (size_t a = 0; a < m.ref.size() && !found; a++) {
+            for (auto &q : slabs) std::fill(q.taken.begin(), q.taken.end(), 0);
+            found = place_find(slabs, n_prod, (int)a, -1, &r_prod) && place_find(slabs, n_rest, -1, (int)a, &r_rest);
+        }
+    }
+    if (found) {
+        // cut the slabs: [values | column indices | row indices] out of one run, the product stream out of the other; every cut is
+        // a block of the pool, the pieces not wanted go back to it
+        struct Cut { char *p; bool keep; };
+        char *p_rest = slabs[r_rest.slab].b0 + r_rest.first * kPlaceBlock, *p_prod = slabs[r_prod.slab].b0 + r_prod.first * kPlaceBlock;
+        for (size_t si = 0; si < slabs.size(); si++) {
+            PlaceSlab &sl = slabs[si];
+            std::vector<Cut> cuts;          // ascending addresses inside this slab
+            auto add = [&](char *p, bool keep) { if (p > sl.base && p < sl.base + sl.bytes) cuts.push_back(Cut{p, keep}); };
+            std::vector<std::pair<char *, bool>> marks;
+            if (r_rest.slab == si) {
+                marks.push_back({p_rest, true});
+                marks.push_back({p_rest + a_vals, true});
+                marks.push_back({p_rest + a_vals + a_idx, true});
+                marks.push_back({p_rest + a_vals + 2 * a_idx, false});
+            }
+            if (r_prod.slab == si) {
+                marks.push_back({p_prod, true});
+                marks.push_back({p_prod + a_prod, false});
+            }
+            std::sort(marks.begin(), marks.end());
+            for (size_t k = 0; k < marks.size(); k++) {
+                if (k + 1 < marks.size() && marks[k + 1].first == marks[k].first) { marks[k + 1].second = marks[k].second || marks[k + 1].second; continue; }
+                add(marks[k].first, marks[k].second);
+            }
+            // from the highest address down: every split then acts on the block that still starts at sl.base
+            bool ok = true;
+            for (size_t k = cuts.size(); k-- > 0 && ok;) ok = pool_split(sl.base, (size_t)(cuts[k].p - sl.base));
+            if (!ok) { found = false; break; }           // (cannot happen: every cut is granule-aligned inside the block)
+            const bool base_kept = (r_rest.slab == si && p_rest == sl.base) || (r_prod.slab == si && p_prod == sl.base);
+            if (!base_kept) CM_DROP(hipFree(sl.base));
+            for (auto &c : cuts)
+                if (!c.keep) CM_DROP(hipFree(c.p));
+            sl.base = nullptr;
+        }
+        if (found) {
+            *vals = p_rest;
+            *pc = p_rest + a_vals;
+            *pr = p_rest + a_vals + a_idx;
+            *prod = p_prod;
+            *placed = true;
+        }
+    }
+    for (auto &sl : slabs)
+        if (sl.base) CM_DROP(hipFree(sl.base));
+    if (verbose) {
+        std::string seen;
+        for (auto &sl : slabs) {
+            for (int c : sl.cls) seen += c < 0 ? '?' : (char)('0' + c % 10);
+            seen += ' ';
+        }
+        fprintf(stderr, "[cudamat] pb placement: %s; %zu slab(s) of %.0f GB, blocks by class: %s, %d timed launches, %.1f ms (one block read + written: %.3f ms)\n",
+                *placed ? "product stream in a memory class of its own, values and indices in another" : "no arrangement found: arrays allocated one after the other",
+                slabs.size(), (double)slab_bytes / (double)((size_t)1 << 30), seen.c_str(), tm.launches, (now_s() - t0) * 1e3, m.t_own);
+    }
+    return CUDAMAT_OK;
+}
+
 int pb_build_values(hipStream_t st, PbBuild *b, const ValDict *vd)
 {
     PbPlan &p = b->p;
+    const size_t cap = b->cap;
+    const bool dict = vd && vd->n > 0;
     int rc = CUDAMAT_OK;
-    if (vd && vd->n > 0) {
-        if ((rc = dalloc(&p.pvi, b->cap)) == CUDAMAT_OK && hipMemsetAsync(p.pvi, 0, b->cap, st) != hipSuccess) rc = CUDAMAT_ERR_HIP;
-        p.dict = vd->dict;
-        p.ndict = vd->n;
-    } else {
-        if ((rc = dalloc(&p.pv, b->cap)) == CUDAMAT_OK && hipMemsetAsync(p.pv, 0, sizeof(double) * b->cap, st) != hipSuccess) rc = CUDAMAT_ERR_HIP;
-    }
+    do {
+        if (!p.P && b->place > 0 && sizeof(double) * cap >= kPlaceMinBytes) {
+            void *v = nullptr, *c = nullptr, *r = nullptr, *pp = nullptr;
+            bool placed = false;
+            if ((rc = place_copy(st, b->verbose, dict ? cap : sizeof(double) * cap, sizeof(u16) * cap, sizeof(double) * cap, &v, &c, &r, &pp, &placed))) break;
+            if (placed) {
+                if (dict) p.pvi = (unsigned char *)v; else p.pv = (double *)v;
+                p.pc = (u16 *)c;
+                p.pr = (u16 *)r;
+                p.P = (double *)pp;
+            }
+        }
+        if (dict) {
+            if (!p.pvi && (rc = dalloc(&p.pvi, cap))) break;
+            if (hipMemsetAsync(p.pvi, 0, cap, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+            p.dict = vd->dict;
+            p.ndict = vd->n;
+        } else {
+            if (!p.pv && (rc = dalloc(&p.pv, cap))) break;
+            if (hipMemsetAsync(p.pv, 0, sizeof(double) * cap, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        }
+        if (p.P && p.pc && p.pr && p.pc_zeroed) break;          // (the drop-in path swaps fp64 values for dictionary indices afterwards: the rest is in place)
+        if (!p.pc && (rc = dalloc(&p.pc, cap))) break;
+        if (!p.pr && (rc = dalloc(&p.pr, cap))) break;
+        if (!p.P && (rc = dalloc(&p.P, cap))) break;
+        if (kPbAlign > 1 && hipMemsetAsync(p.pc, 0, sizeof(u16) * cap, st) != hipSuccess) { rc = CUDAMAT_ERR_HIP; break; }
+        p.pc_zeroed = true;
+    } while (0);
     if (rc) pb_build_abort(b);
     return rc;
 }

@@ -1,0 +1,52 @@
+"""Run by tests/test_gpu_parity.py::test_placed_blocked_copy_is_the_same_copy in a process of its own: a blocked copy whose
+arrays are placed by memory class (csrc/spmv_pb.hip place_copy: slabs cut into pool blocks) against the same copy allocated
+one array after the other -- identical SpMV results, the placement reported under VERBOSE, and every byte back with the
+driver after close + trim (the cuts leak nothing)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cuda_mat_amd as cm  # noqa: E402
+
+
+def main():
+    lib = cm.lib()
+    n, per = 6_000_000, 50                     # 3e8 entries: a 2.4 GB product stream (placement starts at 2 GB)
+    results = {}
+    for place in ("1", "0", "1"):
+        ctx = cm.Context(0)
+        ctx.set_option("VALUE_DICT", "0").set_option("SPMV_MODE", "pb").set_option("PB_PLACE", place).set_option("VERBOSE", "1")
+
+        def free_now():
+            ctx.sync()
+            f, t, pf = C.c_size_t(), C.c_size_t(), C.c_size_t()
+            assert lib.cudamat_mem_info(0, C.byref(f), C.byref(t), C.byref(pf)) == 0
+            return f.value, pf.value
+
+        rp, ci, va = ctx.empty(n + 1, np.int32), ctx.empty(n * per, np.int32), ctx.empty(n * per)
+        ctx.gen_rand_rows(n, per, 11, 0, n, 0, rp, ci, va)
+        x, y = ctx.empty(n), ctx.empty(n)
+        ctx.gen_xstar(0, n, 5, x)
+        assert lib.cudamat_pool_trim() == 0
+        f0, _ = free_now()
+        s = cm.Solver(ctx, n, n, n * per, rp, ci, va, 0)
+        s.spmv(x, y)
+        assert s.spmv_mode() == 1
+        out = y.download()
+        s.close()
+        assert lib.cudamat_pool_trim() == 0
+        f1, pf1 = free_now()
+        assert abs(f1 - f0) <= (64 << 20) and pf1 == 0, (place, f0, f1, pf1)          # nothing of the copy is left anywhere
+        results.setdefault(place, []).append(out)
+        for a in (rp, ci, va, x, y):
+            a.free()
+        ctx.close()
+    assert np.array_equal(results["1"][0], results["0"][0]) and np.array_equal(results["1"][1], results["0"][0])
+    print("place_check ok")
+
+
+if __name__ == "__main__":
+    main()
