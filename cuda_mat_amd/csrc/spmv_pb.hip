@@ -857,10 +857,15 @@ static int place_copy(hipStream_t st, bool verbose, size_t b_vals, size_t b_idx,
     const size_t gran = (size_t)2 << 20;
     auto up = [&](size_t x) { return (x + gran - 1) / gran * gran; };
     const size_t a_vals = up(b_vals), a_idx = up(b_idx), a_prod = up(b_prod);
-    const size_t n_prod = (a_prod + kPlaceBlock - 1) / kPlaceBlock, n_rest = (a_vals + 2 * a_idx + kPlaceBlock - 1) / kPlaceBlock;
-    const size_t slab_bytes = std::max(kPlaceSlab, (n_prod + n_rest + 1) * kPlaceBlock);
+    // [values | column indices | row indices] out of one run of blocks, the product stream out of a run of another class.  (Measured
+    // at C4, ms per launch of phase 1 / phase 2: this arrangement 1.645-1.658 / 0.934-0.964; the indices in a third class
+    // 1.662-1.683 / 0.935-0.971; the indices in the products' class 1.674-1.715 / 0.957-0.987; unplaced, same box: 1.715-1.752 /
+    // 0.964-1.003.)
+    const size_t n_prod = (a_prod + kPlaceBlock - 1) / kPlaceBlock;
+    const size_t n_vals = (a_vals + 2 * a_idx + kPlaceBlock - 1) / kPlaceBlock;
+    const size_t slab_bytes = std::max(kPlaceSlab, (n_prod + n_vals + 1) * kPlaceBlock);
     std::vector<PlaceSlab> slabs;
-    PlaceRun r_prod{}, r_rest{};
+    PlaceRun r_prod{}, r_vals{};
     bool found = false;
     size_t held = 0;
     while (!found) {
@@ -887,49 +892,42 @@ static int place_copy(hipStream_t st, bool verbose, size_t b_vals, size_t b_idx,
         // the product stream in a class of its own: try every class met so far for it
         for (size_t a = 0; a < m.ref.size() && !found; a++) {
             for (auto &q : slabs) std::fill(q.taken.begin(), q.taken.end(), 0);
-            found = place_find(slabs, n_prod, (int)a, -1, &r_prod) && place_find(slabs, n_rest, -1, (int)a, &r_rest);
+            found = place_find(slabs, n_prod, (int)a, -1, &r_prod) && place_find(slabs, n_vals, -1, (int)a, &r_vals);
         }
     }
     if (found) {
-        // cut the slabs: [values | column indices | row indices] out of one run, the product stream out of the other; every cut is
-        // a block of the pool, the pieces not wanted go back to it
-        struct Cut { char *p; bool keep; };
-        char *p_rest = slabs[r_rest.slab].b0 + r_rest.first * kPlaceBlock, *p_prod = slabs[r_prod.slab].b0 + r_prod.first * kPlaceBlock;
+        // cut the slabs: every array becomes a block of the pool (freed on its own as ever), the pieces not wanted go back to it
+        struct Keep { size_t slab; char *p; size_t bytes; void **out; };
+        char *p_vals = slabs[r_vals.slab].b0 + r_vals.first * kPlaceBlock, *p_prod = slabs[r_prod.slab].b0 + r_prod.first * kPlaceBlock;
+        char *p_idx = p_vals + a_vals;
+        const size_t s_idx = r_vals.slab;
+        const Keep keeps[4] = {{r_vals.slab, p_vals, a_vals, vals}, {s_idx, p_idx, a_idx, pc}, {s_idx, p_idx + a_idx, a_idx, pr}, {r_prod.slab, p_prod, a_prod, prod}};
         for (size_t si = 0; si < slabs.size(); si++) {
             PlaceSlab &sl = slabs[si];
-            std::vector<Cut> cuts;          // ascending addresses inside this slab
-            auto add = [&](char *p, bool keep) { if (p > sl.base && p < sl.base + sl.bytes) cuts.push_back(Cut{p, keep}); };
-            std::vector<std::pair<char *, bool>> marks;
-            if (r_rest.slab == si) {
-                marks.push_back({p_rest, true});
-                marks.push_back({p_rest + a_vals, true});
-                marks.push_back({p_rest + a_vals + a_idx, true});
-                marks.push_back({p_rest + a_vals + 2 * a_idx, false});
-            }
-            if (r_prod.slab == si) {
-                marks.push_back({p_prod, true});
-                marks.push_back({p_prod + a_prod, false});
+            std::vector<std::pair<char *, bool>> marks, cuts;          // (address, the block that starts there is kept)
+            bool base_kept = false;
+            for (const Keep &k : keeps) {
+                if (k.slab != si) continue;
+                marks.push_back({k.p, true});
+                marks.push_back({k.p + k.bytes, false});
+                base_kept = base_kept || k.p == sl.base;
             }
             std::sort(marks.begin(), marks.end());
             for (size_t k = 0; k < marks.size(); k++) {
                 if (k + 1 < marks.size() && marks[k + 1].first == marks[k].first) { marks[k + 1].second = marks[k].second || marks[k + 1].second; continue; }
-                add(marks[k].first, marks[k].second);
+                if (marks[k].first > sl.base && marks[k].first < sl.base + sl.bytes) cuts.push_back(marks[k]);
             }
             // from the highest address down: every split then acts on the block that still starts at sl.base
             bool ok = true;
-            for (size_t k = cuts.size(); k-- > 0 && ok;) ok = pool_split(sl.base, (size_t)(cuts[k].p - sl.base));
+            for (size_t k = cuts.size(); k-- > 0 && ok;) ok = pool_split(sl.base, (size_t)(cuts[k].first - sl.base));
             if (!ok) { found = false; break; }           // (cannot happen: every cut is granule-aligned inside the block)
-            const bool base_kept = (r_rest.slab == si && p_rest == sl.base) || (r_prod.slab == si && p_prod == sl.base);
             if (!base_kept) CM_DROP(hipFree(sl.base));
             for (auto &c : cuts)
-                if (!c.keep) CM_DROP(hipFree(c.p));
+                if (!c.second) CM_DROP(hipFree(c.first));
             sl.base = nullptr;
         }
         if (found) {
-            *vals = p_rest;
-            *pc = p_rest + a_vals;
-            *pr = p_rest + a_vals + a_idx;
-            *prod = p_prod;
+            for (const Keep &k : keeps) *k.out = k.p;
             *placed = true;
         }
     }
