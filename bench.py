@@ -534,7 +534,7 @@ def main():
 
 # keys of a full line that a side section keeps (the rest is either the headline's business or repeats the section's name)
 SECTION_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "spmv_gbs", "spmv_form", "value_dictionary",
-                "trsv_ms_per_apply", "trsv_roofline", "trsv_traffic", "levels", "setup_s", "drop_in", "gpu_state")
+                "trsv_ms_per_apply", "trsv_roofline", "trsv_traffic", "levels", "setup_s", "drop_in", "gpu_state", "memory_placement")
 OTHER_CONFIGS = (      # BASELINE.json configs[2], [4], [1]: name, argument overrides
     ("poisson5", {"workload": "poisson5", "precond": "none", "steps": 200, "warmup": 10}),
     ("rand50_ilu0", {"workload": "rand50", "precond": "ilu0", "steps": 50, "warmup": 5}),
@@ -806,6 +806,7 @@ def run_bench(args):
         # run like a host program's would -- not beside a second ~50 GB solver of the same matrix -- and draw on the blocks it
         # hands back to the library's pool (csrc/pool.cpp)
         sv_mode, sv_kernel, sv_dict = solver.spmv_mode(), solver.spmv_kernel(), solver.value_dict()
+        sv_place = solver.placement()
 
         # The value dictionary as a side figure: the same workload timed -- outside the judged region, one GPU only -- with
         # the 8-bit value indices the library would pick by itself for this matrix (<= 256 distinct values)
@@ -985,6 +986,9 @@ def run_bench(args):
             # (CUDAMAT_VALUE_DICT=0) unless CUDAMAT_BENCH_HEADLINE=dict: SURVEY 8d's generator draws from 39 distinct values,
             # which the 8-bit dictionary form would exploit -- that run is the side figure `with_value_dictionary`
             "value_dictionary": sv_dict,
+            # where the blocked copy's arrays went: device memory comes in three classes and the product stream is placed in one of
+            # its own (csrc/spmv_pb.hip place_copy; unplaced, the same kernels took 2.50 ... 2.77 ms per launch pair by luck of the draw)
+            "memory_placement": sv_place,
             # untimed iterations run before the W warm-up steps to bring the GPU out of its idle power state (--gpu-warm-seconds)
             "gpu_warm": {"seconds": args.gpu_warm_seconds, "steps": warm_steps},
             # where the host side of this process runs: the CPUs local to the GPU's PCIe root (bind_near_gpu)

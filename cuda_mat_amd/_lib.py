@@ -121,6 +121,7 @@ _SIGS = {
     "cudamat_solver_spmv_mode": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "cudamat_solver_spmv_kernel": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "cudamat_solver_value_dict": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "cudamat_solver_placement": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_char_p, C.c_int]),
     "cudamat_solver_spmv": (C.c_int, [_P, _P, _P]),
     "cudamat_solver_solve": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                        C.POINTER(Stats)]),

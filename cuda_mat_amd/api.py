@@ -346,6 +346,13 @@ class Solver:
         check(_lib.lib().cudamat_solver_spmv_kernel(self.h, buf, 96))
         return buf.value.decode()
 
+    def placement(self):
+        """where the blocked copy's arrays went: {"placed": 1 / 0 / -1 (not tried), "slabs", "seconds", "classes"} (include/cudamat.h)"""
+        placed, slabs, sec = C.c_int(), C.c_int(), C.c_double()
+        buf = C.create_string_buffer(128)
+        check(_lib.lib().cudamat_solver_placement(self.h, C.byref(placed), C.byref(slabs), C.byref(sec), buf, 128))
+        return {"placed": placed.value, "slabs": slabs.value, "seconds": sec.value, "blocks_by_class": buf.value.decode().strip()}
+
     def value_dict(self):
         """distinct values when the selected SpMV form reads 8-bit indices into a value dictionary, else 0"""
         m = C.c_int()

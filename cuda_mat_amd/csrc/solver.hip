@@ -884,6 +884,21 @@ extern "C" int cudamat_solver_value_dict(cudamat_solver *s, int *distinct)
     return CUDAMAT_OK;
 }
 
+extern "C" int cudamat_solver_placement(cudamat_solver *s, int *placed, int *slabs, double *seconds, char *classes, int cap)
+{
+    CM_ARG(s, "null pointer");
+    CM_HIP(hipSetDevice(s->ctx->device));
+    CM_TRY(ensure_work(s));
+    CM_TRY(ensure_spmv_mode(s));
+    // (a preconditioned loop that runs in the level-major spaces multiplies by the permuted matrix's copy)
+    const PbPlan *q = s->pb_perm.P ? &s->pb_perm : s->spmv_mode == 1 && s->pb.P ? &s->pb : nullptr;
+    if (placed) *placed = q ? q->placed : -1;
+    if (slabs) *slabs = q ? q->place_slabs : 0;
+    if (seconds) *seconds = q ? q->place_seconds : 0.0;
+    if (classes && cap > 0) snprintf(classes, (size_t)cap, "%s", q ? q->place_classes : "");
+    return CUDAMAT_OK;
+}
+
 extern "C" int cudamat_solver_spmv_kernel(cudamat_solver *s, char *name, int cap)
 {
     CM_ARG(s && name && cap > 0, "null pointer");

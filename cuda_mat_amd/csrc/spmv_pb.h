@@ -48,6 +48,10 @@ struct PbPlan {
     // phase-1 launch parts: part 0 = the blocks of the local slice, part 1 + c = piece c of every other slice
     int *order = nullptr;          // NCB block ids, part after part
     int part_off[kPbMaxChunks + 2] = {0};
+    int placed = -1;               // -1: not tried (small copy / PB_PLACE=0); 0: no arrangement found; 1: product stream in a memory class of its own
+    int place_slabs = 0;           // slabs of device memory the placement search classified
+    double place_seconds = 0.0;
+    char place_classes[96] = {0};  // their 2 GB blocks by class, e.g. "00000000 11112222"
     bool pc_zeroed = false;        // (construction: the alignment pads of pc are in place)
     double build_seconds = 0.0;
 };

@@ -840,7 +840,8 @@ static bool place_find(std::vector<PlaceSlab> &slabs, size_t need, int want, int
 
 // the four big arrays of a copy, placed (see above).  sizes in bytes; vals / idx / prod receive pointers that are pooled blocks
 // of their own (freed one by one as ever).  CUDAMAT_OK with *placed = false: nothing allocated, allocate as before.
-static int place_copy(hipStream_t st, bool verbose, size_t b_vals, size_t b_idx, size_t b_prod, void **vals, void **pc, void **pr, void **prod, bool *placed)
+static int place_copy(hipStream_t st, bool verbose, size_t b_vals, size_t b_idx, size_t b_prod, void **vals, void **pc, void **pr, void **prod, bool *placed,
+                      PbPlan *report)
 {
     *placed = false;
     if (!pool_enabled()) return CUDAMAT_OK;
@@ -933,12 +934,16 @@ static int place_copy(hipStream_t st, bool verbose, size_t b_vals, size_t b_idx,
     }
     for (auto &sl : slabs)
         if (sl.base) CM_DROP(hipFree(sl.base));
+    std::string seen;
+    for (auto &sl : slabs) {
+        for (int c : sl.cls) seen += c < 0 ? '?' : (char)('0' + c % 10);
+        seen += ' ';
+    }
+    report->placed = *placed ? 1 : 0;
+    report->place_slabs = (int)slabs.size();
+    report->place_seconds = now_s() - t0;
+    snprintf(report->place_classes, sizeof(report->place_classes), "%s", seen.c_str());
     if (verbose) {
-        std::string seen;
-        for (auto &sl : slabs) {
-            for (int c : sl.cls) seen += c < 0 ? '?' : (char)('0' + c % 10);
-            seen += ' ';
-        }
         fprintf(stderr, "[cudamat] pb placement: %s; %zu slab(s) of %.0f GB, blocks by class: %s, %d timed launches, %.1f ms (one block read + written: %.3f ms)\n",
                 *placed ? "product stream in a memory class of its own, values and indices in another" : "no arrangement found: arrays allocated one after the other",
                 slabs.size(), (double)slab_bytes / (double)((size_t)1 << 30), seen.c_str(), tm.launches, (now_s() - t0) * 1e3, m.t_own);
@@ -956,7 +961,7 @@ int pb_build_values(hipStream_t st, PbBuild *b, const ValDict *vd)
         if (!p.P && b->place > 0 && sizeof(double) * cap >= kPlaceMinBytes) {
             void *v = nullptr, *c = nullptr, *r = nullptr, *pp = nullptr;
             bool placed = false;
-            if ((rc = place_copy(st, b->verbose, dict ? cap : sizeof(double) * cap, sizeof(u16) * cap, sizeof(double) * cap, &v, &c, &r, &pp, &placed))) break;
+            if ((rc = place_copy(st, b->verbose, dict ? cap : sizeof(double) * cap, sizeof(u16) * cap, sizeof(double) * cap, &v, &c, &r, &pp, &placed, &p))) break;
             if (placed) {
                 if (dict) p.pvi = (unsigned char *)v; else p.pv = (double *)v;
                 p.pc = (u16 *)c;

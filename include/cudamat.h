@@ -306,6 +306,12 @@ int cudamat_solver_value_dict(cudamat_solver *s, int *distinct);
 /* name(s) of the HIP kernel(s) one SpMV launch of this solver runs (e.g. "k_pb_phase1 + k_pb_phase2", "k_spmv_stream_c<256>",
  * "k_spmv<32>"): what a rocprofv3 kernel trace of the loop shows, for the bench line's `roofline.kernel`            */
 int cudamat_solver_spmv_kernel(cudamat_solver *s, char *name, int cap);
+/* Where the blocked copy's arrays went (round 5, csrc/spmv_pb.hip): device memory comes in classes, and a kernel that reads one
+ * array while it writes another loses 5-7 % when both lie in one class, so the product stream of a large copy is placed in a
+ * class of its own.  *placed: 1 placed, 0 searched without finding an arrangement, -1 not tried (another SpMV form, a copy
+ * below 2 GB of products, PB_PLACE = 0, a drop-in call without PB_PLACE = 2); *slabs: 16 GB slabs classified; *seconds: what
+ * the search took; classes: their 2 GB blocks by class ("00000000 11112222"), at most cap - 1 characters.            */
+int cudamat_solver_placement(cudamat_solver *s, int *placed, int *slabs, double *seconds, char *classes, int cap);
 /* y_local = (A + diag(d)) x ; x is the LOCAL slice, gathered through comm if sharded  */
 int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, double *y_local);
 /* Solve.  b, x: device vectors of n_local doubles; x holds the initial guess on entry
