@@ -637,6 +637,11 @@ def run_bench(args):
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         ctx = cm.Context(local_rank, stream=stream.cuda_stream)
+        # the resident solver's one-off placement of its arrays by memory class may take what it takes: on boxes whose
+        # allocator runs at 8 GB/s the search's 32 GB of slabs cost 4 s, the library's default budget (0.3 s) would give up, and the
+        # loop timed below would run at the luck of the draw (175 ... 190 it/s).  Set-up, reported in `memory_placement.seconds`.
+        if "CUDAMAT_PB_PLACE_MAX_MS" not in os.environ:
+            ctx.set_option("PB_PLACE_MAX_MS", "20000")
         # ---- generate this rank's row block in HBM
         def make_solver():
             if args.workload == "rand50":
@@ -807,6 +812,7 @@ def run_bench(args):
         # hands back to the library's pool (csrc/pool.cpp)
         sv_mode, sv_kernel, sv_dict = solver.spmv_mode(), solver.spmv_kernel(), solver.value_dict()
         sv_place = solver.placement()
+        sv_place["budget_ms"] = int(os.environ.get("CUDAMAT_PB_PLACE_MAX_MS", "20000"))
 
         # The value dictionary as a side figure: the same workload timed -- outside the judged region, one GPU only -- with
         # the 8-bit value indices the library would pick by itself for this matrix (<= 256 distinct values)

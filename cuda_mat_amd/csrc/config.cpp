@@ -54,6 +54,7 @@ const Option kOptions[] = {
     OPT_INT("PB_FILL_OCC", pb_fill_occ, 0, 64, "resident waves per CU of the two-pass fill's first pass (0: 8; probing)"),
     OPT_FLAG("PB_FILL2", pb_fill2, "0: fill the blocked copy with the single-pass scatter kernel (rounds 1-4) instead of the two-pass partition"),
     OPT_INT("PB_PLACE", pb_place, 0, 2, "blocked copy of a large matrix: 1 (default): a resident solver's product stream is placed in a memory class of its own, values and indices in another (timed probe of the device's memory classes, 10-35 ms per copy: spmv_pb.hip); 2: the drop-in calls place theirs as well; 0: arrays wherever the allocator puts them"),
+    OPT_INT("PB_PLACE_MAX_MS", pb_place_max_ms, 0, 60000, "PB_PLACE: what the search for an arrangement may take before the arrays are allocated as ever (ms; the slabs it allocates included -- 0.3 ms per 16 GB on most boxes, 2 s on some)"),
     OPT_FLAG("PB_PROBE_FAIL", pb_probe_fail, "1 (tests): treat the run-time LDS-order probe as failed, i.e. select the architected-order phase 2"),
     OPT_FLAG("PB_STRICT", pb_strict, "1: phase 2 adds a row's products of one wave instruction rank by rank (architected order, +10 %)"),
     {"FUSED", K_LLONG, nullptr, &Config::fused, 0, 1LL << 40, nullptr,

@@ -34,6 +34,7 @@ struct Config {
     int pb_fill_occ = 0;          // PB_FILL_OCC        resident waves per CU of the two-pass fill's first pass (0: 8)
     int pb_fill2 = 1;             // PB_FILL2           0: the blocked copy is filled by the single-pass kernel of rounds 1-4
     int pb_place = 1;             // PB_PLACE           large blocked copies: product stream in a memory class of its own (1: resident solvers, 2: drop-in calls too, 0: off)
+    int pb_place_max_ms = 300;    // PB_PLACE_MAX_MS    what the placement search may take (allocations included: some boxes allocate at 8 GB/s)
     int pb_probe_fail = 0;        // PB_PROBE_FAIL      1 (tests): the LDS-order probe reports "not lane order"
     int pb_strict = 0;            // PB_STRICT          1: phase 2 adds a row's products of one wave instruction rank by rank (architected order)
     // ---- loop forms

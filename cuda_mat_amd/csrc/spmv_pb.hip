@@ -660,6 +660,7 @@ int pb_build_alloc(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int
         b->NG = (p.NCB + b->GB - 1) / b->GB;
         b->fill_occ = cfg.pb_fill_occ;
         b->place = cfg.pb_place;
+        b->place_max_seconds = 1e-3 * cfg.pb_place_max_ms;
         b->verbose = cfg.verbose != 0;
         b->two_pass = cfg.pb_fill2 != 0 && nnz > 0 && nnz < 0x7fffffffLL && p.SR <= 65536 && b->GB <= 64;
         if (b->two_pass) {
@@ -722,7 +723,7 @@ int pb_build_count(hipStream_t st, const Config &cfg, const int *rp, const int *
 // 2 GB blocks (from the segment's start), every block is classified by timing (read a known block of class k, write this
 // one: slow = same class; <= 2 launches of 0.4 ms per block, remembered per address), and the arrays are cut out of runs
 // of blocks: the product stream in a class of its own, values and indices in another.  What is not used goes back to the
-// pool.  Bounded (<= 96 GB held, <= 0.3 s); if no such arrangement turns up the arrays are allocated as before round 5.
+// pool.  Bounded (<= 96 GB held, <= PB_PLACE_MAX_MS = 0.3 s); if no such arrangement turns up the arrays are allocated as before round 5.
 __global__ __launch_bounds__(1024) void k_place_probe(const double2 *rd, double2 *wr, long n2)
 {
     const long per = (n2 + gridDim.x - 1) / gridDim.x;
@@ -770,20 +771,19 @@ constexpr size_t kPlaceSample = (size_t)896 << 20;        // bytes read and byte
 constexpr size_t kPlaceSlab = (size_t)16 << 30;
 constexpr size_t kPlaceMinBytes = (size_t)2 << 30;        // copies whose product stream is smaller are not placed
 constexpr size_t kPlaceMaxHeld = (size_t)96 << 30;
-constexpr double kPlaceMaxSeconds = 0.3;
 constexpr float kPlaceRatio = 0.97f;                      // another class: reading the reference beside the writes takes less than this
                                                           // fraction of reading and writing inside one block (measured: 0.93-0.95 / 1.0)
 
 // what is known about pooled addresses: the class of every 2 GB block met so far, one reference block per class, the time of
 // a sample read and written inside one block.  Forgotten when the pool hands a segment back to the driver.
 struct PlaceMemo {
-    std::mutex mu;
     unsigned gen = ~0u;
     std::map<char *, int> cls;
     std::vector<char *> ref;
     float t_own = 0.f;
 };
-static PlaceMemo g_place;
+static std::mutex g_place_mu;
+static std::map<int, PlaceMemo> g_place;          // per device (a reference block is read by the probe: it has to be local)
 
 struct PlaceRun { size_t slab; size_t first, count; int cls; };      // blocks [first, first + count) of one slab, all of one class
 
@@ -840,7 +840,7 @@ static bool place_find(std::vector<PlaceSlab> &slabs, size_t need, int want, int
 
 // the four big arrays of a copy, placed (see above).  sizes in bytes; vals / idx / prod receive pointers that are pooled blocks
 // of their own (freed one by one as ever).  CUDAMAT_OK with *placed = false: nothing allocated, allocate as before.
-static int place_copy(hipStream_t st, bool verbose, size_t b_vals, size_t b_idx, size_t b_prod, void **vals, void **pc, void **pr, void **prod, bool *placed,
+static int place_copy(hipStream_t st, bool verbose, double max_seconds, size_t b_vals, size_t b_idx, size_t b_prod, void **vals, void **pc, void **pr, void **prod, bool *placed,
                       PbPlan *report)
 {
     *placed = false;
@@ -848,8 +848,10 @@ static int place_copy(hipStream_t st, bool verbose, size_t b_vals, size_t b_idx,
     const double t0 = now_s();
     PlaceTimer tm(st);
     if (!tm.ok) return CUDAMAT_OK;
-    std::lock_guard<std::mutex> lock(g_place.mu);
-    PlaceMemo &m = g_place;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return CUDAMAT_OK;
+    std::lock_guard<std::mutex> lock(g_place_mu);
+    PlaceMemo &m = g_place[dev];
     if (m.gen != pool_generation()) {
         m.gen = pool_generation();
         m.cls.clear();
@@ -870,7 +872,7 @@ static int place_copy(hipStream_t st, bool verbose, size_t b_vals, size_t b_idx,
     bool found = false;
     size_t held = 0;
     while (!found) {
-        if (held + slab_bytes > kPlaceMaxHeld || now_s() - t0 > kPlaceMaxSeconds) break;
+        if (held + slab_bytes > kPlaceMaxHeld || now_s() - t0 > max_seconds) break;
         PlaceSlab sl;
         if (hipMalloc(&sl.base, slab_bytes) != hipSuccess) { CM_DROP(hipGetLastError()); break; }
         sl.bytes = slab_bytes;
@@ -961,7 +963,7 @@ int pb_build_values(hipStream_t st, PbBuild *b, const ValDict *vd)
         if (!p.P && b->place > 0 && sizeof(double) * cap >= kPlaceMinBytes) {
             void *v = nullptr, *c = nullptr, *r = nullptr, *pp = nullptr;
             bool placed = false;
-            if ((rc = place_copy(st, b->verbose, dict ? cap : sizeof(double) * cap, sizeof(u16) * cap, sizeof(double) * cap, &v, &c, &r, &pp, &placed, &p))) break;
+            if ((rc = place_copy(st, b->verbose, b->place_max_seconds, dict ? cap : sizeof(double) * cap, sizeof(u16) * cap, sizeof(double) * cap, &v, &c, &r, &pp, &placed, &p))) break;
             if (placed) {
                 if (dict) p.pvi = (unsigned char *)v; else p.pv = (double *)v;
                 p.pc = (u16 *)c;
