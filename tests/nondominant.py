@@ -238,7 +238,7 @@ def compare_loop(O, A, b, loop, vm, gpu, maxit, tol, k_nb_plain=None):
 def compare_factors(vm, lu, amax):
     """ILU(0) values of the HIP path against the oracle's; amax = max |entry of A|.  Returns (findings, digits_lost).
     The componentwise error of an elimination grows with its growth factor g = max|factor entry| / max|a_ij|: tolerance
-    max(1e-12, 1e-13 g) on every entry while g < 1e10 (the reference CLI's default workload: g = 3.4e5, measured 2.6e-12;
+    max(1e-12, 1e-13 g) on every entry (beyond an absolute 2e-14 g max|a_ij|) while g < 1e10 (the reference CLI's default workload: g = 3.4e5, measured 2.6e-12;
     soak: 5.7e-12 at g = 130, 9.4e-12 at g = 460 -- entries that are themselves the result of a cancellation);
     beyond that the factors carry no digits (a cancellation at 1e10+ has eaten them; soak: g = 1e92 ... overflow) --
     `digits_lost`: which entries end as inf, NaN, 1e100 or 1e300 is decided by the rounding of the row updates; asserted is
@@ -254,6 +254,10 @@ def compare_factors(vm, lu, amax):
             return ([] if blew else ["the oracle's factors grow by %.1e, the GPU's do not" % g]), True
         if not np.isfinite(lu).all():
             return ["non-finite factor entries on the GPU only (oracle growth %.1e)" % g], False
-        rel = np.abs(lu - vm) / np.maximum(np.abs(vm), 1e-300)
-    tolf = max(1e-12, 1e-13 * g)
-    return ([] if rel.max() <= tolf else ["factors differ by %.2e (growth %.1e: tolerance %.1e)" % (rel.max(), g, tolf)]), False
+        tolf = max(1e-12, 1e-13 * g)
+        # an entry that is itself what a cancellation left (|entry| << the terms of its row update) carries the ABSOLUTE error
+        # of those terms: 2e-14 of the largest magnitude in play (soak seed 601 case 75: g = 1.2, every entry but a handful
+        # to 1e-13, one small entry 1.96e-12 off in relative terms)
+        excess = np.abs(lu - vm) - 2e-14 * amax * max(1.0, g)
+        rel = np.maximum(excess, 0.0) / np.maximum(np.abs(vm), 1e-300)
+    return ([] if rel.max() <= tolf else ["factors differ by %.2e beyond the absolute term (growth %.1e: tolerance %.1e)" % (rel.max(), g, tolf)]), False

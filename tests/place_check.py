@@ -35,6 +35,8 @@ def main():
         s = cm.Solver(ctx, n, n, n * per, rp, ci, va, 0)
         s.spmv(x, y)
         assert s.spmv_mode() == 1
+        pl = s.placement()
+        assert pl["placed"] == (1 if place == "1" else -1) and (pl["slabs"] >= 1) == (place == "1"), pl
         out = y.download()
         s.close()
         assert lib.cudamat_pool_trim() == 0

@@ -23,7 +23,7 @@ divide whatever they get).  What CAN agree between two correct implementations t
     non-finite residual (or the |omega| guard of :735); a run that reports convergence is backed by its true residual as
     well as the oracle's converged runs are.
  4. ILU(0) factors with small pivots (down to 2.5e-4 after cancellation among entries of size 1..10): every entry to
-    max(1e-12, 1e-13 g), g = the growth factor max|factor entry| / max|a_ij| (the default workload: g = 3.4e5, measured
+    max(1e-12, 1e-13 g) beyond an absolute 2e-14 g max|a_ij| (entries that a cancellation left), g = the growth factor max|factor entry| / max|a_ij| (the default workload: g = 3.4e5, measured
     2.6e-12; the row updates use fma on the GPU and two roundings in the oracle); beyond g = 1e10 the factors carry no
     digits (example1000_p90 overflows to 4e252): asserted is that the GPU's factorisation blows up as well, and the
     preconditioned loop is then held to the meaning of its flags only (tests/nondominant.py compare_factors).
