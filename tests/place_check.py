@@ -19,6 +19,7 @@ def main():
     for place in ("1", "0", "1"):
         ctx = cm.Context(0)
         ctx.set_option("VALUE_DICT", "0").set_option("SPMV_MODE", "pb").set_option("PB_PLACE", place).set_option("VERBOSE", "1")
+        ctx.set_option("PB_PLACE_MAX_MS", "30000")          # (boxes whose allocator takes 0.5 - 2 s for a 16 GB slab: the default budget would give up)
 
         def free_now():
             ctx.sync()
