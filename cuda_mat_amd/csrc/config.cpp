@@ -36,7 +36,7 @@ struct Option {
 #define OPT_ENUM(NAME, FIELD, WORDS, HELP) {NAME, K_ENUM, &Config::FIELD, nullptr, 0, 0, WORDS, HELP}
 
 const Option kOptions[] = {
-    OPT_FLAG("VERBOSE", verbose, "set-up breakdowns and auto-tune timings on stderr"),
+    OPT_INT("VERBOSE", verbose, 0, 2, "1: set-up breakdowns and auto-tune timings on stderr; 2: also the memory classes of a large blocked copy's arrays (timed probe, diagnosis)"),
     OPT_FLAG("ROCTX", roctx, "roctx ranges around solver creation, SpMV-form choice, ILU(0) set-up, the loop, SpMVs and all-reduces"),
     OPT_ENUM("SPMV_MODE", spmv_mode, "csr=0,pb=1,sell=2,pat=3", "force the CSR forms / the blocked two-phase form / SELL-C-sigma / the row-pattern dictionary"),
     OPT_FLAG("SPMV_SELL", spmv_sell, "0: keep SELL-C-sigma out of the candidates"),

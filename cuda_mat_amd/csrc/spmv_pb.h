@@ -71,6 +71,7 @@ struct PbBuild {
     // per entry between the passes (the values travel in the product stream), first entry of every (sub-block, group) bucket
     bool two_pass = false;
     int place = 0;             // Config::pb_place
+    bool report_classes = false;      // VERBOSE >= 2
     double place_max_seconds = 0.3;
     int fill_occ = 0;          // Config::pb_fill_occ: resident waves per CU of pass A (0: default)
     int GB = 1, NG = 1;

@@ -662,6 +662,7 @@ int pb_build_alloc(hipStream_t st, const Config &cfg, int n, int64_t n_cols, int
         b->place = cfg.pb_place;
         b->place_max_seconds = 1e-3 * cfg.pb_place_max_ms;
         b->verbose = cfg.verbose != 0;
+        b->report_classes = cfg.verbose >= 2;
         b->two_pass = cfg.pb_fill2 != 0 && nnz > 0 && nnz < 0x7fffffffLL && p.SR <= 65536 && b->GB <= 64;
         if (b->two_pass) {
             if (dalloc(&b->smeta, (size_t)nnz) != CUDAMAT_OK || dalloc(&b->gstart, (size_t)p.NSUB * (size_t)(b->NG + 1)) != CUDAMAT_OK) {
@@ -702,6 +703,7 @@ int pb_build_count(hipStream_t st, const Config &cfg, const int *rp, const int *
             rc = CUDAMAT_ERR_ARG; set_error("pb_build: counted %d entries, expected %lld", counted, (long long)nnz); break;
         }
         b->verbose = cfg.verbose != 0;
+        b->report_classes = cfg.verbose >= 2;
     } while (0);
     if (rc) pb_build_abort(b);
     return rc;
@@ -771,8 +773,7 @@ constexpr size_t kPlaceSample = (size_t)896 << 20;        // bytes read and byte
 constexpr size_t kPlaceSlab = (size_t)16 << 30;
 constexpr size_t kPlaceMinBytes = (size_t)2 << 30;        // copies whose product stream is smaller are not placed
 constexpr size_t kPlaceMaxHeld = (size_t)96 << 30;
-constexpr float kPlaceRatio = 0.97f;                      // another class: reading the reference beside the writes takes less than this
-                                                          // fraction of reading and writing inside one block (measured: 0.93-0.95 / 1.0)
+constexpr float kPlaceGap = 1.035f;                       // two groups of cross timings: slowest / fastest beyond this (measured: 1.06-1.07)
 
 // what is known about pooled addresses: the class of every 2 GB block met so far, one reference block per class, the time of
 // a sample read and written inside one block.  Forgotten when the pool hands a segment back to the driver.
@@ -780,7 +781,11 @@ struct PlaceMemo {
     unsigned gen = ~0u;
     std::map<char *, int> cls;
     std::vector<char *> ref;
-    float t_own = 0.f;
+    float t_own = 0.f;                                 // read + write inside the first block (reported only)
+    float t_lo = 0.f, t_hi = 0.f;                      // fastest / slowest cross timing met so far
+    std::vector<std::pair<char *, float>> provisional; // blocks labelled before both groups of timings had been seen
+    bool relabel = false;                              // ... some of them have just been forgotten: the caller classifies its slabs again
+    void reset() { cls.clear(); ref.clear(); provisional.clear(); t_own = t_lo = t_hi = 0.f; relabel = false; }
 };
 static std::mutex g_place_mu;
 static std::map<int, PlaceMemo> g_place;          // per device (a reference block is read by the probe: it has to be local)
@@ -795,25 +800,54 @@ struct PlaceSlab {
     std::vector<char> taken;
 };
 
-// class of the 2 GB block at `blk` (memo held by the caller's lock); -1: no verdict
+// class of the 2 GB block at `blk` (memo held by the caller's lock); -1: no verdict.  Decided by CROSS timings alone (read a
+// reference block of class k, write into this one): same class = slow.  "Slow" is relative: the timings met so far fall into
+// two groups 6-7 % apart (0.365 / 0.341 ms here); until both have been seen every block counts as the first block's class
+// (what a fresh process's first 14 GB are), and when the faster group first shows up the provisional labels are re-examined.
+// (Round 5's first version compared with a read + write INSIDE one block, which is itself up to 4 % slower than a same-class
+// cross pair: on one box in five a same-class pair passed for "another class" and the placement put all four arrays in one.)
 static int place_class_of(PlaceTimer &tm, PlaceMemo &m, char *blk)
 {
     auto it = m.cls.find(blk);
     if (it != m.cls.end()) return it->second;
-    if (m.t_own <= 0.f) {
-        m.t_own = tm.ms(blk, blk + kPlaceBlock - kPlaceSample, kPlaceSample);
+    if (m.ref.empty()) {
+        m.t_own = tm.ms(blk, blk + kPlaceBlock - kPlaceSample, kPlaceSample);          // (reported only)
         if (m.t_own <= 0.f) return -1;
-    }
-    int c = -1;
-    for (size_t k = 0; k < m.ref.size() && c < 0; k++) {
-        if (k + 1 == m.ref.size() && m.ref.size() >= 3) { c = (int)k; break; }          // (three classes: not the first two = the third)
-        const float t = tm.ms(m.ref[k], blk + kPlaceBlock - kPlaceSample, kPlaceSample);
-        if (t <= 0.f) return -1;
-        if (t >= kPlaceRatio * m.t_own) c = (int)k;
-    }
-    if (c < 0) {
-        c = (int)m.ref.size();
         m.ref.push_back(blk);
+        m.cls[blk] = 0;
+        return 0;
+    }
+    float t[3] = {0.f, 0.f, 0.f};
+    const bool was_separated = m.t_hi >= kPlaceGap * m.t_lo && m.t_lo > 0.f;
+    for (size_t k = 0; k < m.ref.size() && k < 3; k++) {
+        t[k] = tm.ms(m.ref[k], blk + kPlaceBlock - kPlaceSample, kPlaceSample);
+        if (t[k] <= 0.f) return -1;
+        if (m.t_lo <= 0.f || t[k] < m.t_lo) m.t_lo = t[k];
+        if (t[k] > m.t_hi) m.t_hi = t[k];
+    }
+    const bool separated = m.t_hi >= kPlaceGap * m.t_lo;
+    int c = 0;
+    if (separated) {
+        const float mid = sqrtf(m.t_lo * m.t_hi);
+        if (!was_separated) {
+            // the first fast pair: whoever was labelled "class 0" on the strength of a timing that now counts as fast is forgotten
+            for (auto p = m.provisional.begin(); p != m.provisional.end(); ++p)
+                if (p->second <= mid) { m.cls.erase(p->first); m.relabel = true; }
+            m.provisional.clear();
+        }
+        int slow = 0, arg = 0;
+        for (size_t k = 0; k < m.ref.size() && k < 3; k++) {
+            if (t[k] > mid) slow++;
+            if (t[k] > t[arg]) arg = (int)k;
+        }
+        if (slow == 0 && m.ref.size() < 3) {
+            c = (int)m.ref.size();
+            m.ref.push_back(blk);
+        } else {
+            c = arg;
+        }
+    } else {
+        m.provisional.push_back({blk, t[0]});
     }
     m.cls[blk] = c;
     return c;
@@ -854,8 +888,7 @@ static int place_copy(hipStream_t st, bool verbose, double max_seconds, size_t b
     PlaceMemo &m = g_place[dev];
     if (m.gen != pool_generation()) {
         m.gen = pool_generation();
-        m.cls.clear();
-        m.ref.clear();
+        m.reset();
     }
     const size_t gran = (size_t)2 << 20;
     auto up = [&](size_t x) { return (x + gran - 1) / gran * gran; };
@@ -891,6 +924,14 @@ static int place_copy(hipStream_t st, bool verbose, double max_seconds, size_t b
         }
         sl.taken.assign(sl.cls.size(), 0);
         slabs.push_back(sl);
+        if (verdicts && m.relabel) {          // provisional labels were withdrawn: every held block once more (the memo answers for most)
+            m.relabel = false;
+            for (auto &q : slabs)
+                for (size_t i = 0; i < q.cls.size() && verdicts; i++) {
+                    q.cls[i] = place_class_of(tm, m, q.b0 + i * kPlaceBlock);
+                    verdicts = q.cls[i] >= 0;
+                }
+        }
         if (!verdicts) break;
         // the product stream in a class of its own: try every class met so far for it
         for (size_t a = 0; a < m.ref.size() && !found; a++) {
@@ -1048,10 +1089,59 @@ static void pb_print_plan(const PbPlan &p)
             hist[4], hist[5], hist[6], 100.0 * (double)in_long / (double)(p.nnz > 0 ? p.nnz : 1));
 }
 
+// VERBOSE >= 2 (diagnosis): the memory class of every ~1 GB of the copy's four big arrays, found from the READ side (the arrays
+// are in use): the region is read while a free block of a known class is written; slow = that class.  Needs one free block per
+// class: slabs are taken from the pool until three classes (or 64 GB) have been met, and given back.
+static void place_report_classes(hipStream_t st, const PbPlan &p, size_t cap)
+{
+    if (!pool_enabled()) return;
+    PlaceTimer tm(st);
+    if (!tm.ok) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_place_mu);
+    PlaceMemo &m = g_place[dev];
+    if (m.gen != pool_generation()) { m.gen = pool_generation(); m.reset(); }
+    std::vector<char *> slabs;
+    std::vector<char *> scratch(3, nullptr);          // a writable block per class
+    for (int k = 0; k < 4 && !(scratch[0] && scratch[1] && scratch[2]); k++) {
+        char *base = nullptr;
+        if (hipMalloc(&base, kPlaceSlab) != hipSuccess) { CM_DROP(hipGetLastError()); break; }
+        slabs.push_back(base);
+        char *seg = nullptr;
+        size_t bytes = 0;
+        if (!pool_segment_of(base, &seg, &bytes)) break;
+        char *b0 = seg + ((size_t)(base - seg) + kPlaceBlock - 1) / kPlaceBlock * kPlaceBlock;
+        for (char *q = b0; q + kPlaceBlock <= base + bytes; q += kPlaceBlock) {
+            const int c = place_class_of(tm, m, q);
+            if (c >= 0 && c < 3 && !scratch[c]) scratch[c] = q;
+        }
+    }
+    struct Arr { const char *name; const char *ptr; size_t bytes; };
+    const Arr arrs[4] = {{"values", p.pv ? (const char *)p.pv : (const char *)p.pvi, p.pv ? sizeof(double) * cap : cap},
+                         {"col idx", (const char *)p.pc, sizeof(u16) * cap}, {"row idx", (const char *)p.pr, sizeof(u16) * cap}, {"products", (const char *)p.P, sizeof(double) * cap}};
+    for (const Arr &a : arrs) {
+        std::string line;
+        for (size_t off = 0; off + kPlaceSample <= a.bytes; off += kPlaceSample) {
+            int cls = -1;
+            float worst = 0.f;
+            for (int k = 0; k < 3; k++) {
+                if (!scratch[k]) continue;
+                const float t = tm.ms(a.ptr + off, scratch[k] + kPlaceBlock - kPlaceSample, kPlaceSample);
+                if (t > worst) { worst = t; cls = k; }
+            }
+            line += cls < 0 || !(m.t_hi >= kPlaceGap * m.t_lo) || worst <= sqrtf(m.t_lo * m.t_hi) ? '?' : (char)('0' + cls);
+        }
+        fprintf(stderr, "[cudamat] pb classes: %-8s at %p, per %zu MB: %s\n", a.name, (const void *)a.ptr, kPlaceSample >> 20, line.c_str());
+    }
+    for (char *q : slabs) CM_DROP(hipFree(q));
+}
+
 int pb_build_end(hipStream_t st, PbBuild *b, PbPlan *out)
 {
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("pb fill failed"); pb_build_abort(b); return CUDAMAT_ERR_HIP; }
     if (b->verbose) pb_print_plan(b->p);
+    if (b->report_classes && sizeof(double) * b->cap >= kPlaceMinBytes) place_report_classes(st, b->p, b->cap);
     pb_scratch_free(b);
     CM_DROP(hipFree(b->bins));
     b->bins = nullptr;

@@ -11,8 +11,9 @@ import json, sys
 d = json.loads(open("gpurun_out/headline_state_%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
 g, r = d.get("gpu_state") or {}, d["roofline"]
 c = r["measured_stream_ceiling"]
-print("run %s: %.1f it/s  spmv %.3f ms  triad %.0f read %.0f GB/s  sclk %s  power %s  junction %s  hbm %s  %s" % (
-    sys.argv[1], d["value"], r["avg_launch_ms"], c["gbs"], c["read_gbs"], g.get("sclk_mhz"), g.get("power_w"), g.get("junction_c"), g.get("hbm_c"),
-    (d.get("host_placement") or {}).get("gpu_pci")), flush=True)
+m = d.get("memory_placement") or {}
+print("run %s: %.1f it/s  spmv %.3f ms  triad %.0f read %.0f GB/s  sclk %s  power %s  hbm %s  %s  placed %s in %.3f s (%s)" % (
+    sys.argv[1], d["value"], r["avg_launch_ms"], c["gbs"], c["read_gbs"], (g.get("sclk_mhz") or {}).get("median"), (g.get("power_w") or {}).get("median"),
+    (g.get("hbm_c") or {}).get("median"), (d.get("host_placement") or {}).get("gpu_pci"), m.get("placed"), m.get("seconds", 0.0), m.get("blocks_by_class")), flush=True)
 PY
 done
