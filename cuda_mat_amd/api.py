@@ -349,8 +349,8 @@ class Solver:
     def placement(self):
         """where the blocked copy's arrays went: {"placed": 1 / 0 / -1 (not tried), "slabs", "seconds", "classes"} (include/cudamat.h)"""
         placed, slabs, sec = C.c_int(), C.c_int(), C.c_double()
-        buf = C.create_string_buffer(128)
-        check(_lib.lib().cudamat_solver_placement(self.h, C.byref(placed), C.byref(slabs), C.byref(sec), buf, 128))
+        buf = C.create_string_buffer(256)
+        check(_lib.lib().cudamat_solver_placement(self.h, C.byref(placed), C.byref(slabs), C.byref(sec), buf, 256))
         return {"placed": placed.value, "slabs": slabs.value, "seconds": sec.value, "blocks_by_class": buf.value.decode().strip()}
 
     def value_dict(self):

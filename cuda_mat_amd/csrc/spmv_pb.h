@@ -51,7 +51,8 @@ struct PbPlan {
     int placed = -1;               // -1: not tried (small copy / PB_PLACE=0); 0: no arrangement found; 1: product stream in a memory class of its own
     int place_slabs = 0;           // slabs of device memory the placement search classified
     double place_seconds = 0.0;
-    char place_classes[96] = {0};  // their 2 GB blocks by class, e.g. "00000000 11112222"
+    float place_check_ms = 0.f, place_fast_ms = 0.f, place_slow_ms = 0.f;      // the final check's timing between the two groups' extremes
+    char place_classes[192] = {0};  // their 2 GB blocks by class, e.g. "00000000 11112222"
     bool pc_zeroed = false;        // (construction: the alignment pads of pc are in place)
     double build_seconds = 0.0;
 };

@@ -310,7 +310,8 @@ int cudamat_solver_spmv_kernel(cudamat_solver *s, char *name, int cap);
  * array while it writes another loses 5-7 % when both lie in one class, so the product stream of a large copy is placed in a
  * class of its own.  *placed: 1 placed, 0 searched without finding an arrangement, -1 not tried (another SpMV form, a copy
  * below 2 GB of products, PB_PLACE = 0, a drop-in call without PB_PLACE = 2); *slabs: 16 GB slabs classified; *seconds: what
- * the search took; classes: their 2 GB blocks by class ("00000000 11112222"), at most cap - 1 characters.            */
+ * the search took; classes: their 2 GB blocks by class ("00000000 11112222"), then the final check's timing (values read beside
+ * writes into the product stream) between the fastest and slowest pair met, at most cap - 1 characters.            */
 int cudamat_solver_placement(cudamat_solver *s, int *placed, int *slabs, double *seconds, char *classes, int cap);
 /* y_local = (A + diag(d)) x ; x is the LOCAL slice, gathered through comm if sharded  */
 int cudamat_solver_spmv(cudamat_solver *s, const double *x_local, double *y_local);
