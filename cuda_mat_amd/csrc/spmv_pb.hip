@@ -911,7 +911,7 @@ static int place_copy(hipStream_t st, bool verbose, double max_seconds, size_t b
     std::vector<PlaceSlab> slabs;
     PlaceRun r_prod{}, r_vals{};
     float check_ms = 0.f;
-    bool found = false;
+    bool found = false, verified = false;
     size_t held = 0;
     while (!found) {
         if (held + slab_bytes > kPlaceMaxHeld || now_s() - t0 > max_seconds) break;
@@ -983,7 +983,8 @@ static int place_copy(hipStream_t st, bool verbose, double max_seconds, size_t b
             for (const Keep &k : keeps) *k.out = k.p;
             // the arrangement once more, directly: the values read beside writes into the product stream must time with the fast group
             const float t_check = tm.ms(p_vals, p_prod + kPlaceBlock - kPlaceSample, kPlaceSample);
-            *placed = t_check > 0.f && m.t_hi >= kPlaceGap * m.t_lo && t_check < sqrtf(m.t_lo * m.t_hi);
+            *placed = true;          // (the arrays are the caller's now, whatever the check says)
+            verified = t_check > 0.f && m.t_hi >= kPlaceGap * m.t_lo && t_check < sqrtf(m.t_lo * m.t_hi);
             check_ms = t_check;
         }
     }
@@ -994,7 +995,7 @@ static int place_copy(hipStream_t st, bool verbose, double max_seconds, size_t b
         for (int c : sl.cls) seen += c < 0 ? '?' : (char)('0' + c % 10);
         seen += ' ';
     }
-    report->placed = *placed ? 1 : 0;
+    report->placed = *placed && verified ? 1 : 0;
     report->place_check_ms = check_ms;
     report->place_fast_ms = m.t_lo;
     report->place_slow_ms = m.t_hi;
@@ -1003,7 +1004,7 @@ static int place_copy(hipStream_t st, bool verbose, double max_seconds, size_t b
     snprintf(report->place_classes, sizeof(report->place_classes), "%s| check %.3f ms, groups %.3f / %.3f ms", seen.c_str(), check_ms, m.t_lo, m.t_hi);
     if (verbose) {
         fprintf(stderr, "[cudamat] pb placement: %s; %zu slab(s) of %.0f GB, blocks by class: %s, %d timed launches, %.1f ms (one block read + written: %.3f ms)\n",
-                *placed ? "product stream in a memory class of its own, values and indices in another" : found ? "an arrangement was cut, but its own check timed slow (classes misjudged?)" : "no arrangement found: arrays allocated one after the other",
+                *placed && verified ? "product stream in a memory class of its own, values and indices in another" : *placed ? "an arrangement was cut, but its own check timed slow (classes misjudged?)" : "no arrangement found: arrays allocated one after the other",
                 slabs.size(), (double)slab_bytes / (double)((size_t)1 << 30), seen.c_str(), tm.launches, (now_s() - t0) * 1e3, m.t_own);
     }
     return CUDAMAT_OK;
